@@ -1,0 +1,35 @@
+# Top-level build: the gfx950 product library, the C++ host, and (test infrastructure) the CPU oracle.
+#
+#   make            -> rbrt_amd/lib/librbrt_hip.so  (HIP kernels + C ABI)   [hipcc, gfx950 only]
+#                      rbrt_amd/lib/librbrt_host.so, rbrt_amd/bin/rbrt      [C++ host: CLI/YAML/OBJ/PNG]
+#                      oracle/librbrt_oracle.so                            [CPU checker, tests only]
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+
+# -ffp-contract=off is load-bearing: hipcc's default (fast-honor-pragmas) would fuse mul+add into FMA
+# and the radiance would no longer match the reference's unfused f32 arithmetic (vec3_avx.rs:18-21).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+            -Wall -Wextra -Wno-unused-parameter
+CSRC := rbrt_amd/csrc
+LIBDIR := rbrt_amd/lib
+BINDIR := rbrt_amd/bin
+
+all: $(LIBDIR)/librbrt_hip.so host oracle
+
+$(LIBDIR)/librbrt_hip.so: $(CSRC)/kernels.hip $(CSRC)/api.cpp $(CSRC)/bvh.cpp $(CSRC)/bvh.h \
+                          $(CSRC)/device_types.h include/rbrt_hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/api.cpp $(CSRC)/bvh.cpp
+
+host:
+	@if [ -f rbrt_amd/host/Makefile ]; then $(MAKE) -C rbrt_amd/host; fi
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(LIBDIR) $(BINDIR)
+	$(MAKE) -C oracle clean
+
+.PHONY: all host oracle clean

@@ -1,0 +1,230 @@
+/*
+ * rbrt_hip.h — C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * This is the drop-in boundary for the ONE call the reference makes into its
+ * render hot path:
+ *
+ *     rbrt_lib::render_scene(cam: Camera, num_samples: u32, scene: Scene)
+ *         -> image::ImageBuffer<Rgb<u8>, Vec<u8>>          (rbrt_lib/src/lib.rs:75-79,
+ *                                                           called at src/main.rs:82)
+ *
+ * Everything below is plain-old-data: borrowed pointers + sizes, no callbacks,
+ * no C++/torch types. A Rust host binds it with an `extern "C"` block (see
+ * INTEGRATION.md); the C++ host in rbrt_amd/host/ and the Python ctypes mirror
+ * in rbrt_amd/abi.py bind the same symbols.
+ *
+ * Conventions
+ *   - every entry point returns 0 (RBRT_OK) or a negative rbrt_status_t; it never
+ *     aborts or throws across the boundary. rbrt_hip_last_error() returns a
+ *     thread-local human-readable message for the last failure.
+ *   - all pointers are borrowed for the duration of the call only (scene_create
+ *     copies what it needs to the device before returning).
+ *   - images are row-major, row 0 = TOP row, 3 channels interleaved (RGB):
+ *       radiance: float[H][W][3]  — linear, pre-gamma mean over samples (lib.rs:95-101)
+ *       rgb8    : uint8[H][W][3]  — (sqrt(c)*256) saturating cast (lib.rs:116-122)
+ *   - there is NO CPU fallback: without a usable HIP device every render entry
+ *     point fails with RBRT_ERR_NO_DEVICE.
+ */
+#ifndef RBRT_HIP_H
+#define RBRT_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBRT_ABI_VERSION 1
+
+typedef enum rbrt_status {
+    RBRT_OK = 0,
+    RBRT_ERR_INVALID_ARG = -1,
+    RBRT_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init */
+    RBRT_ERR_HIP = -3,         /* a HIP call failed; see rbrt_hip_last_error() */
+    RBRT_ERR_OOM = -4,
+    RBRT_ERR_UNSUPPORTED = -5, /* e.g. max_depth above the kernel's compiled limit */
+    RBRT_ERR_NAN = -6          /* reference would have panicked: sphere.rs:33 "Encountered NAN" */
+} rbrt_status_t;
+
+/* Material = the closed set the reference's YAML factory can build
+ * (blueprints.rs:50-74); replaces `Box<dyn RayScattering + Sync>` (materials.rs:4-12). */
+typedef enum rbrt_material_kind {
+    RBRT_MAT_LAMBERTIAN = 0, /* lambertian.rs:11-24: albedo            */
+    RBRT_MAT_METAL = 1,      /* metal.rs:12-25     : albedo, param=roughness */
+    RBRT_MAT_DIELECTRIC = 2  /* dielectric.rs:11-59: param=ref_idx     */
+} rbrt_material_kind_t;
+
+typedef struct rbrt_material {
+    int32_t kind;    /* rbrt_material_kind_t */
+    float albedo[3]; /* ignored for dielectric (attenuation is (1,1,1), dielectric.rs:18) */
+    float param;     /* metal: roughness; dielectric: ref_idx; lambertian: unused */
+} rbrt_material_t;
+
+/* sphere.rs:6-10 */
+typedef struct rbrt_sphere {
+    float center[3];
+    float radius;
+    rbrt_material_t mat;
+} rbrt_sphere_t;
+
+/* mesh.rs:12-25 as produced by convert_to_soa_mesh (mesh.rs:123-181).
+ * Every SoA array has n_total = N + N % 8 entries (the reference's padding rule,
+ * mesh.rs:134-144, kept as is). The library applies the chunks_exact(8)
+ * truncation of triangle.rs:166-167 itself: only the first 8*floor(n_total/8)
+ * entries are ever tested, and entries with is_padding[i] != 0 never win
+ * (triangle.rs:400). vertices[1], vertices[2] of the reference struct are never
+ * read on the hot path and are not part of the ABI. */
+typedef struct rbrt_mesh {
+    uint32_t n_total;          /* length of each array below */
+    uint32_t n_real;           /* N = triangles loaded from the .obj (informational) */
+    const float* v0x;          /* vertices[0][0..2]  (triangle.rs:177-179) */
+    const float* v0y;
+    const float* v0z;
+    const float* e1x;          /* edges[0][0..2] = v1 - v0 (mesh.rs:57-60) */
+    const float* e1y;
+    const float* e1z;
+    const float* e2x;          /* edges[1][0..2] = v2 - v0 */
+    const float* e2y;
+    const float* e2z;
+    const float* nx;           /* normals[0..2] = normalize(e1 x e2) (triangle.rs:30-34) */
+    const float* ny;
+    const float* nz;
+    const uint8_t* is_padding; /* mesh.rs:138-144 */
+    float bbox_lo[3];          /* BoundingBox of the N real triangles (mesh.rs:62, aabbox.rs:62-88) */
+    float bbox_hi[3];
+    rbrt_material_t mat;       /* one material per mesh (mesh.rs:24) */
+} rbrt_mesh_t;
+
+/* scene.rs:12-16 (lights are always empty in the reference: blueprints.rs:151) */
+typedef struct rbrt_scene {
+    uint32_t n_spheres;
+    const rbrt_sphere_t* spheres; /* Scene::elements, YAML order (scene.rs:23-31) */
+    uint32_t n_meshes;
+    const rbrt_mesh_t* meshes;    /* Scene::triangle_meshes, YAML order (scene.rs:33-41) */
+} rbrt_scene_t;
+
+/* The 8 of Camera's 14 fields (cam.rs:4-19) that get_ray_through_pixel (cam.rs:64-82) reads. */
+typedef struct rbrt_camera {
+    float position[3];
+    float right[3];
+    float up[3]; /* raw YAML vector, not normalised (cam.rs:55,75) */
+    float img_center_point[3];
+    float mm_per_pix_hor;
+    float mm_per_pix_vert;
+    uint32_t img_width_pix;
+    uint32_t img_height_pix;
+} rbrt_camera_t;
+
+/* Values the reference hard-codes are fields here with those defaults
+ * (rbrt_render_opts_default): max depth 50 (lib.rs:99), min/max dist
+ * (lib.rs:44-45), background (lib.rs:89-93). `seed` replaces the reference's
+ * OS-seeded rand::random (cam.rs:69,71; materials.rs:17-19; dielectric.rs:48):
+ * the random stream of sample s of pixel (row, col) is a pure function of
+ * (seed, row*W+col, s), consumed in the reference's draw order. */
+typedef struct rbrt_render_opts {
+    uint32_t spp;       /* num_samples */
+    uint32_t max_depth; /* 50 */
+    float min_dist;     /* 0.001 */
+    float max_dist;     /* 2000.0 */
+    float bg[3];        /* (0.05, 0.05, 0.8) */
+    uint64_t seed;
+    /* pixel-tile sharding for multi-GPU: 8x8 tiles in row-major tile order are
+     * dealt round-robin, this call renders tiles t with t % tile_world == tile_rank.
+     * tile_world <= 1 renders the whole image. */
+    uint32_t tile_rank;
+    uint32_t tile_world;
+    uint32_t flags;     /* RBRT_FLAG_* */
+    uint32_t reserved;
+} rbrt_render_opts_t;
+
+#define RBRT_FLAG_NONE 0u
+#define RBRT_FLAG_COLLECT_STATS 1u /* run the counting variant of the kernel (slower); see rbrt_hip_stats_t */
+
+#define RBRT_TILE 8u /* tile edge in pixels used for sharding and work ordering */
+
+/* Per-render work counters from the counting kernel variant: the inputs of the
+ * algorithmic-bytes figure ("Measurement"). */
+typedef struct rbrt_hip_stats {
+    uint64_t rays;            /* Scene::hit calls (scene.rs:19) */
+    uint64_t mesh_gate_pass;  /* rays x meshes that passed BoundingBox::hit (aabbox.rs:28-58) */
+    uint64_t nodes_visited;   /* BVH node records fetched */
+    uint64_t tris_tested;     /* Moller-Trumbore evaluations (triangle.rs:189-255 per lane) */
+    uint64_t mesh_hits;       /* accepted mesh hits (normal fetch, mesh.rs:253-257) */
+    uint64_t samples;         /* paths traced */
+    uint64_t nan_discriminants; /* sphere.rs:33 would have panicked */
+    uint32_t node_bytes;      /* size of one BVH node record */
+    uint32_t tri_bytes;       /* size of one device triangle record */
+} rbrt_hip_stats_t;
+
+typedef struct rbrt_hip_scene rbrt_hip_scene_t; /* opaque: device-resident scene + BVH + workspace */
+
+/* ---- one-shot convenience: the closest analogue of lib.rs:75-79 --------------------------- */
+
+/* Renders the whole image (tile_world ignored unless > 1, then only this rank's tiles are
+ * written and all other pixels are left untouched). out_radiance and out_rgb8 are HOST buffers of
+ * H*W*3 elements; either may be NULL. */
+int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene,
+                    const rbrt_render_opts_t* opts, float* out_radiance, uint8_t* out_rgb8);
+
+/* ---- resident scene: upload + BVH build once, render many times --------------------------- */
+
+int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** out);
+int rbrt_hip_scene_destroy(rbrt_hip_scene_t* scene);
+
+/* Number of pixels this rank owns for a W x H image under (tile_rank, tile_world), counting
+ * the padded pixels of partial edge tiles (each tile contributes RBRT_TILE*RBRT_TILE slots). */
+size_t rbrt_hip_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_world);
+
+/* Renders into DEVICE memory on `stream` (a hipStream_t, may be NULL = default stream) and
+ * returns without synchronising.
+ *   d_radiance: if tile_world <= 1: float[H][W][3] row-major.
+ *               else: this rank's tiles packed, float[n_local_tiles][64][3] (tile-local pixel
+ *               p = (y%8)*8 + (x%8)); feed the gathered buffers to rbrt_hip_unpack_tiles.
+ *   d_rgb8    : same indexing with uint8 elements; may be NULL. d_radiance may be NULL too. */
+int rbrt_hip_render_device(rbrt_hip_scene_t* scene, const rbrt_camera_t* cam,
+                           const rbrt_render_opts_t* opts, void* stream, float* d_radiance,
+                           uint8_t* d_rgb8);
+
+/* De-interleave gathered per-rank packed tile buffers (concatenated rank 0..world-1, each
+ * rbrt_hip_packed_pixels(...)*3 floats, device memory) into a row-major float[H][W][3] device
+ * image and/or its uint8 quantisation. Runs on `stream`. */
+int rbrt_hip_unpack_tiles(int device, void* stream, const float* d_gathered, uint32_t width,
+                          uint32_t height, uint32_t tile_world, float* d_radiance, uint8_t* d_rgb8);
+
+/* Counters of the last render on this scene that had RBRT_FLAG_COLLECT_STATS set. */
+int rbrt_hip_scene_stats(rbrt_hip_scene_t* scene, rbrt_hip_stats_t* out);
+
+/* Test / diagnostic hook for Scene::hit (scene.rs:19-43): closest hit of n rays against the
+ * resident scene. Host arrays. rays = n x {ox,oy,oz,dx,dy,dz}. Outputs (each may be NULL):
+ *   out_t[n]      ray parameter of the winning object (NaN on miss)
+ *   out_obj[n]    -1 on miss, sphere index in [0,n_spheres), or n_spheres + mesh index
+ *   out_tri[n]    winning triangle index (reference numbering) for mesh hits, else -1
+ *   out_dist[n]   dist_from_ray_orig of the winner (lib.rs:35)                            */
+int rbrt_hip_trace_rays(rbrt_hip_scene_t* scene, const float* rays, size_t n, float min_dist,
+                        float max_dist, float* out_t, int32_t* out_obj, int32_t* out_tri,
+                        float* out_dist);
+
+/* Diagnostic: run the host-side BVH builder alone (needs no device). *nodes_out / *tris_out are
+ * malloc'ed copies of the 64-B node and 48-B triangle records (layout: rbrt_amd/csrc/device_types.h);
+ * release them with rbrt_hip_free_host. */
+int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
+                            size_t* n_tris, uint32_t* max_depth, float* max_e12);
+void rbrt_hip_free_host(void* p);
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+
+void rbrt_render_opts_default(rbrt_render_opts_t* opts); /* spp = 5 (src/main.rs:47), seed = 1 */
+int rbrt_hip_device_count(void);                         /* >= 0, or negative status */
+const char* rbrt_hip_last_error(void);
+int rbrt_hip_abi_version(void);
+/* Most recent kernel timing of this scene handle in milliseconds, measured with HIP events
+ * recorded on the launch stream around the render kernel only (requires a prior
+ * rbrt_hip_scene_set_timing(scene, 1); reading it synchronises on the stop event). */
+int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* scene, int enable);
+int rbrt_hip_scene_last_kernel_ms(rbrt_hip_scene_t* scene, float* trace_ms, float* resolve_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBRT_HIP_H */

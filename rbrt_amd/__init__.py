@@ -1,0 +1,109 @@
+"""rbrt_amd — MI355X (gfx950) implementation of baurst/rbrt's path-tracing hot path.
+
+The product is the C ABI in include/rbrt_hip.h (rbrt_amd/lib/librbrt_hip.so: hand-written HIP
+kernels + host BVH builder) and the C++ host in rbrt_amd/host (CLI, YAML, .obj, PNG). This Python
+package is a thin ctypes binding over those for tests and bench.py.
+
+    render_scene(cam, num_samples, scene)  <->  rbrt_lib::render_scene (lib.rs:75-79)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .abi import (Camera, Material, RenderOpts, RbrtError, SceneData, MeshData, default_opts, load_hip,  # noqa: F401
+                  material, MAT_DIELECTRIC, MAT_LAMBERTIAN, MAT_METAL)
+
+__all__ = ["render_scene", "HipScene", "abi", "device_count"]
+
+
+def device_count() -> int:
+    return int(load_hip().rbrt_hip_device_count())
+
+
+def render_scene(cam: abi.Camera, num_samples: int, scene: abi.SceneData, seed: int = 1, **opt_overrides):
+    """One-shot render through rbrt_hip_render (host buffers in and out).
+
+    Same contract as the reference's render_scene (lib.rs:75-79) plus the pre-gamma radiance:
+    returns (radiance float32[H,W,3], rgb8 uint8[H,W,3]).
+    """
+    lib = load_hip()
+    opts = default_opts(spp=num_samples, seed=seed, **opt_overrides)
+    H, W = cam.img_height_pix, cam.img_width_pix
+    rad = np.zeros((H, W, 3), np.float32)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    rc = lib.rbrt_hip_render(C.byref(cam), scene.ptr(), C.byref(opts), rad.ctypes.data_as(abi.f32p),
+                             rgb.ctypes.data_as(abi.u8p))
+    abi.check(rc)
+    return rad, rgb
+
+
+class HipScene:
+    """Device-resident scene (rbrt_hip_scene_create): upload + BVH build once, render many times."""
+
+    def __init__(self, scene: abi.SceneData, device: int = 0):
+        self._lib = load_hip()
+        self._h = C.c_void_p()
+        self.device = device
+        self.scene = scene  # keep host arrays alive
+        abi.check(self._lib.rbrt_hip_scene_create(scene.ptr(), device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.rbrt_hip_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def render_device(self, cam: abi.Camera, opts: abi.RenderOpts, d_radiance: int | None, d_rgb8: int | None = None,
+                      stream: int | None = None):
+        """Asynchronous render into device pointers (ints, e.g. torch.Tensor.data_ptr())."""
+        abi.check(self._lib.rbrt_hip_render_device(self._h, C.byref(cam), C.byref(opts), C.c_void_p(stream or 0),
+                                                   C.c_void_p(d_radiance or 0), C.c_void_p(d_rgb8 or 0)))
+
+    def set_timing(self, on: bool = True):
+        abi.check(self._lib.rbrt_hip_scene_set_timing(self._h, int(on)))
+
+    def last_kernel_ms(self):
+        t, r = C.c_float(), C.c_float()
+        abi.check(self._lib.rbrt_hip_scene_last_kernel_ms(self._h, C.byref(t), C.byref(r)))
+        return t.value, r.value
+
+    def stats(self) -> dict:
+        st = abi.Stats()
+        abi.check(self._lib.rbrt_hip_scene_stats(self._h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in abi.Stats._fields_}
+
+    def trace_rays(self, rays, min_dist=0.001, max_dist=2000.0):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        t = np.zeros(n, np.float32)
+        dist = np.zeros(n, np.float32)
+        obj = np.zeros(n, np.int32)
+        tri = np.zeros(n, np.int32)
+        abi.check(self._lib.rbrt_hip_trace_rays(self._h, rays.ctypes.data_as(abi.f32p), n, min_dist, max_dist,
+                                                t.ctypes.data_as(abi.f32p), obj.ctypes.data_as(abi.i32p),
+                                                tri.ctypes.data_as(abi.i32p), dist.ctypes.data_as(abi.f32p)))
+        return t, obj, tri, dist
+
+
+def packed_pixels(width: int, height: int, rank: int, world: int) -> int:
+    return int(load_hip().rbrt_hip_packed_pixels(width, height, rank, world))
+
+
+def unpack_tiles(device: int, d_gathered: int, width: int, height: int, world: int, d_radiance: int | None,
+                 d_rgb8: int | None = None, stream: int | None = None):
+    abi.check(load_hip().rbrt_hip_unpack_tiles(device, C.c_void_p(stream or 0), C.c_void_p(d_gathered), width,
+                                               height, world, C.c_void_p(d_radiance or 0), C.c_void_p(d_rgb8 or 0)))

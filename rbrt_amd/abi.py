@@ -1,0 +1,241 @@
+"""ctypes mirror of include/rbrt_hip.h (the C ABI of the HIP hot path).
+
+Python here is plumbing for tests and bench.py: it declares the same POD structs a Rust
+`extern "C"` block or the C++ host would, loads `rbrt_amd/lib/librbrt_hip.so`, and checks return
+codes. There is no Python or CPU implementation of the render path behind it: if the shared
+library is missing, `load_hip()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB_HIP = ROOT / "rbrt_amd" / "lib" / "librbrt_hip.so"
+LIB_HOST = ROOT / "rbrt_amd" / "lib" / "librbrt_host.so"
+
+RBRT_OK = 0
+RBRT_ERR_INVALID_ARG = -1
+RBRT_ERR_NO_DEVICE = -2
+RBRT_ERR_HIP = -3
+RBRT_ERR_OOM = -4
+RBRT_ERR_UNSUPPORTED = -5
+RBRT_ERR_NAN = -6
+
+MAT_LAMBERTIAN = 0
+MAT_METAL = 1
+MAT_DIELECTRIC = 2
+
+FLAG_COLLECT_STATS = 1
+TILE = 8
+
+f32p = C.POINTER(C.c_float)
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+
+
+class Material(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("albedo", C.c_float * 3), ("param", C.c_float)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("mat", Material)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [
+        ("n_total", C.c_uint32),
+        ("n_real", C.c_uint32),
+        ("v0x", f32p), ("v0y", f32p), ("v0z", f32p),
+        ("e1x", f32p), ("e1y", f32p), ("e1z", f32p),
+        ("e2x", f32p), ("e2y", f32p), ("e2z", f32p),
+        ("nx", f32p), ("ny", f32p), ("nz", f32p),
+        ("is_padding", u8p),
+        ("bbox_lo", C.c_float * 3),
+        ("bbox_hi", C.c_float * 3),
+        ("mat", Material),
+    ]
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("n_spheres", C.c_uint32),
+        ("spheres", C.POINTER(Sphere)),
+        ("n_meshes", C.c_uint32),
+        ("meshes", C.POINTER(Mesh)),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("position", C.c_float * 3),
+        ("right", C.c_float * 3),
+        ("up", C.c_float * 3),
+        ("img_center_point", C.c_float * 3),
+        ("mm_per_pix_hor", C.c_float),
+        ("mm_per_pix_vert", C.c_float),
+        ("img_width_pix", C.c_uint32),
+        ("img_height_pix", C.c_uint32),
+    ]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [
+        ("spp", C.c_uint32),
+        ("max_depth", C.c_uint32),
+        ("min_dist", C.c_float),
+        ("max_dist", C.c_float),
+        ("bg", C.c_float * 3),
+        ("seed", C.c_uint64),
+        ("tile_rank", C.c_uint32),
+        ("tile_world", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("rays", C.c_uint64),
+        ("mesh_gate_pass", C.c_uint64),
+        ("nodes_visited", C.c_uint64),
+        ("tris_tested", C.c_uint64),
+        ("mesh_hits", C.c_uint64),
+        ("samples", C.c_uint64),
+        ("nan_discriminants", C.c_uint64),
+        ("node_bytes", C.c_uint32),
+        ("tri_bytes", C.c_uint32),
+    ]
+
+
+# every symbol include/rbrt_hip.h declares: name -> (restype, argtypes)
+HIP_SYMBOLS = {
+    "rbrt_hip_render": (C.c_int, [C.POINTER(Camera), C.POINTER(Scene), C.POINTER(RenderOpts), f32p, u8p]),
+    "rbrt_hip_scene_create": (C.c_int, [C.POINTER(Scene), C.c_int, C.POINTER(C.c_void_p)]),
+    "rbrt_hip_scene_destroy": (C.c_int, [C.c_void_p]),
+    "rbrt_hip_packed_pixels": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rbrt_hip_render_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "rbrt_hip_unpack_tiles": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_void_p, C.c_void_p]),
+    "rbrt_hip_scene_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "rbrt_hip_trace_rays": (C.c_int, [C.c_void_p, f32p, C.c_size_t, C.c_float, C.c_float, f32p, i32p, i32p, f32p]),
+    "rbrt_hip_bvh_build_host": (C.c_int, [C.POINTER(Mesh), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
+                                          f32p]),
+    "rbrt_hip_free_host": (None, [C.c_void_p]),
+    "rbrt_render_opts_default": (None, [C.POINTER(RenderOpts)]),
+    "rbrt_hip_device_count": (C.c_int, []),
+    "rbrt_hip_last_error": (C.c_char_p, []),
+    "rbrt_hip_abi_version": (C.c_int, []),
+    "rbrt_hip_scene_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "rbrt_hip_scene_last_kernel_ms": (C.c_int, [C.c_void_p, f32p, f32p]),
+}
+
+
+class RbrtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rbrt_hip error {code}: {msg}")
+        self.code = code
+
+
+_hip = None
+
+
+def load_hip() -> C.CDLL:
+    """Load the product library. Fails loudly when it has not been built: no fallback exists."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    if not LIB_HIP.exists():
+        raise FileNotFoundError(
+            f"{LIB_HIP} is missing: build it with `make` (or __graft_entry__.build()). "
+            "rbrt_amd has no CPU or pure-Python render path.")
+    lib = C.CDLL(str(LIB_HIP), mode=getattr(os, "RTLD_NOW", 2))
+    for name, (res, args) in HIP_SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _hip = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != RBRT_OK:
+        raise RbrtError(code, load_hip().rbrt_hip_last_error().decode(errors="replace"))
+
+
+# ------------------------------------------------------------------------------------------
+# helpers to build the POD structs from Python values (keeping the backing arrays alive)
+# ------------------------------------------------------------------------------------------
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def material(kind: int, albedo=(0.0, 0.0, 0.0), param: float = 0.0) -> Material:
+    return Material(kind, _f3(albedo), float(param))
+
+
+def fptr(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(f32p)
+
+
+class SceneData:
+    """Owns the numpy arrays and ctypes arrays a `Scene` struct points into."""
+
+    def __init__(self, spheres=(), meshes=()):
+        # spheres: iterable of (center, radius, Material); meshes: iterable of MeshData
+        self.spheres = list(spheres)
+        self.meshes = list(meshes)
+        self._sph = (Sphere * max(1, len(self.spheres)))()
+        for i, (c, r, m) in enumerate(self.spheres):
+            self._sph[i] = Sphere(_f3(c), float(r), m)
+        self._msh = (Mesh * max(1, len(self.meshes)))()
+        for i, md in enumerate(self.meshes):
+            self._msh[i] = md.struct
+        self.struct = Scene(len(self.spheres), self._sph, len(self.meshes), self._msh)
+
+    def ptr(self):
+        return C.byref(self.struct)
+
+
+class MeshData:
+    """SoA arrays of one mesh in the reference's layout (mesh.rs:12-25)."""
+
+    FIELDS = ("v0x", "v0y", "v0z", "e1x", "e1y", "e1z", "e2x", "e2y", "e2z", "nx", "ny", "nz")
+
+    def __init__(self, arrays: dict, is_padding: np.ndarray, n_real: int, bbox_lo, bbox_hi, mat: Material):
+        self.arrays = {k: np.ascontiguousarray(arrays[k], dtype=np.float32) for k in self.FIELDS}
+        self.is_padding = np.ascontiguousarray(is_padding, dtype=np.uint8)
+        n_total = len(self.is_padding)
+        for k in self.FIELDS:
+            assert len(self.arrays[k]) == n_total, k
+        self.n_total, self.n_real = n_total, int(n_real)
+        self.bbox_lo, self.bbox_hi = np.float32(bbox_lo), np.float32(bbox_hi)
+        self.struct = Mesh()
+        self.struct.n_total = n_total
+        self.struct.n_real = self.n_real
+        for k in self.FIELDS:
+            setattr(self.struct, k, fptr(self.arrays[k]))
+        self.struct.is_padding = self.is_padding.ctypes.data_as(u8p)
+        self.struct.bbox_lo = _f3(bbox_lo)
+        self.struct.bbox_hi = _f3(bbox_hi)
+        self.struct.mat = mat
+
+
+def default_opts(spp: int = 5, seed: int = 1, **kw) -> RenderOpts:
+    o = RenderOpts()
+    o.spp, o.max_depth, o.min_dist, o.max_dist = spp, 50, 0.001, 2000.0
+    o.bg = _f3((0.05, 0.05, 0.8))
+    o.seed, o.tile_rank, o.tile_world, o.flags, o.reserved = seed, 0, 1, 0, 0
+    for k, v in kw.items():
+        if k == "bg":
+            o.bg = _f3(v)
+        else:
+            setattr(o, k, v)
+    return o

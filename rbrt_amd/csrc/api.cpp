@@ -1,0 +1,557 @@
+// api.cpp — implementation of the C ABI in include/rbrt_hip.h on top of the gfx950 kernels.
+// Host C++ only (compiled by hipcc for the HIP runtime headers); no torch, no Python.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "bvh.h"
+#include "device_types.h"
+
+namespace rbrt {
+hipError_t launch_trace(const TraceParams& P, bool stats, hipStream_t stream);
+hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
+hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
+                         float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
+hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, float* out_t, int32_t* out_obj,
+                             int32_t* out_tri, float* out_dist, hipStream_t stream);
+uint64_t host_splitmix64(uint64_t x);
+}  // namespace rbrt
+
+using namespace rbrt;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            int _code = (_e == hipErrorOutOfMemory) ? RBRT_ERR_OOM                                   \
+                        : (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? RBRT_ERR_NO_DEVICE \
+                                                                                  : RBRT_ERR_HIP;    \
+            return fail(_code, std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+        }                                                                                            \
+    } while (0)
+
+uint32_t local_tiles_of(uint32_t n_tiles, uint32_t rank, uint32_t world) {
+    return rank < n_tiles ? (n_tiles - rank + world - 1u) / world : 0u;
+}
+
+size_t workspace_cap_bytes() {
+    size_t mb = 2048;
+    if (const char* e = std::getenv("RBRT_HIP_WORKSPACE_MB")) {
+        long v = std::atol(e);
+        if (v > 0) mb = size_t(v);
+    }
+    return mb << 20;
+}
+
+}  // namespace
+
+struct rbrt_hip_scene {
+    int device = 0;
+    uint32_t n_spheres = 0, n_meshes = 0;
+    std::vector<void*> allocs;  // everything hipMalloc'ed for the scene itself
+    DevSphere* d_spheres = nullptr;
+    DevMaterial* d_materials = nullptr;
+    DevMesh* d_meshes = nullptr;
+    DevCounters* d_counters = nullptr;
+    // workspace, grown on demand
+    float* d_sample_buf = nullptr;
+    size_t sample_buf_bytes = 0;
+    float* d_acc = nullptr;
+    size_t acc_bytes = 0;
+    // stats / timing
+    rbrt_hip_stats_t stats{};
+    bool stats_pending = false;
+    bool timing = false;
+    std::vector<hipEvent_t> events;  // [t0, t1, r1] per batch
+    size_t events_used = 0;
+    uint64_t total_nodes = 0, total_tris = 0;
+};
+
+namespace {
+
+int ensure_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RBRT_ERR_NO_DEVICE, std::string("no HIP device available: ") +
+                                            (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= n) return fail(RBRT_ERR_INVALID_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    return RBRT_OK;
+}
+
+template <class T>
+int upload(rbrt_hip_scene* s, const std::vector<T>& host, T** out) {
+    void* d = nullptr;
+    size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+    HIP_TRY(hipMalloc(&d, bytes));
+    s->allocs.push_back(d);
+    if (!host.empty()) HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<T*>(d);
+    return RBRT_OK;
+}
+
+int check_material(const rbrt_material_t& m) {
+    if (m.kind < RBRT_MAT_LAMBERTIAN || m.kind > RBRT_MAT_DIELECTRIC)
+        return fail(RBRT_ERR_INVALID_ARG, "unknown material kind");
+    return RBRT_OK;
+}
+
+int fill_trace_params(const rbrt_hip_scene* s, const rbrt_camera_t* cam, const rbrt_render_opts_t* o,
+                      TraceParams& P) {
+    std::memset(&P, 0, sizeof(P));
+    if (cam) P.cam = *cam;
+    P.min_dist = o->min_dist;
+    P.max_dist = o->max_dist;
+    P.eps_frac = 1.0f / o->min_dist;  // triangle.rs:146
+    for (int k = 0; k < 3; ++k) P.bg[k] = o->bg[k];
+    P.max_depth = o->max_depth;
+    P.seed_key = host_splitmix64(o->seed);
+    P.n_spheres = s->n_spheres;
+    P.n_meshes = s->n_meshes;
+    P.spheres = s->d_spheres;
+    P.materials = s->d_materials;
+    P.meshes = s->d_meshes;
+    P.counters = s->d_counters;
+    return RBRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rbrt_hip_abi_version(void) { return RBRT_ABI_VERSION; }
+
+const char* rbrt_hip_last_error(void) { return g_last_error.c_str(); }
+
+void rbrt_render_opts_default(rbrt_render_opts_t* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->spp = 5;             // src/main.rs:47
+    o->max_depth = 50;      // lib.rs:99
+    o->min_dist = 0.001f;   // lib.rs:44
+    o->max_dist = 2000.0f;  // lib.rs:45
+    o->bg[0] = 0.05f, o->bg[1] = 0.05f, o->bg[2] = 0.8f;  // lib.rs:89-93
+    o->seed = 1;
+    o->tile_rank = 0;
+    o->tile_world = 1;
+    o->flags = RBRT_FLAG_NONE;
+}
+
+int rbrt_hip_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return 0;
+    }
+    return n;
+}
+
+size_t rbrt_hip_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_world) {
+    const uint32_t tx = (width + RBRT_TILE - 1) / RBRT_TILE, ty = (height + RBRT_TILE - 1) / RBRT_TILE;
+    const uint32_t world = tile_world ? tile_world : 1;
+    return size_t(local_tiles_of(tx * ty, tile_rank, world)) * 64u;
+}
+
+int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** out) {
+    if (!scene || !out) return fail(RBRT_ERR_INVALID_ARG, "scene_create: null argument");
+    *out = nullptr;
+    if (scene->n_spheres && !scene->spheres) return fail(RBRT_ERR_INVALID_ARG, "spheres is null");
+    if (scene->n_meshes && !scene->meshes) return fail(RBRT_ERR_INVALID_ARG, "meshes is null");
+    if (uint64_t(scene->n_spheres) + scene->n_meshes > uint64_t(kMaxObjects))
+        return fail(RBRT_ERR_UNSUPPORTED, "more than 255 objects (spheres + meshes) in one scene");
+    for (uint32_t i = 0; i < scene->n_spheres; ++i)
+        if (int rc = check_material(scene->spheres[i].mat)) return rc;
+    for (uint32_t i = 0; i < scene->n_meshes; ++i) {
+        const rbrt_mesh_t& m = scene->meshes[i];
+        if (int rc = check_material(m.mat)) return rc;
+        if (m.n_total >= (1u << 28)) return fail(RBRT_ERR_UNSUPPORTED, "mesh has 2^28 or more triangles");
+        if (m.n_total && (!m.v0x || !m.v0y || !m.v0z || !m.e1x || !m.e1y || !m.e1z || !m.e2x || !m.e2y ||
+                          !m.e2z || !m.nx || !m.ny || !m.nz || !m.is_padding))
+            return fail(RBRT_ERR_INVALID_ARG, "mesh array pointer is null");
+    }
+    if (int rc = ensure_device(device)) return rc;
+
+    rbrt_hip_scene* s = new rbrt_hip_scene();
+    s->device = device;
+    s->n_spheres = scene->n_spheres;
+    s->n_meshes = scene->n_meshes;
+    auto bail = [&](int rc) {
+        rbrt_hip_scene_destroy(s);
+        return rc;
+    };
+
+    std::vector<DevSphere> spheres(scene->n_spheres);
+    std::vector<DevMaterial> mats(scene->n_spheres + scene->n_meshes);
+    auto put_mat = [&](size_t k, const rbrt_material_t& m) {
+        for (int c = 0; c < 3; ++c) mats[k].albedo[c] = m.albedo[c];
+        mats[k].param = m.param;
+        mats[k].kind = m.kind;
+    };
+    for (uint32_t i = 0; i < scene->n_spheres; ++i) {
+        for (int c = 0; c < 3; ++c) spheres[i].center[c] = scene->spheres[i].center[c];
+        spheres[i].radius = scene->spheres[i].radius;
+        put_mat(i, scene->spheres[i].mat);
+    }
+    std::vector<DevMesh> meshes(scene->n_meshes);
+    for (uint32_t i = 0; i < scene->n_meshes; ++i) {
+        const rbrt_mesh_t& m = scene->meshes[i];
+        put_mat(scene->n_spheres + i, m.mat);
+        BvhBuildResult bvh = build_bvh(m);
+        std::vector<Normal4> normals(m.n_total);
+        for (uint32_t k = 0; k < m.n_total; ++k) normals[k] = Normal4{m.nx[k], m.ny[k], m.nz[k], 0.0f};
+        DevMesh& dm = meshes[i];
+        BvhNode* d_nodes = nullptr;
+        BvhTri* d_tris = nullptr;
+        Normal4* d_normals = nullptr;
+        if (int rc = upload(s, bvh.nodes, &d_nodes)) return bail(rc);
+        if (int rc = upload(s, bvh.tris, &d_tris)) return bail(rc);
+        if (int rc = upload(s, normals, &d_normals)) return bail(rc);
+        dm.nodes = d_nodes, dm.tris = d_tris, dm.normals = d_normals;
+        float diag2 = 0.0f;
+        for (int c = 0; c < 3; ++c) {
+            dm.bbox_lo[c] = m.bbox_lo[c];
+            dm.bbox_hi[c] = m.bbox_hi[c];
+            dm.center[c] = 0.5f * m.bbox_lo[c] + 0.5f * m.bbox_hi[c];
+            float h = 0.5f * m.bbox_hi[c] - 0.5f * m.bbox_lo[c];
+            diag2 += h * h;
+        }
+        // Radius bounds |v - center| for every indexed vertex; padded a little for its own rounding.
+        dm.radius = std::sqrt(diag2) * 1.0001f;
+        if (!std::isfinite(dm.radius)) dm.radius = std::numeric_limits<float>::max();
+        dm.max_e12 = bvh.max_e12;
+        dm.n_nodes = uint32_t(bvh.nodes.size());
+        dm.n_tris = uint32_t(bvh.tris.size());
+        s->total_nodes += bvh.nodes.size();
+        s->total_tris += bvh.tris.size();
+    }
+    if (int rc = upload(s, spheres, &s->d_spheres)) return bail(rc);
+    if (int rc = upload(s, mats, &s->d_materials)) return bail(rc);
+    if (int rc = upload(s, meshes, &s->d_meshes)) return bail(rc);
+    {
+        std::vector<DevCounters> z(1);
+        std::memset(z.data(), 0, sizeof(DevCounters));
+        if (int rc = upload(s, z, &s->d_counters)) return bail(rc);
+    }
+    *out = s;
+    return RBRT_OK;
+}
+
+int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
+    if (!s) return RBRT_OK;
+    (void)hipSetDevice(s->device);
+    for (void* p : s->allocs) (void)hipFree(p);
+    if (s->d_sample_buf) (void)hipFree(s->d_sample_buf);
+    if (s->d_acc) (void)hipFree(s->d_acc);
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    delete s;
+    return RBRT_OK;
+}
+
+int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* s, int enable) {
+    if (!s) return fail(RBRT_ERR_INVALID_ARG, "null scene");
+    s->timing = enable != 0;
+    return RBRT_OK;
+}
+
+int rbrt_hip_scene_last_kernel_ms(rbrt_hip_scene_t* s, float* trace_ms, float* resolve_ms) {
+    if (!s) return fail(RBRT_ERR_INVALID_ARG, "null scene");
+    if (!s->timing || s->events_used == 0) return fail(RBRT_ERR_INVALID_ARG, "no timed render on this scene");
+    HIP_TRY(hipSetDevice(s->device));
+    float tsum = 0.0f, rsum = 0.0f;
+    for (size_t b = 0; b + 3 <= s->events_used; b += 3) {
+        HIP_TRY(hipEventSynchronize(s->events[b + 2]));
+        float t = 0.0f, r = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, s->events[b], s->events[b + 1]));
+        HIP_TRY(hipEventElapsedTime(&r, s->events[b + 1], s->events[b + 2]));
+        tsum += t;
+        rsum += r;
+    }
+    if (trace_ms) *trace_ms = tsum;
+    if (resolve_ms) *resolve_ms = rsum;
+    return RBRT_OK;
+}
+
+int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const rbrt_render_opts_t* o,
+                           void* stream_v, float* d_radiance, uint8_t* d_rgb8) {
+    if (!s || !cam || !o) return fail(RBRT_ERR_INVALID_ARG, "render: null argument");
+    if (o->spp == 0) return fail(RBRT_ERR_INVALID_ARG, "spp must be >= 1");
+    if (o->max_depth > uint32_t(kMaxPathDepth))
+        return fail(RBRT_ERR_UNSUPPORTED, "max_depth above the kernel limit of 64");
+    if (cam->img_width_pix == 0 || cam->img_height_pix == 0)
+        return fail(RBRT_ERR_INVALID_ARG, "image has zero pixels");
+    if (uint64_t(cam->img_width_pix) * cam->img_height_pix >= (1ull << 32))
+        return fail(RBRT_ERR_UNSUPPORTED, "image has 2^32 or more pixels");
+    const uint32_t world = o->tile_world ? o->tile_world : 1;
+    if (o->tile_rank >= world) return fail(RBRT_ERR_INVALID_ARG, "tile_rank >= tile_world");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+
+    const uint32_t W = cam->img_width_pix, H = cam->img_height_pix;
+    const uint32_t tiles_x = (W + RBRT_TILE - 1) / RBRT_TILE, tiles_y = (H + RBRT_TILE - 1) / RBRT_TILE;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    const uint32_t n_local = local_tiles_of(n_tiles, o->tile_rank, world);
+    const size_t npix = size_t(n_local) * 64u;
+    if (npix == 0) return RBRT_OK;
+
+    // workspace: as many samples per batch as fit the cap (at least one)
+    const size_t per_sample = npix * 3u * sizeof(float);
+    size_t batch = workspace_cap_bytes() / per_sample;
+    if (batch < 1) batch = 1;
+    if (batch > o->spp) batch = o->spp;
+    const size_t need = batch * per_sample;
+    if (need > s->sample_buf_bytes) {
+        if (s->d_sample_buf) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipFree(s->d_sample_buf));
+            s->d_sample_buf = nullptr, s->sample_buf_bytes = 0;
+        }
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, need));
+        s->d_sample_buf = static_cast<float*>(p), s->sample_buf_bytes = need;
+    }
+    if (per_sample > s->acc_bytes) {
+        if (s->d_acc) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipFree(s->d_acc));
+            s->d_acc = nullptr, s->acc_bytes = 0;
+        }
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, per_sample));
+        s->d_acc = static_cast<float*>(p), s->acc_bytes = per_sample;
+    }
+
+    const bool stats = (o->flags & RBRT_FLAG_COLLECT_STATS) != 0;
+    if (stats) {
+        HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DevCounters), stream));
+        s->stats_pending = true;
+    }
+
+    TraceParams P;
+    fill_trace_params(s, cam, o, P);
+    P.tiles_x = tiles_x, P.tiles_y = tiles_y, P.n_tiles = n_tiles;
+    P.tile_rank = o->tile_rank, P.tile_world = world, P.n_local_tiles = n_local;
+    P.sample_buf = s->d_sample_buf;
+
+    ResolveParams R;
+    std::memset(&R, 0, sizeof(R));
+    R.width = W, R.height = H, R.tiles_x = tiles_x, R.n_tiles = n_tiles;
+    R.tile_rank = o->tile_rank, R.tile_world = world, R.n_local_tiles = n_local;
+    R.inv_spp = 1.0f / float(o->spp);  // lib.rs:101
+    R.sample_buf = s->d_sample_buf;
+    R.acc = s->d_acc;
+    R.out_radiance = d_radiance;
+    R.out_rgb8 = d_rgb8;
+
+    const size_t n_batches = (size_t(o->spp) + batch - 1) / batch;
+    if (s->timing) {
+        while (s->events.size() < 3 * n_batches) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            s->events.push_back(e);
+        }
+        s->events_used = 0;
+    }
+    for (size_t b = 0; b < n_batches; ++b) {
+        const uint32_t base = uint32_t(b * batch);
+        const uint32_t nb = uint32_t(std::min<size_t>(batch, o->spp - base));
+        P.sample_base = base;
+        P.batch = nb;
+        P.n_items = uint64_t(npix) * nb;
+        if (s->timing) HIP_TRY(hipEventRecord(s->events[3 * b], stream));
+        HIP_TRY(launch_trace(P, stats, stream));
+        if (s->timing) HIP_TRY(hipEventRecord(s->events[3 * b + 1], stream));
+        R.batch = nb;
+        R.first_batch = b == 0;
+        R.last_batch = b + 1 == n_batches;
+        HIP_TRY(launch_resolve(R, stream));
+        if (s->timing) {
+            HIP_TRY(hipEventRecord(s->events[3 * b + 2], stream));
+            s->events_used = 3 * (b + 1);
+        }
+    }
+    return RBRT_OK;
+}
+
+int rbrt_hip_scene_stats(rbrt_hip_scene_t* s, rbrt_hip_stats_t* out) {
+    if (!s || !out) return fail(RBRT_ERR_INVALID_ARG, "stats: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    DevCounters c;
+    HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    s->stats.rays = c.rays;
+    s->stats.mesh_gate_pass = c.mesh_gate_pass;
+    s->stats.nodes_visited = c.nodes_visited;
+    s->stats.tris_tested = c.tris_tested;
+    s->stats.mesh_hits = c.mesh_hits;
+    s->stats.samples = c.samples;
+    s->stats.nan_discriminants = c.nan_discriminants;
+    s->stats.node_bytes = sizeof(BvhNode);
+    s->stats.tri_bytes = sizeof(BvhTri);
+    *out = s->stats;
+    return RBRT_OK;
+}
+
+int rbrt_hip_unpack_tiles(int device, void* stream, const float* d_gathered, uint32_t width, uint32_t height,
+                          uint32_t tile_world, float* d_radiance, uint8_t* d_rgb8) {
+    if (!d_gathered) return fail(RBRT_ERR_INVALID_ARG, "unpack: null input");
+    if (int rc = ensure_device(device)) return rc;
+    HIP_TRY(launch_unpack(d_gathered, width, height, tile_world ? tile_world : 1, d_radiance, d_rgb8,
+                          static_cast<hipStream_t>(stream)));
+    return RBRT_OK;
+}
+
+int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const rbrt_render_opts_t* opts,
+                    float* out_radiance, uint8_t* out_rgb8) {
+    if (!cam || !scene || !opts) return fail(RBRT_ERR_INVALID_ARG, "render: null argument");
+    rbrt_hip_scene_t* s = nullptr;
+    if (int rc = rbrt_hip_scene_create(scene, 0, &s)) return rc;
+    const uint32_t world = opts->tile_world ? opts->tile_world : 1;
+    const size_t npix_img = size_t(cam->img_width_pix) * cam->img_height_pix;
+    const size_t n_out = world > 1
+                             ? rbrt_hip_packed_pixels(cam->img_width_pix, cam->img_height_pix, opts->tile_rank, world)
+                             : npix_img;
+    float* d_rad = nullptr;
+    uint8_t* d_rgb = nullptr;
+    int rc = RBRT_OK;
+    auto cleanup = [&]() {
+        if (d_rad) (void)hipFree(d_rad);
+        if (d_rgb) (void)hipFree(d_rgb);
+        rbrt_hip_scene_destroy(s);
+    };
+#define TRY_OR_CLEAN(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            cleanup();                                                                      \
+            return fail(_e == hipErrorOutOfMemory ? RBRT_ERR_OOM : RBRT_ERR_HIP,            \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+        }                                                                                   \
+    } while (0)
+    if (n_out == 0) {
+        cleanup();
+        return RBRT_OK;
+    }
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_rad), n_out * 3 * sizeof(float)));
+    if (out_rgb8) TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_rgb), n_out * 3));
+    rc = rbrt_hip_render_device(s, cam, opts, nullptr, d_rad, d_rgb);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    TRY_OR_CLEAN(hipDeviceSynchronize());
+    if (world > 1) {
+        // scatter this rank's packed tiles into the caller's full-size images
+        std::vector<float> hr(n_out * 3);
+        std::vector<uint8_t> hb(out_rgb8 ? n_out * 3 : 0);
+        TRY_OR_CLEAN(hipMemcpy(hr.data(), d_rad, hr.size() * sizeof(float), hipMemcpyDeviceToHost));
+        if (out_rgb8) TRY_OR_CLEAN(hipMemcpy(hb.data(), d_rgb, hb.size(), hipMemcpyDeviceToHost));
+        const uint32_t W = cam->img_width_pix, H = cam->img_height_pix;
+        const uint32_t tiles_x = (W + RBRT_TILE - 1) / RBRT_TILE;
+        const size_t n_local = n_out / 64;
+        for (size_t tl = 0; tl < n_local; ++tl) {
+            const uint32_t tile = uint32_t(tl) * world + opts->tile_rank;
+            const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
+            for (uint32_t p = 0; p < 64; ++p) {
+                const uint32_t row = ty * RBRT_TILE + p / 8, col = tx * RBRT_TILE + p % 8;
+                if (row >= H || col >= W) continue;
+                const size_t src = (tl * 64 + p) * 3, dst = (size_t(row) * W + col) * 3;
+                for (int c = 0; c < 3; ++c) {
+                    if (out_radiance) out_radiance[dst + c] = hr[src + c];
+                    if (out_rgb8) out_rgb8[dst + c] = hb[src + c];
+                }
+            }
+        }
+    } else {
+        if (out_radiance)
+            TRY_OR_CLEAN(hipMemcpy(out_radiance, d_rad, n_out * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (out_rgb8) TRY_OR_CLEAN(hipMemcpy(out_rgb8, d_rgb, n_out * 3, hipMemcpyDeviceToHost));
+    }
+    DevCounters c;
+    TRY_OR_CLEAN(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    cleanup();
+#undef TRY_OR_CLEAN
+    if (c.nan_discriminants)
+        return fail(RBRT_ERR_NAN, "a sphere discriminant was NaN (the reference panics: sphere.rs:33); "
+                                  "those rays were treated as misses");
+    return RBRT_OK;
+}
+
+// Diagnostic: run the host BVH builder alone (no device needed) and hand back copies of its arrays.
+int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
+                            size_t* n_tris, uint32_t* max_depth, float* max_e12) {
+    if (!mesh || !nodes_out || !n_nodes || !tris_out || !n_tris)
+        return fail(RBRT_ERR_INVALID_ARG, "bvh_build_host: null argument");
+    BvhBuildResult r = build_bvh(*mesh);
+    *n_nodes = r.nodes.size();
+    *n_tris = r.tris.size();
+    *nodes_out = std::malloc(std::max<size_t>(1, r.nodes.size() * sizeof(BvhNode)));
+    *tris_out = std::malloc(std::max<size_t>(1, r.tris.size() * sizeof(BvhTri)));
+    if (!*nodes_out || !*tris_out) return fail(RBRT_ERR_OOM, "bvh_build_host: malloc failed");
+    std::memcpy(*nodes_out, r.nodes.data(), r.nodes.size() * sizeof(BvhNode));
+    std::memcpy(*tris_out, r.tris.data(), r.tris.size() * sizeof(BvhTri));
+    if (max_depth) *max_depth = r.max_depth;
+    if (max_e12) *max_e12 = r.max_e12;
+    return RBRT_OK;
+}
+void rbrt_hip_free_host(void* p) { std::free(p); }
+
+int rbrt_hip_trace_rays(rbrt_hip_scene_t* s, const float* rays, size_t n, float min_dist, float max_dist,
+                        float* out_t, int32_t* out_obj, int32_t* out_tri, float* out_dist) {
+    if (!s || (!rays && n)) return fail(RBRT_ERR_INVALID_ARG, "trace_rays: null argument");
+    if (n == 0) return RBRT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    rbrt_render_opts_t o;
+    rbrt_render_opts_default(&o);
+    o.min_dist = min_dist;
+    o.max_dist = max_dist;
+    TraceParams P;
+    fill_trace_params(s, nullptr, &o, P);
+    float *d_rays = nullptr, *d_t = nullptr, *d_dist = nullptr;
+    int32_t *d_obj = nullptr, *d_tri = nullptr;
+    int rc = RBRT_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_rays), (void)hipFree(d_t), (void)hipFree(d_dist), (void)hipFree(d_obj), (void)hipFree(d_tri);
+    };
+#define TRY_OR_CLEAN(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            cleanup();                                                                           \
+            return fail(RBRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+        }                                                                                        \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_rays), n * 6 * sizeof(float)));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_t), n * sizeof(float)));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_dist), n * sizeof(float)));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_obj), n * sizeof(int32_t)));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_tri), n * sizeof(int32_t)));
+    TRY_OR_CLEAN(hipMemcpy(d_rays, rays, n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(launch_trace_rays(P, d_rays, n, d_t, d_obj, d_tri, d_dist, nullptr));
+    TRY_OR_CLEAN(hipDeviceSynchronize());
+    if (out_t) TRY_OR_CLEAN(hipMemcpy(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_dist) TRY_OR_CLEAN(hipMemcpy(out_dist, d_dist, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_obj) TRY_OR_CLEAN(hipMemcpy(out_obj, d_obj, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out_tri) TRY_OR_CLEAN(hipMemcpy(out_tri, d_tri, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    cleanup();
+#undef TRY_OR_CLEAN
+    return rc;
+}
+
+}  // extern "C"

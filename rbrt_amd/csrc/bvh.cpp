@@ -1,0 +1,266 @@
+// bvh.cpp — binned-SAH BVH2 builder (host). See bvh.h for what the structure must guarantee.
+#include "bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rbrt {
+namespace {
+
+constexpr int kBins = 16;
+constexpr float kCostTraverse = 1.0f;  // one node fetch + two slab tests
+constexpr float kCostTri = 1.0f;       // one 48-B fetch + Moller-Trumbore
+// Inner nodes live at depths 0..kMaxInnerDepth; a root-to-leaf walk defers at most one child per
+// inner node, so the traversal stack never holds more than kMaxInnerDepth + 1 <= kStackEntries.
+constexpr int kMaxInnerDepth = kStackEntries - 2;
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::numeric_limits<float>::max();
+            hi[k] = -std::numeric_limits<float>::max();
+        }
+    }
+    void grow(const float* p) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], p[k]);
+            hi[k] = std::max(hi[k], p[k]);
+        }
+    }
+    void grow(const Box& b) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], b.lo[k]);
+            hi[k] = std::max(hi[k], b.hi[k]);
+        }
+    }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim {
+    Box box;
+    float c[3];
+    float e12;
+    uint32_t idx;
+};
+
+struct ChildInfo {
+    int32_t ref;
+    Box box;
+    float max_e12;
+};
+
+struct Builder {
+    const rbrt_mesh_t& m;
+    std::vector<Prim> prims;
+    BvhBuildResult out;
+
+    explicit Builder(const rbrt_mesh_t& mesh) : m(mesh) {}
+
+    BvhTri make_tri(uint32_t i) const {
+        BvhTri t;
+        t.v0[0] = m.v0x[i], t.v0[1] = m.v0y[i], t.v0[2] = m.v0z[i];
+        t.e1x = m.e1x[i], t.e1yz[0] = m.e1y[i], t.e1yz[1] = m.e1z[i];
+        t.e2xy[0] = m.e2x[i], t.e2xy[1] = m.e2y[i], t.e2z = m.e2z[i];
+        t.index = i;
+        t.pad[0] = t.pad[1] = 0;
+        return t;
+    }
+
+    // How many triangles fit under a subtree whose root inner node would sit at `depth`.
+    static uint64_t capacity(int depth) {
+        if (depth > kMaxInnerDepth) return kLeafMax;
+        return uint64_t(kLeafMax) << (kMaxInnerDepth - depth + 1);
+    }
+
+    ChildInfo make_leaf(size_t b, size_t e, const Box& box, float max_e12) {
+        uint32_t first = uint32_t(out.tris.size());
+        uint32_t count = uint32_t(e - b);
+        // deterministic order inside a leaf: ascending reference index
+        std::sort(prims.begin() + b, prims.begin() + e,
+                  [](const Prim& x, const Prim& y) { return x.idx < y.idx; });
+        for (size_t i = b; i < e; ++i) out.tris.push_back(make_tri(prims[i].idx));
+        ++out.n_leaves;
+        return ChildInfo{~int32_t((first << 3) | (count - 1)), box, max_e12};
+    }
+
+    ChildInfo build_range(size_t b, size_t e, int depth) {
+        const size_t count = e - b;
+        Box box, cbox;
+        box.reset();
+        cbox.reset();
+        float max_e12 = 0.0f;
+        for (size_t i = b; i < e; ++i) {
+            box.grow(prims[i].box);
+            cbox.grow(prims[i].c);
+            max_e12 = std::max(max_e12, prims[i].e12);
+        }
+        if (depth > kMaxInnerDepth || count <= 1) return make_leaf(b, e, box, max_e12);
+
+        // binned SAH over the three axes
+        const float parent_area = box.half_area();
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1, best_split = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            const float cmin = cbox.lo[axis], cext = cbox.hi[axis] - cbox.lo[axis];
+            if (!(cext > 0.0f)) continue;
+            const float scale = float(kBins) / cext;
+            Box bin_box[kBins];
+            uint32_t bin_cnt[kBins] = {0};
+            for (auto& bb : bin_box) bb.reset();
+            for (size_t i = b; i < e; ++i) {
+                int bi = std::min(kBins - 1, std::max(0, int((prims[i].c[axis] - cmin) * scale)));
+                bin_box[bi].grow(prims[i].box);
+                ++bin_cnt[bi];
+            }
+            float right_area[kBins];
+            uint32_t right_cnt[kBins];
+            Box acc;
+            acc.reset();
+            uint32_t n = 0;
+            for (int i = kBins - 1; i > 0; --i) {
+                acc.grow(bin_box[i]);
+                n += bin_cnt[i];
+                right_area[i] = acc.half_area();
+                right_cnt[i] = n;
+            }
+            acc.reset();
+            n = 0;
+            for (int i = 1; i < kBins; ++i) {  // split = first bin of the right side
+                acc.grow(bin_box[i - 1]);
+                n += bin_cnt[i - 1];
+                if (n == 0 || right_cnt[i] == 0) continue;
+                float cost = acc.half_area() * float(n) + right_area[i] * float(right_cnt[i]);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_split = i;
+                }
+            }
+        }
+        const float leaf_cost = kCostTri * float(count);
+        float split_cost = std::numeric_limits<float>::infinity();
+        if (best_axis >= 0 && parent_area > 0.0f)
+            split_cost = kCostTraverse + kCostTri * best_cost / parent_area;
+        if (count <= size_t(kLeafMax) && leaf_cost <= split_cost) return make_leaf(b, e, box, max_e12);
+
+        size_t mid = b;
+        if (best_axis >= 0) {
+            const float cmin = cbox.lo[best_axis];
+            const float scale = float(kBins) / (cbox.hi[best_axis] - cbox.lo[best_axis]);
+            auto it = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim& p) {
+                int bi = std::min(kBins - 1, std::max(0, int((p.c[best_axis] - cmin) * scale)));
+                return bi < best_split;
+            });
+            mid = size_t(it - prims.begin());
+        }
+        const uint64_t cap = capacity(depth + 1);
+        if (mid == b || mid == e || (mid - b) > cap || (e - mid) > cap) {
+            // degenerate or too unbalanced for the depth budget: median split along the widest axis
+            int axis = 0;
+            for (int k = 1; k < 3; ++k)
+                if (cbox.hi[k] - cbox.lo[k] > cbox.hi[axis] - cbox.lo[axis]) axis = k;
+            mid = b + count / 2;
+            std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
+                             [axis](const Prim& x, const Prim& y) {
+                                 return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
+                             });
+        }
+        const uint32_t node = uint32_t(out.nodes.size());
+        out.nodes.emplace_back();
+        out.max_depth = std::max(out.max_depth, uint32_t(depth));
+        ChildInfo l = build_range(b, mid, depth + 1);
+        ChildInfo r = build_range(mid, e, depth + 1);
+        set_node(node, l, r);
+        return ChildInfo{int32_t(node), box, max_e12};
+    }
+
+    void set_node(uint32_t node, const ChildInfo& l, const ChildInfo& r) {
+        BvhNode& n = out.nodes[node];
+        for (int k = 0; k < 3; ++k) {
+            n.lo0[k] = l.box.lo[k], n.hi0[k] = l.box.hi[k];
+            n.lo1[k] = r.box.lo[k], n.hi1[k] = r.box.hi[k];
+        }
+        n.child0 = l.ref, n.child1 = r.ref;
+        n.max_e12_0 = l.max_e12, n.max_e12_1 = r.max_e12;
+    }
+
+    // A leaf holding one zero-area triangle: |a| = 0 < eps rejects it for every ray
+    // (triangle.rs:198-200), so it stands in for "no child".
+    ChildInfo make_dummy() {
+        uint32_t first = uint32_t(out.tris.size());
+        BvhTri t;
+        std::memset(&t, 0, sizeof(t));
+        t.index = 0xFFFFFFFFu;
+        out.tris.push_back(t);
+        Box b;
+        for (int k = 0; k < 3; ++k) b.lo[k] = b.hi[k] = 0.0f;
+        return ChildInfo{~int32_t((first << 3) | 0), b, 0.0f};
+    }
+
+    void run() {
+        const uint32_t n_tested = (m.n_total / 8u) * 8u;  // triangle.rs:166-167
+        prims.reserve(n_tested);
+        for (uint32_t i = 0; i < n_tested; ++i) {
+            if (m.is_padding && m.is_padding[i]) continue;  // triangle.rs:400
+            Prim p;
+            float v0[3] = {m.v0x[i], m.v0y[i], m.v0z[i]};
+            float e1[3] = {m.e1x[i], m.e1y[i], m.e1z[i]};
+            float e2[3] = {m.e2x[i], m.e2y[i], m.e2z[i]};
+            // Non-finite v0/e1/e2 can never pass the ordered compares of triangle.rs:198-241
+            // (a, u, v or t comes out inf/NaN), so such a triangle is not indexed.
+            bool finite = true;
+            for (int k = 0; k < 3; ++k)
+                finite = finite && std::isfinite(v0[k]) && std::isfinite(e1[k]) && std::isfinite(e2[k]);
+            if (!finite) continue;
+            const float fmax = std::numeric_limits<float>::max();
+            float v1[3], v2[3];
+            for (int k = 0; k < 3; ++k) {  // clamp in case v0 + e overflows
+                v1[k] = std::min(std::max(v0[k] + e1[k], -fmax), fmax);
+                v2[k] = std::min(std::max(v0[k] + e2[k], -fmax), fmax);
+            }
+            p.box.reset();
+            p.box.grow(v0), p.box.grow(v1), p.box.grow(v2);
+            for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * p.box.lo[k] + 0.5f * p.box.hi[k];
+            float l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+            float l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+            p.e12 = l1 * l2;
+            p.idx = i;
+            prims.push_back(p);
+        }
+        out.n_indexed = uint32_t(prims.size());
+        out.nodes.reserve(prims.size() / 2 + 2);
+        out.tris.reserve(prims.size() + 2);
+        if (prims.empty()) {
+            out.nodes.emplace_back();
+            ChildInfo d0 = make_dummy();
+            set_node(0, d0, d0);
+        } else {
+            ChildInfo root = build_range(0, prims.size(), 0);
+            if (root.ref < 0) {  // whole mesh fits one leaf
+                out.nodes.emplace_back();
+                ChildInfo d = make_dummy();
+                set_node(0, root, d);
+            }
+            out.max_e12 = root.max_e12;
+        }
+        prims.clear();
+        prims.shrink_to_fit();
+    }
+};
+
+}  // namespace
+
+BvhBuildResult build_bvh(const rbrt_mesh_t& mesh) {
+    Builder b(mesh);
+    b.run();
+    return std::move(b.out);
+}
+
+}  // namespace rbrt

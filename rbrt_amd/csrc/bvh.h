@@ -1,0 +1,32 @@
+// bvh.h — host-side BVH2 builder for one triangle mesh.
+//
+// The reference has NO acceleration structure beyond one box per mesh (mesh.rs:232-243 tests every
+// triangle for every ray that passes aabbox.rs:28-58). This BVH is purely a culling structure: the
+// device traversal must return exactly what the brute-force scan of triangle.rs:134-262 +
+// triangle.rs:392-410 returns (smallest accepted t, lowest reference index on ties). To that end
+//   - only triangles the scan can ever return are indexed: i < 8*floor(n_total/8)
+//     (chunks_exact(8), triangle.rs:166-167) and !is_padding[i] (triangle.rs:400);
+//   - every node carries max |e1|*|e2| of its subtree, from which the traversal derives a per-ray
+//     inflation of the node boxes that covers the fp32 error of the Moller-Trumbore test
+//     (DESIGN.md "Why the BVH cannot change the answer").
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "device_types.h"
+
+namespace rbrt {
+
+struct BvhBuildResult {
+    std::vector<BvhNode> nodes;  // nodes[0] = root
+    std::vector<BvhTri> tris;    // leaf order
+    float max_e12 = 0.0f;
+    uint32_t max_depth = 0;
+    uint32_t n_indexed = 0;  // triangles in the BVH
+    uint32_t n_leaves = 0;
+};
+
+// Builds over the mesh's SoA arrays (host pointers).
+BvhBuildResult build_bvh(const rbrt_mesh_t& mesh);
+
+}  // namespace rbrt

@@ -1,0 +1,113 @@
+// device_types.h — HBM-resident data layout shared by the host-side builder and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rbrt_hip.h"
+
+namespace rbrt {
+
+// Compile-time limits of the megakernel.
+constexpr int kBlock = 256;        // threads per workgroup = 4 wave64
+constexpr int kStackEntries = 32;  // per-lane traversal stack (LDS); the builder caps the depth to fit
+constexpr int kMaxDepthBuild = 32; // max BVH2 depth (root = 0) => at most 31 deferred children
+constexpr int kMaxPathDepth = 64;  // opts.max_depth limit (reference: 50, lib.rs:99)
+constexpr int kMaxObjects = 255;   // spheres + meshes (object id is stored in one byte per bounce)
+constexpr int kLeafMax = 8;        // triangles per leaf (3-bit count field)
+
+// One BVH2 node = 64 B = half a 128-B cache line, fetched as 4 x dwordx4 by ONE lane.
+// Both child boxes live in the parent so a visit decides both children with one fetch.
+// child >= 0 : index of an inner node; child < 0 : leaf, ~child = (first_tri << 3) | (count - 1).
+// An absent child has an inverted box (lo = +inf, hi = -inf) and can never be entered.
+struct alignas(64) BvhNode {
+    float lo0[3];
+    float hi0[3];
+    float lo1[3];
+    float hi1[3];
+    int32_t child0;
+    int32_t child1;
+    float max_e12_0;  // max over subtree 0 of |e1|*|e2| (error-bound term of the culling pad)
+    float max_e12_1;
+};
+static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
+
+// One triangle record = 48 B (3 x dwordx4), stored in leaf order. The 9 fp32 values are exactly
+// the 9 SoA streams the reference kernel reads (triangle.rs:177-187); `index` is the triangle's
+// position in the reference arrays (ties in t resolve to the lowest index: triangle.rs:400).
+struct alignas(16) BvhTri {
+    float v0[3];
+    float e1x;
+    float e1yz[2];
+    float e2xy[2];
+    float e2z;
+    uint32_t index;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhTri) == 48, "tri must be 48 B");
+
+struct alignas(16) Normal4 {
+    float x, y, z, w;
+};
+
+struct DevSphere {
+    float center[3];
+    float radius;
+};
+
+struct DevMaterial {
+    float albedo[3];
+    float param;
+    int32_t kind;
+};
+
+struct DevMesh {
+    const BvhNode* nodes;
+    const BvhTri* tris;
+    const Normal4* normals;  // [reference index] -> (nx, ny, nz, 0)
+    float bbox_lo[3];
+    float bbox_hi[3];
+    float center[3];  // of the bbox
+    float radius;     // half diagonal of the bbox
+    float max_e12;    // max |e1|*|e2| over the indexed triangles
+    uint32_t n_nodes;
+    uint32_t n_tris;
+};
+
+struct DevCounters {  // mirrors rbrt_hip_stats_t's counters
+    unsigned long long rays, mesh_gate_pass, nodes_visited, tris_tested, mesh_hits, samples,
+        nan_discriminants;
+};
+
+// Kernel arguments of one trace launch (passed by value).
+struct TraceParams {
+    rbrt_camera_t cam;
+    float min_dist, max_dist, eps_frac;  // eps_frac = 1/min_dist (triangle.rs:146)
+    float bg[3];
+    uint32_t max_depth;
+    uint64_t seed_key;  // splitmix64(seed)
+    uint32_t n_spheres, n_meshes;
+    const DevSphere* spheres;
+    const DevMaterial* materials;  // [object id]: spheres first, then meshes
+    const DevMesh* meshes;
+    // work decomposition
+    uint32_t tiles_x, tiles_y, n_tiles;
+    uint32_t tile_rank, tile_world, n_local_tiles;
+    uint32_t sample_base;   // first sample index of this batch
+    uint32_t batch;         // samples in this batch
+    uint64_t n_items;       // n_local_tiles * 64 * batch
+    float* sample_buf;      // [batch][n_local_tiles*64][3]
+    DevCounters* counters;
+};
+
+struct ResolveParams {
+    uint32_t width, height, tiles_x, n_tiles;
+    uint32_t tile_rank, tile_world, n_local_tiles;
+    uint32_t batch;
+    uint32_t first_batch, last_batch;  // flags
+    float inv_spp;                     // 1.0f / spp (lib.rs:101)
+    const float* sample_buf;
+    float* acc;           // [n_local_tiles*64][3] running sum
+    float* out_radiance;  // row-major image if tile_world <= 1, else packed tiles; may be null
+    uint8_t* out_rgb8;    // same indexing; may be null
+};
+
+}  // namespace rbrt

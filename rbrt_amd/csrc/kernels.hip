@@ -1,0 +1,663 @@
+// kernels.hip — gfx950 (MI355X / CDNA4) kernels of the rbrt path-tracing hot path.
+//
+// What runs here is the whole of the reference's L1 layer for one (pixel, sample):
+//   camera ray        cam.rs:64-82
+//   closest hit       scene.rs:19-43 -> sphere.rs:20-66, mesh.rs:225-267 (gate aabbox.rs:28-58,
+//                     Moller-Trumbore triangle.rs:189-255, arg-min triangle.rs:392-410)
+//   scatter           lambertian.rs:11-24, metal.rs:12-25, dielectric.rs:11-85, materials.rs:14-37
+//   integrator        lib.rs:43-73 (depth 50, sky gradient), per-pixel mean lib.rs:95-101,
+//                     quantisation lib.rs:116-122
+// Arithmetic follows the reference operation by operation (f32, mul-then-add, no FMA on any value
+// that reaches the image: this file is compiled with -ffp-contract=off, and IEEE-correct / and sqrt)
+// so that the radiance matches the CPU restatement of the reference bit for bit. The only place
+// the GPU does something the reference does not is culling: triangles are found through a BVH
+// instead of a scan over all of them, with node boxes inflated by a per-ray error bound so that no
+// triangle the scan would accept can be skipped (mesh_closest below).
+//
+// Wave64 only; no MFMA (there is no dense contraction on this path).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+#pragma clang fp contract(off)
+
+namespace rbrt {
+
+// ---------------------------------------------------------------------------------------------
+// Vec3 with the reference's evaluation order (vec3.rs:12-160)
+// ---------------------------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 mk(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 b) { return V3{s * b.x, s * b.y, s * b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float length(V3 a) {
+    return __builtin_sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+}
+__device__ __forceinline__ V3 normalize(V3 a) {  // three divisions, vec3.rs:119-126
+    float len = length(a);
+    return V3{a.x / len, a.y / len, a.z / len};
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Random stream: xoroshiro64** keyed by (seed, pixel, sample); see DESIGN.md "RNG".
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) {
+    return __builtin_rotateleft32(x, k);
+}
+struct Rng {
+    uint32_t s0, s1;
+    __device__ __forceinline__ void init(uint64_t seed_key, uint32_t pixel, uint32_t sample) {
+        uint64_t key = splitmix64(seed_key ^ ((uint64_t(pixel) << 32) | uint64_t(sample)));
+        s0 = uint32_t(key);
+        s1 = uint32_t(key >> 32);
+        if ((s0 | s1) == 0) s0 = 1;
+    }
+    __device__ __forceinline__ uint32_t next_u32() {
+        uint32_t r = rotl32(s0 * 0x9E3779BBu, 5) * 5u;
+        uint32_t t = s1 ^ s0;
+        s0 = rotl32(s0, 26) ^ t ^ (t << 9);
+        s1 = rotl32(t, 13);
+        return r;
+    }
+    // 24-bit uniform in [0,1): rand 0.8's Standard distribution for f32
+    __device__ __forceinline__ float next_f32() {
+        return float(next_u32() >> 8) * (1.0f / 16777216.0f);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Per-thread counters (counting variant only)
+// ---------------------------------------------------------------------------------------------
+struct LocalCounters {
+    uint32_t rays, gate, nodes, tris, mesh_hits;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Geometry
+// ---------------------------------------------------------------------------------------------
+
+// sphere.rs:20-66. Returns true on hit with the ray parameter and the distance.
+__device__ __forceinline__ bool sphere_hit(V3 c, float radius, V3 o, V3 d, float min_dist,
+                                           float max_dist, float& t_out, float& dist_out,
+                                           DevCounters* counters) {
+    float a = dot(d, d);
+    V3 l = o - c;
+    float b = dot(d * 2.0f, l);
+    float cc = dot(l, l) - radius * radius;
+    float sol = b * b - 4.0f * a * cc;
+    if (sol != sol) {  // the reference panics here (sphere.rs:33); count it and miss
+        atomicAdd(&counters->nan_discriminants, 1ull);
+        return false;
+    }
+    if (sol < 0.0f) return false;
+    float t = (-b - __builtin_sqrtf(sol)) / (2.0f * a);
+    if (sol > 0.0f && t < 0.0f) {
+        t = (-b + __builtin_sqrtf(sol)) / (2.0f * a);
+        if (t < 0.0f) return false;
+    }
+    V3 p = o + t * d;
+    float dist = length(o - p);
+    if (dist < min_dist || dist > max_dist) return false;
+    t_out = t;
+    dist_out = dist;
+    return true;
+}
+
+// aabbox.rs:28-58, verbatim: six true divisions, NaN-ignoring min/max (fminf/fmaxf = f32::min/max).
+__device__ __forceinline__ bool bbox_gate(const float* lo, const float* hi, V3 o, V3 d) {
+    float t_lower_x = (lo[0] - o.x) / d.x;
+    float t_upper_x = (hi[0] - o.x) / d.x;
+    float t_lower_y = (lo[1] - o.y) / d.y;
+    float t_upper_y = (hi[1] - o.y) / d.y;
+    float t_lower_z = (lo[2] - o.z) / d.z;
+    float t_upper_z = (hi[2] - o.z) / d.z;
+    float t_min_x = __builtin_fminf(t_lower_x, t_upper_x);
+    float t_min_y = __builtin_fminf(t_lower_y, t_upper_y);
+    float t_min_z = __builtin_fminf(t_lower_z, t_upper_z);
+    float t_min = __builtin_fmaxf(__builtin_fmaxf(t_min_x, t_min_y), t_min_z);
+    float t_max_x = __builtin_fmaxf(t_lower_x, t_upper_x);
+    float t_max_y = __builtin_fmaxf(t_lower_y, t_upper_y);
+    float t_max_z = __builtin_fmaxf(t_lower_z, t_upper_z);
+    float t_max = __builtin_fminf(__builtin_fminf(t_max_x, t_max_y), t_max_z);
+    if (t_max < 0.0f) return false;
+    if (t_min > t_max) return false;
+    return true;
+}
+
+// One lane of triangle.rs:189-255. Every compare is an ordered compare (false on NaN) and the
+// accept expression has the reference's shape: !(c1 | c2 | c3) & c4.
+__device__ __forceinline__ bool tri_test(V3 v0, V3 ea, V3 eb, V3 o, V3 d, float eps, float eps_frac,
+                                         float& t_out) {
+    V3 h = cross(d, eb);
+    float a = dot(ea, h);
+    bool c1 = (-eps < a) && (a < eps);
+    float f = 1.0f / a;
+    V3 s = o - v0;
+    float u = f * dot(s, h);
+    bool c2 = (u < 0.0f) || (u > 1.0f);
+    V3 q = cross(s, ea);
+    float v = f * dot(d, q);
+    bool c3 = (v < 0.0f) || ((u + v) > 1.0f);
+    float t = f * dot(eb, q);
+    bool c4 = (t > eps) && (t < eps_frac);
+    t_out = t;
+    return !(c1 || c2 || c3) && c4;
+}
+
+// Slab test of a box grown by `pad` on every side. Not part of the reference's arithmetic: it only
+// decides which triangles get tested, so FMA-free plain ops are used for simplicity, not parity.
+__device__ __forceinline__ bool slab(const float* lo, const float* hi, float pad, V3 o, V3 inv,
+                                     float eps, float best_t, float& tn_out) {
+    float t0x = ((lo[0] - pad) - o.x) * inv.x, t1x = ((hi[0] + pad) - o.x) * inv.x;
+    float t0y = ((lo[1] - pad) - o.y) * inv.y, t1y = ((hi[1] + pad) - o.y) * inv.y;
+    float t0z = ((lo[2] - pad) - o.z) * inv.z, t1z = ((hi[2] + pad) - o.z) * inv.z;
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                               __builtin_fminf(t0z, t1z));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                               __builtin_fmaxf(t0z, t1z));
+    tn_out = tn;
+    return (tn <= tf) && (tf >= eps) && (tn <= best_t);
+}
+
+// Closest accepted triangle of one mesh = triangle.rs:134-262 + 392-410, found through the BVH.
+//
+// Result contract (what the brute-force scan returns): the smallest accepted t below the scan's
+// initial 1e6; among equal t the lowest reference index. best_t stays 1e6 when nothing is hit.
+//
+// Why culling cannot change the result: a triangle accepted by tri_test with parameter t has its
+// point o + t*d within   err <= ~18 * 2^-24 * (K*|d| + 1) * S   of the triangle's exact surface,
+// K = |e1||e2| / eps (|a| >= eps bounds the amplification of rounding errors in u, v, t), S >= |o - v0|.
+// Node boxes are grown by pad = 64 * 2^-24 * (K_subtree*|d| + 1) * S, so that point is strictly
+// inside every ancestor's grown box, the slab interval contains t, and `tn <= best_t` (not <) keeps
+// equal-t candidates with a lower index reachable.
+template <bool STATS>
+__device__ __forceinline__ void mesh_closest(const DevMesh& M, V3 o, V3 d, float eps, float eps_frac,
+                                             uint32_t* __restrict__ stack, float& best_t_out,
+                                             uint32_t& best_idx_out, LocalCounters& lc) {
+    const float kPad = 64.0f / 16777216.0f;
+    const V3 oc = o - mk(M.center);
+    const float S = length(oc) + M.radius;
+    const float pad_base = kPad * S;
+    const float pad_k = pad_base * (length(d) / eps);
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const BvhNode* __restrict__ nodes = M.nodes;
+    const BvhTri* __restrict__ tris = M.tris;
+
+    float best_t = 1000000.0f;  // triangle.rs:398
+    uint32_t best_idx = 0;
+    int sp = 0;
+    int32_t cur = 0;  // root
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (STATS) ++lc.nodes;
+            const float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
+            const float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
+            const int32_t c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            const float pad0 = pad_base + pad_k * n3.z, pad1 = pad_base + pad_k * n3.w;
+            float tn0, tn1;
+            const bool h0 = slab(lo0, hi0, pad0, o, inv, eps, best_t, tn0);
+            const bool h1 = slab(lo1, hi1, pad1, o, inv, eps, best_t, tn1);
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                stack[sp * kBlock] = uint32_t(swap ? c0 : c1);
+                ++sp;
+                cur = swap ? c1 : c0;
+                continue;
+            }
+            if (h0) {
+                cur = c0;
+                continue;
+            }
+            if (h1) {
+                cur = c1;
+                continue;
+            }
+        } else {
+            const uint32_t leaf = uint32_t(~cur);
+            const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const float4* tp = reinterpret_cast<const float4*>(tris + first + i);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                if (STATS) ++lc.tris;
+                float t;
+                const bool hit = tri_test(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d,
+                                          eps, eps_frac, t);
+                const uint32_t idx = __float_as_uint(c.y);
+                // triangle.rs:400: strict < keeps the first (lowest) index among equal t
+                if (hit && (t < best_t || (t == best_t && idx < best_idx))) {
+                    best_t = t;
+                    best_idx = idx;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = int32_t(stack[sp * kBlock]);
+    }
+    best_t_out = best_t;
+    best_idx_out = best_idx;
+}
+
+struct HitRec {
+    float dist;   // dist_from_ray_orig of the winner (lib.rs:35)
+    float t;      // its ray parameter
+    int32_t obj;  // -1 miss, [0,n_spheres) sphere, n_spheres + m mesh
+    uint32_t tri;
+};
+
+// scene.rs:19-43: spheres in order, then meshes in order, strictly smaller distance wins.
+template <bool STATS>
+__device__ __forceinline__ void scene_hit(const TraceParams& P, V3 o, V3 d, uint32_t* stack, HitRec& h,
+                                          LocalCounters& lc) {
+    float closest = 3.40282347e+38f;  // f32::MAX
+    h.obj = -1;
+    h.t = 0.0f;
+    h.tri = 0;
+    if (STATS) ++lc.rays;
+    for (uint32_t i = 0; i < P.n_spheres; ++i) {
+        const DevSphere sp = P.spheres[i];
+        float t, dist;
+        if (sphere_hit(mk(sp.center), sp.radius, o, d, P.min_dist, P.max_dist, t, dist, P.counters)) {
+            if (dist < closest) {
+                closest = dist;
+                h.t = t;
+                h.obj = int32_t(i);
+            }
+        }
+    }
+    for (uint32_t m = 0; m < P.n_meshes; ++m) {
+        const DevMesh& M = P.meshes[m];
+        if (!bbox_gate(M.bbox_lo, M.bbox_hi, o, d)) continue;  // mesh.rs:233-235
+        if (STATS) ++lc.gate;
+        float t;
+        uint32_t idx;
+        mesh_closest<STATS>(M, o, d, P.min_dist, P.eps_frac, stack, t, idx, lc);
+        if (t > P.min_dist && t < 100000.0f) {  // triangle.rs:405
+            V3 p = o + t * d;                    // mesh.rs:247-249
+            float dist = length(o - p);
+            if (dist > P.min_dist && dist < P.max_dist) {
+                if (STATS) ++lc.mesh_hits;
+                if (dist < closest) {
+                    closest = dist;
+                    h.t = t;
+                    h.obj = int32_t(P.n_spheres + m);
+                    h.tri = idx;
+                }
+            }
+        }
+    }
+    h.dist = closest;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Materials
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 random_point_in_unit_sphere(Rng& rng) {  // materials.rs:14-30
+    V3 p;
+    do {
+        float x = rng.next_f32();
+        float y = rng.next_f32();
+        float z = rng.next_f32();
+        p = 2.0f * mk(x, y, z) - mk(1.0f, 1.0f, 1.0f);
+    } while (length(p) > 1.0f);
+    return p;
+}
+
+__device__ __forceinline__ V3 reflect(V3 dir, V3 n) {  // materials.rs:32-37
+    V3 du = normalize(dir);
+    V3 nu = normalize(n);
+    V3 r = du - 2.0f * nu * dot(du, nu);
+    return normalize(r);
+}
+
+__device__ __forceinline__ float schlick(float cosine, float ref_index) {  // dielectric.rs:63-66
+    float q = (1.0f - ref_index) / (1.0f + ref_index);
+    float r0 = q * q;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    return r0 + (1.0f - r0) * (x * x4);  // powi(5) = x * (x^2)^2
+}
+
+__device__ __forceinline__ bool refract(V3 dir, V3 n, float ni_over_nt, V3& out) {  // dielectric.rs:68-85
+    V3 v = normalize(dir);
+    V3 nu = normalize(n);
+    float c = dot(v, nu);
+    float discr = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - c * c);
+    if (discr > 0.0f) {
+        out = ni_over_nt * (v - nu * c) - __builtin_sqrtf(discr) * nu;
+        return true;
+    }
+    return false;
+}
+
+// RayScattering::scatter for the three materials. Returns the reference's bool; `records`
+// says whether the attenuation is anything other than the exact identity (1,1,1).
+__device__ __forceinline__ bool scatter(const DevMaterial& m, V3 in_d, V3 p, V3 n, Rng& rng, V3& out_d) {
+    if (m.kind == RBRT_MAT_LAMBERTIAN) {  // lambertian.rs:11-24
+        V3 target = (p + normalize(n)) + random_point_in_unit_sphere(rng);
+        out_d = normalize(target - p);
+        return true;
+    } else if (m.kind == RBRT_MAT_METAL) {  // metal.rs:12-25
+        V3 target = reflect(in_d, n);
+        out_d = normalize(target + m.param * random_point_in_unit_sphere(rng));
+        return dot(out_d, n) > 0.0f;
+    } else {  // dielectric.rs:11-59
+        V3 reflected = reflect(in_d, n);
+        V3 outward;
+        float ni_over_nt, cosine;
+        float a = dot(normalize(in_d), normalize(n));
+        if (a > 0.0f) {
+            outward = -1.0f * n;
+            ni_over_nt = m.param;
+            cosine = m.param * a;
+        } else {
+            outward = n;
+            ni_over_nt = 1.0f / m.param;
+            cosine = -a;
+        }
+        V3 refracted = mk(0.0f, 0.0f, 0.0f);
+        float reflect_prob = refract(in_d, outward, ni_over_nt, refracted) ? schlick(cosine, m.param) : 1.0f;
+        out_d = (rng.next_f32() < reflect_prob) ? reflected : refracted;
+        return true;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One path: cam.rs:64-82 + lib.rs:43-73 unrolled into a loop.
+//
+// The reference's recursion multiplies attenuations right to left: a1 * (a2 * (... * leaf)).
+// fp32 products do not associate, so the loop records WHICH object scattered at each bounce (one
+// byte per bounce, in LDS) and folds the product from the innermost bounce outwards at the end.
+// Dielectric bounces multiply by exactly (1,1,1) and are not recorded.
+// ---------------------------------------------------------------------------------------------
+template <bool STATS>
+__device__ __forceinline__ V3 trace_path(const TraceParams& P, uint32_t row, uint32_t col, uint32_t sample,
+                                         uint32_t* stack, uint32_t* seq, LocalCounters& lc) {
+    Rng rng;
+    rng.init(P.seed_key, row * P.cam.img_width_pix + col, sample);
+
+    // cam.rs:64-82
+    const float col_off = float(col) - float(P.cam.img_width_pix / 2);
+    const float row_off = float(row) - float(P.cam.img_height_pix / 2);
+    const float u0 = rng.next_f32();
+    const float col_mm = ((col_off + u0) - 0.5f) * P.cam.mm_per_pix_hor;
+    const float u1 = rng.next_f32();
+    const float row_mm = ((row_off + u1) - 0.5f) * P.cam.mm_per_pix_vert;
+    const V3 pos = mk(P.cam.position);
+    const V3 target =
+        (mk(P.cam.img_center_point) + (0.001f * col_mm) * mk(P.cam.right)) - (0.001f * row_mm) * mk(P.cam.up);
+    V3 o = pos;
+    V3 d = normalize(target - pos);
+
+    V3 color;
+    uint32_t nrec = 0, cur_word = 0;
+    for (uint32_t depth = P.max_depth;; --depth) {
+        HitRec h;
+        scene_hit<STATS>(P, o, d, stack, h, lc);
+        if (h.obj < 0) {  // lib.rs:68-71, with the direction as it is (not re-normalised)
+            const float t = 0.5f * (d.y + 1.0f);
+            color = t * mk(1.0f, 1.0f, 1.0f) + (1.0f - t) * mk(P.bg);
+            break;
+        }
+        if (depth == 0) {  // lib.rs:54: scatter is not even called, no draws
+            color = mk(0.0f, 0.0f, 0.0f);
+            break;
+        }
+        const V3 p = o + h.t * d;  // same expression as inside the intersection routines
+        V3 n;
+        if (uint32_t(h.obj) < P.n_spheres) {
+            n = p - mk(P.spheres[h.obj].center);  // sphere.rs:56, unnormalised
+        } else {
+            const Normal4 nn = P.meshes[uint32_t(h.obj) - P.n_spheres].normals[h.tri];  // mesh.rs:253-257
+            n = mk(nn.x, nn.y, nn.z);
+        }
+        const DevMaterial m = P.materials[h.obj];
+        V3 nd;
+        const bool ok = scatter(m, d, p, n, rng, nd);
+        if (!ok) {  // lib.rs:63-66
+            color = mk(0.0f, 0.0f, 0.0f);
+            break;
+        }
+        if (m.kind != RBRT_MAT_DIELECTRIC) {
+            cur_word |= uint32_t(h.obj) << (8u * (nrec & 3u));
+            if ((nrec & 3u) == 3u) {
+                seq[(nrec >> 2) * kBlock] = cur_word;
+                cur_word = 0;
+            }
+            ++nrec;
+        }
+        o = p;
+        d = nd;
+    }
+    if (nrec & 3u) seq[(nrec >> 2) * kBlock] = cur_word;
+    // lib.rs:62: attenuation * colorize(...), innermost first
+    for (uint32_t k = nrec; k-- > 0;) {
+        const uint32_t w = seq[(k >> 2) * kBlock];
+        const uint32_t obj = (w >> (8u * (k & 3u))) & 0xFFu;
+        const DevMaterial m = P.materials[obj];
+        color = mk(m.albedo) * color;
+    }
+    return color;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernels
+// ---------------------------------------------------------------------------------------------
+
+// LDS carve (dynamic): [kStackEntries][kBlock] u32 traversal stack, then [kMaxPathDepth/4][kBlock]
+// u32 scatter records. Entry-major so that the 64 lanes of a wave hit 64 consecutive banks.
+constexpr size_t kLdsBytes = size_t(kStackEntries + kMaxPathDepth / 4) * kBlock * sizeof(uint32_t);
+
+// Work item i of a batch = (local tile, sample in batch, pixel in tile):
+//   i = (tile_local * batch + s) * 64 + p, so one wave = one 8x8 tile at one sample index (coherent
+// primary rays) and neighbouring waves work on the same tile (shared BVH working set in L1/L2).
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* stack = lds + threadIdx.x;
+    uint32_t* seq = lds + kStackEntries * kBlock + threadIdx.x;
+
+    const uint64_t item = uint64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (item >= P.n_items) return;
+    const uint32_t p = uint32_t(item & 63u);
+    const uint64_t ts = item >> 6;
+    const uint32_t s = uint32_t(ts % P.batch);
+    const uint32_t tile_local = uint32_t(ts / P.batch);
+    const uint32_t tile = tile_local * P.tile_world + P.tile_rank;
+    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const uint32_t row = ty * RBRT_TILE + (p >> 3), col = tx * RBRT_TILE + (p & 7u);
+    if (row >= P.cam.img_height_pix || col >= P.cam.img_width_pix) return;
+
+    LocalCounters lc = {0, 0, 0, 0, 0};
+    const V3 c = trace_path<STATS>(P, row, col, P.sample_base + s, stack, seq, lc);
+
+    const size_t npix = size_t(P.n_local_tiles) * 64u;
+    float* out = P.sample_buf + (size_t(s) * npix + size_t(tile_local) * 64u + p) * 3u;
+    out[0] = c.x;
+    out[1] = c.y;
+    out[2] = c.z;
+    if (STATS) {
+        atomicAdd(&P.counters->rays, (unsigned long long)lc.rays);
+        atomicAdd(&P.counters->mesh_gate_pass, (unsigned long long)lc.gate);
+        atomicAdd(&P.counters->nodes_visited, (unsigned long long)lc.nodes);
+        atomicAdd(&P.counters->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&P.counters->mesh_hits, (unsigned long long)lc.mesh_hits);
+        atomicAdd(&P.counters->samples, 1ull);
+    }
+}
+
+// lib.rs:116-122: (sqrt(c) * 256) as u8 — Rust's float->int cast saturates and maps NaN to 0.
+__device__ __forceinline__ uint8_t quantise(float c) {
+    float v = __builtin_sqrtf(c) * 256.0f;
+    if (!(v == v)) return 0;
+    if (v <= 0.0f) return 0;
+    if (v >= 255.0f) return 255;
+    return uint8_t(v);
+}
+
+// Sequential per-pixel sum over the samples of this batch (lib.rs:95-100 adds them in sample
+// order; keeping that order keeps the mean bit-identical), then on the last batch the multiply by
+// 1/spp (lib.rs:101) and the optional quantisation.
+__global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) {
+    const size_t npix = size_t(R.n_local_tiles) * 64u;
+    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    const uint32_t tile_local = uint32_t(i >> 6), p = uint32_t(i & 63u);
+    const uint32_t tile = tile_local * R.tile_world + R.tile_rank;
+    const uint32_t ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
+    const uint32_t row = ty * RBRT_TILE + (p >> 3), col = tx * RBRT_TILE + (p & 7u);
+    const bool valid = row < R.height && col < R.width;
+    const bool packed = R.tile_world > 1;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    if (valid) {
+        if (!R.first_batch) {
+            ax = R.acc[i * 3 + 0];
+            ay = R.acc[i * 3 + 1];
+            az = R.acc[i * 3 + 2];
+        }
+        for (uint32_t s = 0; s < R.batch; ++s) {
+            const float* sp = R.sample_buf + (size_t(s) * npix + i) * 3u;
+            ax = ax + sp[0];
+            ay = ay + sp[1];
+            az = az + sp[2];
+        }
+        if (!R.last_batch) {
+            R.acc[i * 3 + 0] = ax;
+            R.acc[i * 3 + 1] = ay;
+            R.acc[i * 3 + 2] = az;
+            return;
+        }
+        ax = ax * R.inv_spp;
+        ay = ay * R.inv_spp;
+        az = az * R.inv_spp;
+    } else if (!R.last_batch || !packed) {
+        return;
+    }
+    const size_t o = packed ? i * 3u : (size_t(row) * R.width + col) * 3u;
+    if (R.out_radiance) {
+        R.out_radiance[o + 0] = ax;
+        R.out_radiance[o + 1] = ay;
+        R.out_radiance[o + 2] = az;
+    }
+    if (R.out_rgb8) {
+        R.out_rgb8[o + 0] = quantise(ax);
+        R.out_rgb8[o + 1] = quantise(ay);
+        R.out_rgb8[o + 2] = quantise(az);
+    }
+}
+
+__host__ __device__ inline uint32_t local_tiles_of(uint32_t n_tiles, uint32_t rank, uint32_t world) {
+    return rank < n_tiles ? (n_tiles - rank + world - 1u) / world : 0u;
+}
+
+// Gathered per-rank packed tiles -> row-major image (rank r's block starts after the blocks of
+// ranks < r; inside a block tiles are in ascending global tile order).
+__global__ __launch_bounds__(kBlock) void unpack_kernel(const float* __restrict__ gathered, uint32_t width,
+                                                        uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
+                                                        uint32_t world, float* out_radiance,
+                                                        uint8_t* out_rgb8) {
+    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= size_t(width) * height) return;
+    const uint32_t row = uint32_t(i / width), col = uint32_t(i - size_t(row) * width);
+    const uint32_t tile = (row / RBRT_TILE) * tiles_x + col / RBRT_TILE;
+    const uint32_t rank = tile % world, tile_local = tile / world;
+    size_t base = 0;
+    for (uint32_t r = 0; r < rank; ++r) base += size_t(local_tiles_of(n_tiles, r, world)) * 64u;
+    const size_t src = (base + size_t(tile_local) * 64u + (row % RBRT_TILE) * RBRT_TILE + col % RBRT_TILE) * 3u;
+    const float x = gathered[src], y = gathered[src + 1], z = gathered[src + 2];
+    if (out_radiance) {
+        out_radiance[i * 3 + 0] = x;
+        out_radiance[i * 3 + 1] = y;
+        out_radiance[i * 3 + 2] = z;
+    }
+    if (out_rgb8) {
+        out_rgb8[i * 3 + 0] = quantise(x);
+        out_rgb8[i * 3 + 1] = quantise(y);
+        out_rgb8[i * 3 + 2] = quantise(z);
+    }
+}
+
+// Scene::hit for arbitrary rays (test / diagnostic hook behind rbrt_hip_trace_rays).
+__global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceParams P, const float* __restrict__ rays,
+                                                            size_t n, float* out_t, int32_t* out_obj,
+                                                            int32_t* out_tri, float* out_dist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* stack = lds + threadIdx.x;
+    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = mk(rays + 6 * i), d = mk(rays + 6 * i + 3);
+    HitRec h;
+    LocalCounters lc = {0, 0, 0, 0, 0};
+    scene_hit<false>(P, o, d, stack, h, lc);
+    const bool hit = h.obj >= 0;
+    const float nanv = __int_as_float(0x7fc00000);
+    if (out_t) out_t[i] = hit ? h.t : nanv;
+    if (out_obj) out_obj[i] = h.obj;
+    if (out_tri) out_tri[i] = (hit && uint32_t(h.obj) >= P.n_spheres) ? int32_t(h.tri) : -1;
+    if (out_dist) out_dist[i] = hit ? h.dist : nanv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch wrappers (called from api.cpp, which is plain C++)
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_trace(const TraceParams& P, bool stats, hipStream_t stream) {
+    const uint64_t blocks = (P.n_items + kBlock - 1) / kBlock;
+    if (blocks == 0) return hipSuccess;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (stats)
+        hipLaunchKernelGGL(trace_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), kLdsBytes, stream, P);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), kLdsBytes, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream) {
+    const size_t npix = size_t(R.n_local_tiles) * 64u;
+    if (npix == 0) return hipSuccess;
+    hipLaunchKernelGGL(resolve_kernel, dim3(uint32_t((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, R);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
+                         float* out_radiance, uint8_t* out_rgb8, hipStream_t stream) {
+    const uint32_t tiles_x = (width + RBRT_TILE - 1) / RBRT_TILE, tiles_y = (height + RBRT_TILE - 1) / RBRT_TILE;
+    const size_t n = size_t(width) * height;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, gathered,
+                       width, height, tiles_x, tiles_x * tiles_y, world, out_radiance, out_rgb8);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, float* out_t, int32_t* out_obj,
+                             int32_t* out_tri, float* out_dist, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(trace_rays_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock),
+                       size_t(kStackEntries) * kBlock * sizeof(uint32_t), stream, P, rays, n, out_t, out_obj,
+                       out_tri, out_dist);
+    return hipGetLastError();
+}
+
+uint64_t host_splitmix64(uint64_t x) { return splitmix64(x); }
+
+}  // namespace rbrt

@@ -1,0 +1,30 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): oracle/pyoracle.py over oracle/librbrt_oracle.so."""
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library. No fallback: a missing .so or a missing GPU is an error, not a skip."""
+    import rbrt_amd
+    rbrt_amd.load_hip()
+    n = rbrt_amd.device_count()
+    assert n >= 1, "gpu-marked test running without a HIP device"
+    return rbrt_amd
