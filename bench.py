@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — Mray-samples/s of the HIP path-tracing hot path on BASELINE config 2.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one full render of the workload: scenes/example_scene.yaml (the reference's example scene)
+with the 69,451-triangle STAND-IN for bunny.obj (the real asset is not available offline),
+1024x768, 50 samples per pixel, seed 1. With N ranks the image's 8x8 pixel tiles are dealt
+round-robin to the ranks (every rank holds the whole scene + BVH), each rank renders its tiles with
+the same kernel, and one RCCL gather over xGMI brings the packed fp32 radiance to rank 0, which
+de-interleaves it — so the total work per step is fixed ("scaling": "strong").
+
+The scene is resident in HBM before the timed region (upload + BVH build are setup); the timed
+region is K x [render kernels + gather + unpack], bracketed by barrier + synchronize, MAX over ranks.
+
+Rank 0 prints ONE JSON line with, besides the contract's fields:
+  roofline     — the trace kernel's algorithmic bytes / its HIP-event duration vs 8 TB/s HBM
+  cpu_baseline — the CPU oracle (a C++ restatement of the reference's AVX path; the Rust reference
+                 cannot be built here) timed on this host on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+TRI_ALG_BYTES = 36     # the 9 fp32 SoA values Moller-Trumbore reads per triangle (triangle.rs:177-187)
+NORMAL_ALG_BYTES = 12  # normal fetch per accepted mesh hit (mesh.rs:253-257)
+PIXEL_ALG_BYTES = 12   # fp32 radiance store per pixel
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=768)
+    ap.add_argument("--spp", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--triangles", type=int, default=69451)
+    ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
+    ap.add_argument("--cpu-col-stride", type=int, default=16,
+                    help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline)")
+    ap.add_argument("--check", action="store_true", help="also compare the sampled columns with the GPU image")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    import rbrt_amd
+    from rbrt_amd import abi, standin
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- setup (untimed): stand-in asset, YAML through the C++ host, upload + BVH build ---------
+    work = Path(tempfile.mkdtemp(prefix=f"rbrt_bench_r{rank}_"))
+    real_asset = Path("bunny.obj").exists() and args.triangles == standin.BUNNY_TRIANGLES
+    obj = Path("bunny.obj").resolve() if real_asset else standin.ensure_obj(work / "bunny.obj", args.triangles)
+    yaml_text = Path(args.scene).read_text().replace("obj_filepath: bunny.obj", f"obj_filepath: {obj}")
+    (work / "scene.yaml").write_text(yaml_text)
+    devnull = os.open(os.devnull, os.O_WRONLY)  # the host prints the reference's progress lines
+    saved = os.dup(1)
+    os.dup2(devnull, 1)
+    try:
+        host_scene = abi.HostScene(work / "scene.yaml", args.height, args.width)
+    finally:
+        os.dup2(saved, 1)
+        os.close(devnull)
+    cam = host_scene.camera
+    W, H, spp = args.width, args.height, args.spp
+    t0 = time.perf_counter()
+    scene = rbrt_amd.HipScene(host_scene, device=local_rank)
+    setup_s = time.perf_counter() - t0
+    opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=world)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    image = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+    if world > 1:
+        sizes = [rbrt_amd.packed_pixels(W, H, r, world) * 3 for r in range(world)]
+        maxn = max(sizes)
+        mine = torch.empty(maxn, dtype=torch.float32, device=dev)  # equal-size gather, tail unused
+        gathered = [torch.empty(maxn, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+        packed = torch.empty(sum(sizes), dtype=torch.float32, device=dev) if rank == 0 else None
+
+    def step():
+        if world == 1:
+            scene.render_device(cam, opts, image.data_ptr(), None, stream)
+            return
+        scene.render_device(cam, opts, mine.data_ptr(), None, stream)
+        dist.gather(mine, gathered, dst=0)
+        if rank == 0:
+            off = 0
+            for r in range(world):  # drop the equal-size padding
+                packed[off:off + sizes[r]].copy_(gathered[r][:sizes[r]])
+                off += sizes[r]
+            rbrt_amd.unpack_tiles(local_rank, packed.data_ptr(), W, H, world, image.data_ptr(), None, stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- counting pass (untimed): the work counters behind the algorithmic-bytes figure ----------
+    stats_opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=world,
+                                  flags=abi.FLAG_COLLECT_STATS)
+    n_out = rbrt_amd.packed_pixels(W, H, rank, world) * 3 if world > 1 else W * H * 3
+    scratch = torch.empty(n_out, dtype=torch.float32, device=dev)
+    scene.render_device(cam, stats_opts, scratch.data_ptr(), None, stream)
+    torch.cuda.synchronize()
+    st = scene.stats()
+    del scratch
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    scene.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    trace_ms, resolve_ms, n_launches = scene.kernel_ms()
+    scene.set_timing(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    samples_per_step = W * H * spp
+    value = samples_per_step * args.steps / elapsed / 1e6
+    # dominant kernel = trace_kernel; algorithmic bytes of ONE launch on this rank (DESIGN.md "Measurement")
+    local_pixels = (rbrt_amd.packed_pixels(W, H, rank, world) if world > 1 else W * H)
+    alg_bytes = (st["nodes_visited"] * st["node_bytes"] + st["tris_tested"] * TRI_ALG_BYTES +
+                 st["mesh_hits"] * NORMAL_ALG_BYTES + local_pixels * PIXEL_ALG_BYTES)
+    kernel_ms = trace_ms / max(1, n_launches)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = None
+    tf = ROOT / "profiles" / "pmc_traffic.json"  # measured with rocprofv3 --pmc in its own run
+    if tf.exists() and world == 1:
+        try:
+            rec = json.loads(tf.read_text())
+            if rec.get("workload") == f"{W}x{H}x{spp}" and rec.get("triangles") == args.triangles:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": n_launches,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "counters": {k: st[k] for k in ("rays", "mesh_gate_pass", "nodes_visited", "tris_tested", "mesh_hits")}}
+
+    out = {
+        "metric": "Mray-samples/sec (WxHxspp/s) on bunny scene; achieved HBM GB/s vs peak",
+        "value": round(value, 2), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"example_scene.yaml, {args.triangles}-triangle "
+                               f"{'bunny.obj' if real_asset else 'stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
+                   "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
+                   "setup_s_excluded": round(setup_s, 3),
+                   "resolve_kernel_ms": round(resolve_ms / max(1, n_launches), 4)},
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline (rank 0, N = 1 only): bounded sample of the same workload ---------------------
+    if world == 1 and args.cpu_col_stride > 0:
+        from oracle import pyoracle  # the checker, used here only as the timed CPU baseline
+        n_threads = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
+        cols = len(range(0, W, args.cpu_col_stride))
+        t0 = time.perf_counter()
+        rad, _, cpu_rays = pyoracle.render(cam, host_scene, abi.default_opts(spp=spp, seed=args.seed),
+                                           n_threads=n_threads, want_rgb8=False, col_stride=args.cpu_col_stride)
+        cpu_s = time.perf_counter() - t0
+        cpu_samples = cols * H * spp
+        out["cpu_baseline"] = {
+            "value": round(cpu_samples / cpu_s / 1e6, 4), "unit": "Mray-samples/s", "cores": n_threads,
+            "kind": "port",
+            "sample": f"every {args.cpu_col_stride}th column ({cols} of {W}) x {H} rows x {spp} spp of the same "
+                      f"scene and seed, {cpu_s:.1f} s; C++ restatement of the reference AVX path (brute force over "
+                      f"all triangles), not the Rust binary",
+        }
+        if args.check:
+            import numpy as np
+            gpu = image.cpu().numpy()[:, ::args.cpu_col_stride]
+            cpu = rad[:, ::args.cpu_col_stride]
+            out["cpu_baseline"]["gpu_matches_bitwise"] = bool(np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32)))
+            out["cpu_baseline"]["rmse"] = float(np.sqrt(np.mean((gpu.astype(np.float64) - cpu) ** 2)))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

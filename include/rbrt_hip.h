@@ -218,11 +218,13 @@ void rbrt_render_opts_default(rbrt_render_opts_t* opts); /* spp = 5 (src/main.rs
 int rbrt_hip_device_count(void);                         /* >= 0, or negative status */
 const char* rbrt_hip_last_error(void);
 int rbrt_hip_abi_version(void);
-/* Most recent kernel timing of this scene handle in milliseconds, measured with HIP events
- * recorded on the launch stream around the render kernel only (requires a prior
- * rbrt_hip_scene_set_timing(scene, 1); reading it synchronises on the stop event). */
+/* Kernel timing with HIP events recorded on the launch stream around every trace-kernel launch
+ * (and the resolve kernel after it). set_timing(scene, 1) starts / restarts the accumulation;
+ * kernel_ms sums the durations of all launches since then (it synchronises on the last event) and
+ * returns how many trace launches that was. */
 int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* scene, int enable);
-int rbrt_hip_scene_last_kernel_ms(rbrt_hip_scene_t* scene, float* trace_ms, float* resolve_ms);
+int rbrt_hip_scene_kernel_ms(rbrt_hip_scene_t* scene, float* trace_ms_total, float* resolve_ms_total,
+                             uint32_t* n_trace_launches);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,7 @@ def lib() -> C.CDLL:
     L = C.CDLL(str(LIB))
     L.rbrt_oracle_render_window.restype = C.c_uint64
     L.rbrt_oracle_render_window.argtypes = [C.POINTER(abi.Camera), C.POINTER(abi.Scene), C.POINTER(abi.RenderOpts),
-                                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, f32p, u8p]
+                                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, f32p, u8p]
     L.rbrt_oracle_render.restype = C.c_uint64
     L.rbrt_oracle_render.argtypes = [C.POINTER(abi.Camera), C.POINTER(abi.Scene), C.POINTER(abi.RenderOpts),
                                      C.c_int, f32p, u8p]
@@ -113,14 +113,14 @@ def mesh_prep(tri_vertices, scale=1.0, rotation=(0, 0, 0), translation=(0, 0, 0)
 
 # ---- rendering -------------------------------------------------------------------------------
 
-def render(cam: abi.Camera, scene: abi.SceneData, opts: abi.RenderOpts, n_threads: int = 0, window=None,
-           want_rgb8: bool = True):
+def render(cam: abi.Camera, scene, opts: abi.RenderOpts, n_threads: int = 0, window=None,
+           want_rgb8: bool = True, col_stride: int = 1):
     """Returns (radiance[H,W,3] f32, rgb8[H,W,3] u8 or None, n_rays)."""
     H, W = cam.img_height_pix, cam.img_width_pix
     rad = np.zeros((H, W, 3), np.float32)
     rgb = np.zeros((H, W, 3), np.uint8) if want_rgb8 else None
     c0, c1, r0, r1 = window if window is not None else (0, W, 0, H)
-    rays = lib().rbrt_oracle_render_window(C.byref(cam), scene.ptr(), C.byref(opts), c0, c1, r0, r1, n_threads,
+    rays = lib().rbrt_oracle_render_window(C.byref(cam), scene.ptr(), C.byref(opts), c0, c1, r0, r1, col_stride, n_threads,
                                            _p(rad), rgb.ctypes.data_as(u8p) if want_rgb8 else None)
     return rad, rgb, int(rays)
 

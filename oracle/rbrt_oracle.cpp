@@ -468,25 +468,27 @@ inline uint8_t quantise(float c) {
 extern "C" {
 
 // lib.rs:75-124 restricted to columns [c0,c1) x rows [r0,r1) (full image: 0,W,0,H). Pixels outside
-// the window are left untouched. Threads pull columns from a shared counter (rayon's par_iter over
+// the window are left untouched; col_stride > 1 renders only every col_stride-th column of the window
+// (an unbiased sample of the image's workload for the CPU-baseline timing). Threads pull columns from a shared counter (rayon's par_iter over
 // columns, lib.rs:84-86); per-pixel arithmetic is sequential so the result is thread-count independent.
 // Returns the number of Scene::hit calls made (for the CPU-baseline report).
 uint64_t rbrt_oracle_render_window(const rbrt_camera_t* cam, const rbrt_scene_t* scene,
                                    const rbrt_render_opts_t* opts, uint32_t c0, uint32_t c1,
-                                   uint32_t r0, uint32_t r1, int n_threads, float* out_radiance,
-                                   uint8_t* out_rgb8) {
+                                   uint32_t r0, uint32_t r1, uint32_t col_stride, int n_threads,
+                                   float* out_radiance, uint8_t* out_rgb8) {
     const uint32_t W = cam->img_width_pix, H = cam->img_height_pix;
     if (c1 > W) c1 = W;
     if (r1 > H) r1 = H;
     if (n_threads <= 0) n_threads = int(std::thread::hardware_concurrency());
     if (n_threads <= 0) n_threads = 1;
-    std::atomic<uint32_t> next_col{c0};
+    if (col_stride == 0) col_stride = 1;
+    std::atomic<uint32_t> next_col{0};
     std::atomic<uint64_t> total_rays{0};
     const V3 bg = v3(opts->bg);
     auto worker = [&]() {
         uint64_t rays = 0;
         for (;;) {
-            uint32_t col = next_col.fetch_add(1);
+            uint32_t col = c0 + next_col.fetch_add(1) * col_stride;
             if (col >= c1) break;
             for (uint32_t row = r0; row < r1; ++row) {
                 V3 color = v3(0, 0, 0);
@@ -521,7 +523,7 @@ uint64_t rbrt_oracle_render_window(const rbrt_camera_t* cam, const rbrt_scene_t*
 uint64_t rbrt_oracle_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene,
                             const rbrt_render_opts_t* opts, int n_threads, float* out_radiance,
                             uint8_t* out_rgb8) {
-    return rbrt_oracle_render_window(cam, scene, opts, 0, cam->img_width_pix, 0, cam->img_height_pix,
+    return rbrt_oracle_render_window(cam, scene, opts, 0, cam->img_width_pix, 0, cam->img_height_pix, 1,
                                      n_threads, out_radiance, out_rgb8);
 }
 

@@ -76,10 +76,11 @@ class HipScene:
     def set_timing(self, on: bool = True):
         abi.check(self._lib.rbrt_hip_scene_set_timing(self._h, int(on)))
 
-    def last_kernel_ms(self):
-        t, r = C.c_float(), C.c_float()
-        abi.check(self._lib.rbrt_hip_scene_last_kernel_ms(self._h, C.byref(t), C.byref(r)))
-        return t.value, r.value
+    def kernel_ms(self):
+        """(total trace-kernel ms, total resolve-kernel ms, number of trace launches) since set_timing(True)."""
+        t, r, n = C.c_float(), C.c_float(), C.c_uint32()
+        abi.check(self._lib.rbrt_hip_scene_kernel_ms(self._h, C.byref(t), C.byref(r), C.byref(n)))
+        return t.value, r.value, n.value
 
     def stats(self) -> dict:
         st = abi.Stats()

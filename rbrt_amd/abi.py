@@ -132,7 +132,7 @@ HIP_SYMBOLS = {
     "rbrt_hip_last_error": (C.c_char_p, []),
     "rbrt_hip_abi_version": (C.c_int, []),
     "rbrt_hip_scene_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
-    "rbrt_hip_scene_last_kernel_ms": (C.c_int, [C.c_void_p, f32p, f32p]),
+    "rbrt_hip_scene_kernel_ms": (C.c_int, [C.c_void_p, f32p, f32p, C.POINTER(C.c_uint32)]),
 }
 
 
@@ -145,6 +145,30 @@ class RbrtError(RuntimeError):
 _hip = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.
+
+    The PyTorch wheel bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and finds it by file
+    name, so a process that loaded /opt/rocm's copy first ends up with two HIP/HSA runtimes and
+    torch then reports "No HIP GPUs are available". bench.py and some tests use torch for device
+    buffers and torch.distributed next to this library, so when torch is installed its runtime is
+    loaded first and librbrt_hip.so's NEEDED libamdhip64.so.7 binds to that same copy. Without
+    torch (the C++ host, a Rust host) the system runtime under /opt/rocm is used as usual.
+    """
+    if os.environ.get("RBRT_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+        if cand.exists():
+            C.CDLL(str(cand), mode=getattr(os, "RTLD_GLOBAL", 0x100) | getattr(os, "RTLD_NOW", 2))
+    except OSError:
+        pass
+
+
 def load_hip() -> C.CDLL:
     """Load the product library. Fails loudly when it has not been built: no fallback exists."""
     global _hip
@@ -154,6 +178,7 @@ def load_hip() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_HIP} is missing: build it with `make` (or __graft_entry__.build()). "
             "rbrt_amd has no CPU or pure-Python render path.")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(str(LIB_HIP), mode=getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in HIP_SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
@@ -239,3 +264,78 @@ def default_opts(spp: int = 5, seed: int = 1, **kw) -> RenderOpts:
         else:
             setattr(o, k, v)
     return o
+
+
+# ------------------------------------------------------------------------------------------
+# C++ host library (rbrt_amd/host): YAML scene -> camera + SoA meshes, PNG writer
+# ------------------------------------------------------------------------------------------
+_host = None
+
+
+def load_host() -> C.CDLL:
+    global _host
+    if _host is not None:
+        return _host
+    if not LIB_HOST.exists():
+        raise FileNotFoundError(f"{LIB_HOST} is missing: build it with `make`")
+    lib = C.CDLL(str(LIB_HOST))
+    lib.rbrt_host_last_error.restype = C.c_char_p
+    lib.rbrt_host_scene_load.restype = C.c_int
+    lib.rbrt_host_scene_load.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.rbrt_host_scene_camera.restype = C.POINTER(Camera)
+    lib.rbrt_host_scene_camera.argtypes = [C.c_void_p]
+    lib.rbrt_host_scene_scene.restype = C.POINTER(Scene)
+    lib.rbrt_host_scene_scene.argtypes = [C.c_void_p]
+    lib.rbrt_host_scene_free.restype = None
+    lib.rbrt_host_scene_free.argtypes = [C.c_void_p]
+    lib.rbrt_host_write_png.restype = C.c_int
+    lib.rbrt_host_write_png.argtypes = [C.c_char_p, u8p, C.c_uint32, C.c_uint32]
+    lib.rbrt_host_camera_new.restype = None
+    lib.rbrt_host_camera_new.argtypes = [f32p, f32p, f32p, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(Camera)]
+    _host = lib
+    return lib
+
+
+class HostScene:
+    """A scene loaded by the C++ host from a YAML file (src/main.rs:70-80). Quacks like SceneData:
+    `.ptr()` gives the rbrt_scene_t*, `.camera` the rbrt_camera_t for the requested image size."""
+
+    def __init__(self, yaml_path, height: int, width: int):
+        self._lib = load_host()
+        self._h = C.c_void_p()
+        rc = self._lib.rbrt_host_scene_load(str(yaml_path).encode(), height, width, C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("rbrt_host_scene_load: " + self._lib.rbrt_host_last_error().decode(errors="replace"))
+        self.camera = Camera()
+        C.memmove(C.byref(self.camera), self._lib.rbrt_host_scene_camera(self._h), C.sizeof(Camera))
+        self.struct = self._lib.rbrt_host_scene_scene(self._h).contents
+
+    def ptr(self):
+        return C.byref(self.struct)
+
+    def mesh_arrays(self, i: int) -> dict:
+        m = self.struct.meshes[i]
+        out = {k: np.ctypeslib.as_array(getattr(m, k), (m.n_total,)).copy() for k in MeshData.FIELDS}
+        out["is_padding"] = np.ctypeslib.as_array(m.is_padding, (m.n_total,)).copy()
+        out["bbox_lo"] = np.array(list(m.bbox_lo), np.float32)
+        out["bbox_hi"] = np.array(list(m.bbox_hi), np.float32)
+        out["n_real"] = m.n_real
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.rbrt_host_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_png(path, rgb8: np.ndarray) -> None:
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    h, w, _ = rgb8.shape
+    if load_host().rbrt_host_write_png(str(path).encode(), rgb8.ctypes.data_as(u8p), w, h) != 0:
+        raise RuntimeError(load_host().rbrt_host_last_error().decode(errors="replace"))

@@ -267,14 +267,16 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
 int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* s, int enable) {
     if (!s) return fail(RBRT_ERR_INVALID_ARG, "null scene");
     s->timing = enable != 0;
+    s->events_used = 0;
     return RBRT_OK;
 }
 
-int rbrt_hip_scene_last_kernel_ms(rbrt_hip_scene_t* s, float* trace_ms, float* resolve_ms) {
+int rbrt_hip_scene_kernel_ms(rbrt_hip_scene_t* s, float* trace_ms, float* resolve_ms, uint32_t* n_launches) {
     if (!s) return fail(RBRT_ERR_INVALID_ARG, "null scene");
-    if (!s->timing || s->events_used == 0) return fail(RBRT_ERR_INVALID_ARG, "no timed render on this scene");
+    if (!s->timing) return fail(RBRT_ERR_INVALID_ARG, "timing is not enabled on this scene");
     HIP_TRY(hipSetDevice(s->device));
     float tsum = 0.0f, rsum = 0.0f;
+    uint32_t n = 0;
     for (size_t b = 0; b + 3 <= s->events_used; b += 3) {
         HIP_TRY(hipEventSynchronize(s->events[b + 2]));
         float t = 0.0f, r = 0.0f;
@@ -282,9 +284,11 @@ int rbrt_hip_scene_last_kernel_ms(rbrt_hip_scene_t* s, float* trace_ms, float* r
         HIP_TRY(hipEventElapsedTime(&r, s->events[b + 1], s->events[b + 2]));
         tsum += t;
         rsum += r;
+        ++n;
     }
     if (trace_ms) *trace_ms = tsum;
     if (resolve_ms) *resolve_ms = rsum;
+    if (n_launches) *n_launches = n;
     return RBRT_OK;
 }
 
@@ -361,29 +365,29 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
 
     const size_t n_batches = (size_t(o->spp) + batch - 1) / batch;
     if (s->timing) {
-        while (s->events.size() < 3 * n_batches) {
+        while (s->events.size() < s->events_used + 3 * n_batches) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
             s->events.push_back(e);
         }
-        s->events_used = 0;
     }
+    const size_t ev0 = s->events_used;
     for (size_t b = 0; b < n_batches; ++b) {
         const uint32_t base = uint32_t(b * batch);
         const uint32_t nb = uint32_t(std::min<size_t>(batch, o->spp - base));
         P.sample_base = base;
         P.batch = nb;
         P.n_items = uint64_t(npix) * nb;
-        if (s->timing) HIP_TRY(hipEventRecord(s->events[3 * b], stream));
+        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));
         HIP_TRY(launch_trace(P, stats, stream));
-        if (s->timing) HIP_TRY(hipEventRecord(s->events[3 * b + 1], stream));
+        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], stream));
         R.batch = nb;
         R.first_batch = b == 0;
         R.last_batch = b + 1 == n_batches;
         HIP_TRY(launch_resolve(R, stream));
         if (s->timing) {
-            HIP_TRY(hipEventRecord(s->events[3 * b + 2], stream));
-            s->events_used = 3 * (b + 1);
+            HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 2], stream));
+            s->events_used = ev0 + 3 * (b + 1);
         }
     }
     return RBRT_OK;
