@@ -135,6 +135,7 @@ def main():
     scene.render_device(cam, stats_opts, scratch.data_ptr(), None, stream)
     torch.cuda.synchronize()
     st = scene.stats()
+    dbg = scene.debug_counters() if os.environ.get("RBRT_BENCH_DEBUG") else None
     del scratch
 
     for _ in range(args.warmup):
@@ -217,6 +218,8 @@ def main():
             cpu = rad[:, ::args.cpu_col_stride]
             out["cpu_baseline"]["gpu_matches_bitwise"] = bool(np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32)))
             out["cpu_baseline"]["rmse"] = float(np.sqrt(np.mean((gpu.astype(np.float64) - cpu) ** 2)))
+    if dbg is not None:
+        out["debug_counters"] = dbg
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -205,6 +205,12 @@ int rbrt_hip_trace_rays(rbrt_hip_scene_t* scene, const float* rays, size_t n, fl
                         float max_dist, float* out_t, int32_t* out_obj, int32_t* out_tri,
                         float* out_dist);
 
+/* Diagnostic: pass statistics of the persistent megakernel from the last render with
+ * RBRT_FLAG_COLLECT_STATS: out[0..5] passes per kind (empty, traverse, terminate, lambertian, metal,
+ * dielectric), out[6..11] path slots handled per kind, out[12] traversal wave-steps, out[13] busy
+ * lane-steps, out[14] refill rounds, out[15] scheduling rounds. */
+int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* scene, uint64_t* out, size_t n);
+
 /* Diagnostic: run the host-side BVH builder alone (needs no device). *nodes_out / *tris_out are
  * malloc'ed copies of the 64-B node and 48-B triangle records (layout: rbrt_amd/csrc/device_types.h);
  * release them with rbrt_hip_free_host. */

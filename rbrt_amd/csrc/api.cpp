@@ -14,7 +14,11 @@
 #include "device_types.h"
 
 namespace rbrt {
-hipError_t launch_trace(const TraceParams& P, bool stats, hipStream_t stream);
+hipError_t launch_trace_v1(const TraceParams& P, bool stats, hipStream_t stream);
+hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats,
+                                   hipStream_t stream);
+size_t megakernel_gseq_bytes(uint32_t n_waves);
+size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
                          float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
@@ -73,6 +77,13 @@ struct rbrt_hip_scene {
     size_t sample_buf_bytes = 0;
     float* d_acc = nullptr;
     size_t acc_bytes = 0;
+    unsigned long long* d_work_counter = nullptr;
+    uint32_t* d_gseq = nullptr;
+    uint32_t n_waves = 0;  // persistent megakernel grid: as many single-wave workgroups as fit the LDS
+    uint32_t pool = 192;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
+    uint32_t stack_entries = 2;   // deepest BVH of the scene + 2
+    uint32_t y_low_water = 48;    // RBRT_Y_LOW
+    bool use_v1 = false;   // RBRT_TRACE_KERNEL=v1: the one-thread-per-path kernel (kept for A/B timing)
     // stats / timing
     rbrt_hip_stats_t stats{};
     bool stats_pending = false;
@@ -238,6 +249,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         dm.max_e12 = bvh.max_e12;
         dm.n_nodes = uint32_t(bvh.nodes.size());
         dm.n_tris = uint32_t(bvh.tris.size());
+        s->stack_entries = std::max(s->stack_entries, std::min<uint32_t>(bvh.max_depth + 2u, uint32_t(kStackEntries)));
         s->total_nodes += bvh.nodes.size();
         s->total_tris += bvh.tris.size();
     }
@@ -248,6 +260,34 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         std::vector<DevCounters> z(1);
         std::memset(z.data(), 0, sizeof(DevCounters));
         if (int rc = upload(s, z, &s->d_counters)) return bail(rc);
+    }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(RBRT_ERR_HIP, "hipGetDeviceProperties failed"));
+        int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (const char* e = std::getenv("RBRT_POOL")) {
+            int v = std::atoi(e);
+            if (v == 128 || v == 192 || v == 256) s->pool = uint32_t(v);
+        }
+        if (const char* e = std::getenv("RBRT_Y_LOW")) {
+            int v = std::atoi(e);
+            if (v >= 1 && v <= 64) s->y_low_water = uint32_t(v);
+        }
+        // resident waves per CU: LDS-limited (160 KiB per CU), at most 5 per SIMD (VGPR budget)
+        int per_cu = int((160u * 1024u) / megakernel_lds_bytes(s->pool, s->stack_entries));
+        if (per_cu > 20) per_cu = 20;
+        if (per_cu < 1) per_cu = 1;
+        if (const char* e = std::getenv("RBRT_WAVES_PER_CU")) {
+            int v = std::atoi(e);
+            if (v > 0 && v <= 32) per_cu = v;
+        }
+        s->n_waves = uint32_t(cus * per_cu);
+        const char* k = std::getenv("RBRT_TRACE_KERNEL");
+        s->use_v1 = k && std::strcmp(k, "v1") == 0;
+        std::vector<uint32_t> zeros(megakernel_gseq_bytes(s->n_waves) / sizeof(uint32_t), 0u);
+        if (int rc = upload(s, zeros, &s->d_gseq)) return bail(rc);
+        std::vector<unsigned long long> zc(8, 0ull);
+        if (int rc = upload(s, zc, &s->d_work_counter)) return bail(rc);
     }
     *out = s;
     return RBRT_OK;
@@ -317,6 +357,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     // workspace: as many samples per batch as fit the cap (at least one)
     const size_t per_sample = npix * 3u * sizeof(float);
     size_t batch = workspace_cap_bytes() / per_sample;
+    if (batch * npix > 0xFFF00000ull) batch = 0xFFF00000ull / npix;  // work items are 32-bit in the kernel
     if (batch < 1) batch = 1;
     if (batch > o->spp) batch = o->spp;
     const size_t need = batch * per_sample;
@@ -352,6 +393,10 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     P.tiles_x = tiles_x, P.tiles_y = tiles_y, P.n_tiles = n_tiles;
     P.tile_rank = o->tile_rank, P.tile_world = world, P.n_local_tiles = n_local;
     P.sample_buf = s->d_sample_buf;
+    P.work_counter = s->d_work_counter;
+    P.gseq = s->d_gseq;
+    P.stack_entries = s->stack_entries;
+    P.y_low_water = s->y_low_water;
 
     ResolveParams R;
     std::memset(&R, 0, sizeof(R));
@@ -379,7 +424,13 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         P.batch = nb;
         P.n_items = uint64_t(npix) * nb;
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));
-        HIP_TRY(launch_trace(P, stats, stream));
+        if (s->use_v1) {
+            HIP_TRY(launch_trace_v1(P, stats, stream));
+        } else {
+            HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(unsigned long long), stream));
+            if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));  // after the memset node
+            HIP_TRY(launch_trace_megakernel(P, s->n_waves, s->pool, stats, stream));
+        }
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], stream));
         R.batch = nb;
         R.first_batch = b == 0;
@@ -494,6 +545,17 @@ int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const r
     if (c.nan_discriminants)
         return fail(RBRT_ERR_NAN, "a sphere discriminant was NaN (the reference panics: sphere.rs:33); "
                                   "those rays were treated as misses");
+    return RBRT_OK;
+}
+
+// Diagnostic: the megakernel's pass statistics of the last counting render (layout: DevCounters::diag).
+int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* s, uint64_t* out, size_t n) {
+    if (!s || !out) return fail(RBRT_ERR_INVALID_ARG, "debug_counters: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    DevCounters c;
+    HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n && i < 16; ++i) out[i] = c.diag[i];
     return RBRT_OK;
 }
 

@@ -13,6 +13,7 @@ constexpr int kMaxDepthBuild = 32; // max BVH2 depth (root = 0) => at most 31 de
 constexpr int kMaxPathDepth = 64;  // opts.max_depth limit (reference: 50, lib.rs:99)
 constexpr int kMaxObjects = 255;   // spheres + meshes (object id is stored in one byte per bounce)
 constexpr int kLeafMax = 8;        // triangles per leaf (3-bit count field)
+constexpr int kPoolMax = 256;      // largest path pool per wave the persistent megakernel is built for
 
 // One BVH2 node = 64 B = half a 128-B cache line, fetched as 4 x dwordx4 by ONE lane.
 // Both child boxes live in the parent so a visit decides both children with one fetch.
@@ -75,6 +76,10 @@ struct DevMesh {
 struct DevCounters {  // mirrors rbrt_hip_stats_t's counters
     unsigned long long rays, mesh_gate_pass, nodes_visited, tris_tested, mesh_hits, samples,
         nan_discriminants;
+    // megakernel diagnostics (counting variant only; rbrt_hip_scene_debug_counters):
+    // [0..5] passes per status kind, [6..11] lanes used per kind, [12] traversal wave-steps,
+    // [13] active lane-steps, [14] refill rounds, [15] census rounds
+    unsigned long long diag[16];
 };
 
 // Kernel arguments of one trace launch (passed by value).
@@ -96,6 +101,11 @@ struct TraceParams {
     uint64_t n_items;       // n_local_tiles * 64 * batch
     float* sample_buf;      // [batch][n_local_tiles*64][3]
     DevCounters* counters;
+    // persistent megakernel only
+    unsigned long long* work_counter;  // next unclaimed work item (zeroed before every launch)
+    uint32_t* gseq;                    // [n_waves][kPoolMax][kMaxPathDepth/4] scatter records beyond the 4 kept in LDS
+    uint32_t stack_entries;            // per-lane traversal stack depth = deepest BVH + 2
+    uint32_t y_low_water;              // refill a traversal pass when fewer lanes than this are busy
 };
 
 struct ResolveParams {

@@ -507,6 +507,8 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams P) {
     }
 }
 
+#include "megakernel.inl"
+
 // lib.rs:116-122: (sqrt(c) * 256) as u8 — Rust's float->int cast saturates and maps NaN to 0.
 __device__ __forceinline__ uint8_t quantise(float c) {
     float v = __builtin_sqrtf(c) * 256.0f;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceParams P,
 // ---------------------------------------------------------------------------------------------
 // Launch wrappers (called from api.cpp, which is plain C++)
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_trace(const TraceParams& P, bool stats, hipStream_t stream) {
+hipError_t launch_trace_v1(const TraceParams& P, bool stats, hipStream_t stream) {
     const uint64_t blocks = (P.n_items + kBlock - 1) / kBlock;
     if (blocks == 0) return hipSuccess;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
@@ -629,6 +631,37 @@ hipError_t launch_trace(const TraceParams& P, bool stats, hipStream_t stream) {
         hipLaunchKernelGGL(trace_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), kLdsBytes, stream, P);
     else
         hipLaunchKernelGGL(trace_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), kLdsBytes, stream, P);
+    return hipGetLastError();
+}
+
+size_t megakernel_gseq_bytes(uint32_t n_waves) { return size_t(n_waves) * kPoolMax * kSeqWords * sizeof(uint32_t); }
+
+size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries) {
+    return (size_t(kFields) * pool + 2u * pool + size_t(stack_entries) * 64u) * sizeof(uint32_t);
+}
+
+// n_waves single-wave workgroups; each loops until the global work counter (zeroed by the caller on
+// this stream) runs out, so any grid size is correct and no wave ever waits on another.
+hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats,
+                                   hipStream_t stream) {
+    if (P.n_items == 0 || n_waves == 0) return hipSuccess;
+    const size_t lds = megakernel_lds_bytes(pool, P.stack_entries);
+#define RBRT_LAUNCH_MK(POOLN)                                                                              \
+    do {                                                                                                   \
+        if (stats)                                                                                         \
+            hipLaunchKernelGGL((trace_megakernel<POOLN, true>), dim3(n_waves), dim3(64), lds, stream, P);  \
+        else                                                                                               \
+            hipLaunchKernelGGL((trace_megakernel<POOLN, false>), dim3(n_waves), dim3(64), lds, stream, P); \
+    } while (0)
+    if (pool == 128)
+        RBRT_LAUNCH_MK(128);
+    else if (pool == 192)
+        RBRT_LAUNCH_MK(192);
+    else if (pool == 256)
+        RBRT_LAUNCH_MK(256);
+    else
+        return hipErrorInvalidValue;
+#undef RBRT_LAUNCH_MK
     return hipGetLastError();
 }
 

@@ -1,0 +1,495 @@
+// megakernel.inl — the persistent path-tracing megakernel (included by kernels.hip).
+//
+// One wave64 per workgroup, a pool of POOLN path slots in LDS, and wavefront ballots to sort the
+// paths into passes in which all 64 lanes run the same code.
+//
+// Why (measured, profiles/r01_v1_pmc_sq.json): with one thread per path only 15 % of the VALU lanes
+// did useful work — paths end after very different bounce counts, only ~28 % of the rays pass the
+// mesh gate at all, and the material branches serialise. So the wave keeps many more paths than
+// lanes and, each round, picks ONE kind of work that enough slots are waiting for:
+//   TERM  pass: finished paths (miss / depth 0): sky colour, attenuation fold, sample store, then a
+//               fresh path from the global work counter (cam.rs:64-82); also fills empty slots
+//   LAMB / METAL / DIEL pass: RayScattering::scatter of that one material, no branch divergence
+//   ... each followed by the closest-sphere tests and the mesh bbox gate for the new ray
+//   traversal : rays that passed a gate are "parked"; the 64 lanes traverse the BVH with a per-lane
+//               stack in LDS and keep their traversal state in registers ACROSS shading passes, so a
+//               lane that finishes is finalised and refilled (in batches) as soon as parked rays
+//               exist and there is never a tail of a few long traversals holding a wave
+// Which lane works on which path never affects the result: a path owns its RNG stream and its
+// sample slot, and resolve_kernel adds the samples of a pixel in sample order.
+
+enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_S0, F_S1, F_ITEM, F_META, F_DIST, F_T, F_TRI, F_WORD, kFields };
+enum : uint32_t { ST_EMPTY = 0u, ST_TRAV = 1u, ST_TERM = 2u, ST_LAMB = 3u, ST_METAL = 4u, ST_DIEL = 5u, kNumStatus = 6u,
+                  ST_BUSY = 6u /* being traversed by a lane right now */ };
+constexpr int kSeqWords = kMaxPathDepth / 4;
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+// meta word: depth left [0,7) | records [7,14) | object id + 1 [14,22) | mesh index [22,30)
+__device__ __forceinline__ uint32_t pack_meta(uint32_t depth, uint32_t nrec, int32_t obj, uint32_t mesh) {
+    return depth | (nrec << 7) | (uint32_t(obj + 1) << 14) | (mesh << 22);
+}
+
+// First mesh with index >= m0 whose bbox gate (aabbox.rs:28-58) the ray passes, or n_meshes.
+template <bool STATS>
+__device__ __forceinline__ uint32_t next_gated_mesh(const TraceParams& P, uint32_t m0, V3 o, V3 d, LocalCounters& lc) {
+    uint32_t m = m0;
+    for (; m < P.n_meshes; ++m) {
+        if (bbox_gate(P.meshes[m].bbox_lo, P.meshes[m].bbox_hi, o, d)) {
+            if (STATS) ++lc.gate;
+            break;
+        }
+    }
+    return m;
+}
+
+// What has to happen next to a path whose closest hit is known.
+__device__ __forceinline__ uint32_t classify(const TraceParams& P, int32_t obj, uint32_t depth) {
+    if (obj < 0 || depth == 0) return ST_TERM;  // lib.rs:54,68
+    return ST_LAMB + uint32_t(P.materials[obj].kind);
+}
+
+// Culling-only slab test (never feeds the image): box grown by pad, planes through one FMA each.
+// nod = -(o * inv). See mesh_closest for why the pad makes culling result-invariant; the FMA form
+// adds an error of ~eps*|o| per plane which pad_base covers (it includes 64*eps*|o|_inf).
+__device__ __forceinline__ bool slab_fast(const float* lo, const float* hi, float pad, V3 inv, V3 nod, float eps,
+                                          float best_t, float& tn_out) {
+    const float t0x = __builtin_fmaf(lo[0] - pad, inv.x, nod.x), t1x = __builtin_fmaf(hi[0] + pad, inv.x, nod.x);
+    const float t0y = __builtin_fmaf(lo[1] - pad, inv.y, nod.y), t1y = __builtin_fmaf(hi[1] + pad, inv.y, nod.y);
+    const float t0z = __builtin_fmaf(lo[2] - pad, inv.z, nod.z), t1z = __builtin_fmaf(hi[2] + pad, inv.z, nod.z);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                     __builtin_fminf(t0z, t1z));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                                     __builtin_fmaxf(t0z, t1z));
+    tn_out = tn;
+    return (tn <= tf) && (tf >= eps) && (tn <= best_t);
+}
+
+template <int POOLN, bool STATS>
+__global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* const pool = lds;
+    uint32_t* const status = pool + kFields * POOLN;
+    uint32_t* const list = status + POOLN;
+    const uint32_t lane = threadIdx.x;
+    uint32_t* const stack = list + POOLN + lane;
+    uint32_t* const gseq = P.gseq + size_t(blockIdx.x) * kPoolMax * kSeqWords;
+#define POOL(f, s) pool[(f) * POOLN + (s)]
+
+    for (uint32_t s = lane; s < uint32_t(POOLN); s += 64) status[s] = ST_EMPTY;
+    LocalCounters lc = {0, 0, 0, 0, 0};
+    uint32_t n_samples_done = 0;
+    uint32_t dg_pass[kNumStatus] = {0, 0, 0, 0, 0, 0}, dg_lanes[kNumStatus] = {0, 0, 0, 0, 0, 0};
+    uint32_t dg_steps = 0, dg_lane_steps = 0, dg_refills = 0, dg_census = 0;
+    bool more_work = true;  // wave-uniform: the global work counter has not run out yet
+    const size_t npix = size_t(P.n_local_tiles) * 64u;
+    const float eps = P.min_dist;
+
+    // ---- per-lane traversal state; lives in registers across shading passes ----
+    bool t_active = false;      // this lane is in the middle of a traversal
+    bool t_has_result = false;  // this lane finished a traversal that is not finalised yet
+    uint32_t t_slot = 0;
+    V3 t_o = mk(0.0f, 0.0f, 0.0f), t_d = t_o, t_inv = t_o, t_nod = t_o;
+    float t_pad_base = 0.0f, t_pad_k = 0.0f, t_best = 0.0f;
+    uint32_t t_best_idx = 0, t_mesh = 0;
+    const BvhNode* t_nodes = nullptr;
+    const BvhTri* t_tris = nullptr;
+    int t_sp = 0;
+    int32_t t_cur = 0;
+
+    for (;;) {
+        // ---- finalise finished traversals in a batch (mesh.rs:245-266, scene.rs:33-41) ----
+        if (__any(t_has_result)) {
+            if (t_has_result) {
+                const uint32_t slot = t_slot;
+                float closest = __uint_as_float(POOL(F_DIST, slot));
+                const uint32_t meta = POOL(F_META, slot);
+                int32_t obj = int32_t((meta >> 14) & 255u) - 1;
+                if (t_best > eps && t_best < 100000.0f) {  // triangle.rs:405
+                    const V3 p = t_o + t_best * t_d;
+                    const float dist = length(t_o - p);
+                    if (dist > P.min_dist && dist < P.max_dist) {
+                        if (STATS) ++lc.mesh_hits;
+                        if (dist < closest) {
+                            closest = dist;
+                            obj = int32_t(P.n_spheres + t_mesh);
+                            POOL(F_DIST, slot) = __float_as_uint(dist);
+                            POOL(F_T, slot) = __float_as_uint(t_best);
+                            POOL(F_TRI, slot) = t_best_idx;
+                        }
+                    }
+                }
+                const uint32_t m2 = next_gated_mesh<STATS>(P, t_mesh + 1u, t_o, t_d, lc);
+                const uint32_t depth = meta & 127u;
+                POOL(F_META, slot) = pack_meta(depth, (meta >> 7) & 127u, obj, m2 < P.n_meshes ? m2 : 0u);
+                status[slot] = m2 < P.n_meshes ? ST_TRAV : classify(P, obj, depth);
+                t_has_result = false;
+            }
+        }
+        __syncthreads();
+        // ---- census: how many slots wait for each kind of work ---------------------------------
+        uint32_t cnt[kNumStatus] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t g = 0; g < uint32_t(POOLN); g += 64) {
+            const uint32_t st = status[g + lane];
+#pragma unroll
+            for (uint32_t k = 0; k < kNumStatus; ++k) cnt[k] += uint32_t(__popcll(__ballot(st == k)));
+        }
+        if (STATS) ++dg_census;
+        uint32_t n_active = uint32_t(__popcll(__ballot(t_active)));
+
+        // ---- idle lanes take parked rays (in batches: only when enough lanes are idle) ----
+        if (cnt[ST_TRAV] != 0 && (n_active < P.y_low_water || n_active + cnt[ST_TRAV] <= 64u)) {
+            uint32_t ny = 0;
+#pragma unroll
+            for (uint32_t g = 0; g < uint32_t(POOLN); g += 64) {
+                const bool m = status[g + lane] == ST_TRAV;
+                const uint64_t mask = __ballot(m);
+                if (m) list[ny + lane_rank(mask)] = g + lane;
+                ny += uint32_t(__popcll(mask));
+            }
+            __syncthreads();
+            if (STATS) ++dg_refills;
+            const uint64_t idle = __ballot(!t_active);
+            if (!t_active) {
+                const uint32_t k = lane_rank(idle);
+                if (k < ny) {
+                    const uint32_t slot = list[k];
+                    t_slot = slot;
+                    status[slot] = ST_BUSY;
+                    t_o = mk(__uint_as_float(POOL(F_OX, slot)), __uint_as_float(POOL(F_OY, slot)),
+                             __uint_as_float(POOL(F_OZ, slot)));
+                    t_d = mk(__uint_as_float(POOL(F_DX, slot)), __uint_as_float(POOL(F_DY, slot)),
+                             __uint_as_float(POOL(F_DZ, slot)));
+                    t_mesh = (POOL(F_META, slot) >> 22) & 255u;
+                    const DevMesh& M = P.meshes[t_mesh];
+                    t_nodes = M.nodes;
+                    t_tris = M.tris;
+                    // culling-only quantities: fast reciprocal / sqrt are fine here
+                    const V3 oc = t_o - mk(M.center);
+                    const float S = __builtin_amdgcn_sqrtf(dot(oc, oc)) + M.radius;
+                    const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t_o.x), __builtin_fabsf(t_o.y)),
+                                                       __builtin_fabsf(t_o.z));
+                    t_pad_base = (64.0f / 16777216.0f) * (S + omax);
+                    t_pad_k = t_pad_base * (__builtin_amdgcn_sqrtf(dot(t_d, t_d)) * P.eps_frac);
+                    t_inv = mk(__builtin_amdgcn_rcpf(t_d.x), __builtin_amdgcn_rcpf(t_d.y), __builtin_amdgcn_rcpf(t_d.z));
+                    t_nod = mk(-(t_o.x * t_inv.x), -(t_o.y * t_inv.y), -(t_o.z * t_inv.z));
+                    t_best = 1000000.0f;  // triangle.rs:398
+                    t_best_idx = 0;
+                    t_sp = 0;
+                    t_cur = 0;
+                    t_active = true;
+                    if (STATS) ++dg_lanes[ST_TRAV];
+                }
+            }
+            const uint32_t taken = uint32_t(__popcll(idle)) < ny ? uint32_t(__popcll(idle)) : ny;
+            cnt[ST_TRAV] -= taken;
+            n_active += taken;
+        }
+
+        // ---- pick the shading kind with the most waiting slots ----
+        // A TERM pass also starts new paths in empty slots while work is left.
+        const uint32_t n_gen_slots = more_work ? cnt[ST_EMPTY] : 0u;
+        uint32_t kind = ST_TERM, best = cnt[ST_TERM] + n_gen_slots;
+        if (cnt[ST_LAMB] > best) kind = ST_LAMB, best = cnt[ST_LAMB];
+        if (cnt[ST_METAL] > best) kind = ST_METAL, best = cnt[ST_METAL];
+        if (cnt[ST_DIEL] > best) kind = ST_DIEL, best = cnt[ST_DIEL];
+        if (best == 0 && n_active == 0) break;  // nothing waits, nothing runs, no work left
+
+        // Traverse while the lanes are well filled; shade when they are not (that is what parks new
+        // rays) or when shading work has piled up to a full wave.
+        const bool traverse = n_active != 0 && (best == 0 || (n_active >= P.y_low_water && best < 64u));
+        if (traverse) {
+            if (STATS) {
+                ++dg_pass[ST_TRAV];
+                if (best == 0) ++dg_pass[ST_EMPTY];  // diag[0]: traversal entered because nothing else to do
+                dg_lanes[ST_EMPTY] += n_active;       // diag[6]: sum of busy lanes at entry
+            }
+            // leave as soon as enough lanes are idle to make a refill / shading pass worthwhile; when no
+            // other work exists, as soon as one lane has a result (it creates shading work)
+            const uint32_t keep = (best != 0 || cnt[ST_TRAV] != 0) ? (n_active < P.y_low_water ? n_active : P.y_low_water)
+                                                                   : n_active;
+            do {
+                if (STATS) {
+                    ++dg_steps;
+                    dg_lane_steps += uint32_t(__popcll(__ballot(t_active)));
+                }
+                if (t_active) {
+                    bool pop = true;
+                    if (t_cur >= 0) {
+                        const float4* np = reinterpret_cast<const float4*>(t_nodes + t_cur);
+                        const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                        if (STATS) ++lc.nodes;
+                        const float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
+                        const float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
+                        const int32_t c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                        float tn0, tn1;
+                        const bool h0 = slab_fast(lo0, hi0, __builtin_fmaf(t_pad_k, n3.z, t_pad_base), t_inv, t_nod, eps,
+                                                  t_best, tn0);
+                        const bool h1 = slab_fast(lo1, hi1, __builtin_fmaf(t_pad_k, n3.w, t_pad_base), t_inv, t_nod, eps,
+                                                  t_best, tn1);
+                        if (h0 && h1) {
+                            const bool swap = tn1 < tn0;
+                            stack[t_sp * 64] = uint32_t(swap ? c0 : c1);
+                            ++t_sp;
+                            t_cur = swap ? c1 : c0;
+                            pop = false;
+                        } else if (h0 || h1) {
+                            t_cur = h0 ? c0 : c1;
+                            pop = false;
+                        }
+                    } else {
+                        const uint32_t leaf = uint32_t(~t_cur);
+                        const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+                        for (uint32_t i = 0; i < count; ++i) {
+                            const float4* tp = reinterpret_cast<const float4*>(t_tris + first + i);
+                            const float4 a = tp[0], b = tp[1], c = tp[2];
+                            if (STATS) ++lc.tris;
+                            float t;
+                            const bool hit = tri_test(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t_o, t_d,
+                                                      eps, P.eps_frac, t);
+                            const uint32_t idx = __float_as_uint(c.y);
+                            // triangle.rs:400: strict < keeps the lowest index among equal t
+                            if (hit && (t < t_best || (t == t_best && idx < t_best_idx))) {
+                                t_best = t;
+                                t_best_idx = idx;
+                            }
+                        }
+                    }
+                    if (pop) {
+                        if (t_sp == 0) {
+                            t_active = false;
+                            t_has_result = true;
+                        } else {
+                            --t_sp;
+                            t_cur = int32_t(stack[t_sp * 64]);
+                        }
+                    }
+                }
+            } while (uint32_t(__popcll(__ballot(t_active))) >= keep);
+            continue;
+        }
+
+        // ============================ shading pass of one kind ===============================
+        if (STATS) ++dg_pass[kind];
+        uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < uint32_t(POOLN); g += 64) {
+            const bool m = status[g + lane] == kind;
+            const uint64_t mask = __ballot(m);
+            if (m) list[c0 + lane_rank(mask)] = g + lane;
+            c0 += uint32_t(__popcll(mask));
+        }
+        const uint32_t n_main = c0 < 64u ? c0 : 64u;
+        if (kind == ST_TERM && n_gen_slots != 0 && n_main < 64u) {
+#pragma unroll
+            for (uint32_t g = 0; g < uint32_t(POOLN); g += 64) {
+                const bool m = status[g + lane] == ST_EMPTY;
+                const uint64_t mask = __ballot(m);
+                if (m) list[c0 + c1 + lane_rank(mask)] = g + lane;  // c0 + c1 <= POOLN
+                c1 += uint32_t(__popcll(mask));
+            }
+        }
+        const uint32_t n_gen = c1 < 64u - n_main ? c1 : 64u - n_main;
+        __syncthreads();
+        const bool is_main = lane < n_main;
+        const bool is_gen = !is_main && lane < n_main + n_gen;
+        if (STATS) dg_lanes[kind] += n_main + n_gen;
+        const uint32_t slot = is_main ? list[lane] : (is_gen ? list[c0 + (lane - n_main)] : 0u);
+
+        V3 o = mk(0.0f, 0.0f, 0.0f), d = o;
+        Rng rng = {0u, 0u};
+        uint32_t item = 0, depth = 0, nrec = 0, word = 0;
+        bool have_ray = false;
+
+        if (kind == ST_TERM) {
+            bool need_new = is_gen;
+            if (is_main) {
+                const uint32_t meta = POOL(F_META, slot);
+                nrec = (meta >> 7) & 127u;
+                const int32_t obj = int32_t((meta >> 14) & 255u) - 1;
+                V3 color = mk(0.0f, 0.0f, 0.0f);  // hit with depth 0 or a failed scatter: lib.rs:63-66
+                if (obj < 0) {                    // lib.rs:68-71, direction as is (not re-normalised)
+                    const float dy = __uint_as_float(POOL(F_DY, slot));
+                    const float t = 0.5f * (dy + 1.0f);
+                    color = t * mk(1.0f, 1.0f, 1.0f) + (1.0f - t) * mk(P.bg);
+                }
+                if (nrec != 0) {  // lib.rs:62: attenuation * colorize(...), innermost bounce first
+                    word = POOL(F_WORD, slot);
+                    for (uint32_t k = nrec; k-- > 0;) {
+                        const uint32_t w = (k >> 2) == (nrec >> 2) ? word : gseq[size_t(slot) * kSeqWords + (k >> 2)];
+                        const uint32_t ob = (w >> (8u * (k & 3u))) & 0xFFu;
+                        color = mk(P.materials[ob].albedo) * color;
+                    }
+                }
+                item = POOL(F_ITEM, slot);
+                const uint32_t pp = item & 63u;
+                const uint32_t ts = item >> 6;
+                const uint32_t s = ts % P.batch, tile_local = ts / P.batch;
+                float* out = P.sample_buf + (size_t(s) * npix + size_t(tile_local) * 64u + pp) * 3u;
+                out[0] = color.x;
+                out[1] = color.y;
+                out[2] = color.z;
+                if (STATS) ++n_samples_done;
+                need_new = true;
+            }
+            // ---- new paths (cam.rs:64-82); work items come from one global counter ----
+            const uint64_t want = __ballot(need_new && more_work);
+            if (want) {
+                const uint32_t n_want = uint32_t(__popcll(want));
+                const uint32_t leader = uint32_t(__builtin_ctzll(want));
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(P.work_counter, (unsigned long long)n_want);
+                base = (unsigned long long)__shfl(uint32_t(base), int(leader)) |
+                       ((unsigned long long)__shfl(uint32_t(base >> 32), int(leader)) << 32);
+                bool ran_out = false;
+                if (need_new) {
+                    const unsigned long long it = base + lane_rank(want);
+                    if (it < P.n_items) {
+                        item = uint32_t(it);
+                        const uint32_t pp = item & 63u;
+                        const uint32_t ts = item >> 6;
+                        const uint32_t s = ts % P.batch, tile_local = ts / P.batch;
+                        const uint32_t tile = tile_local * P.tile_world + P.tile_rank;
+                        const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+                        const uint32_t row = ty * RBRT_TILE + (pp >> 3), col = tx * RBRT_TILE + (pp & 7u);
+                        if (row < P.cam.img_height_pix && col < P.cam.img_width_pix) {
+                            rng.init(P.seed_key, row * P.cam.img_width_pix + col, P.sample_base + s);
+                            const float col_off = float(col) - float(P.cam.img_width_pix / 2);
+                            const float row_off = float(row) - float(P.cam.img_height_pix / 2);
+                            const float u0 = rng.next_f32();
+                            const float col_mm = ((col_off + u0) - 0.5f) * P.cam.mm_per_pix_hor;
+                            const float u1 = rng.next_f32();
+                            const float row_mm = ((row_off + u1) - 0.5f) * P.cam.mm_per_pix_vert;
+                            const V3 pos = mk(P.cam.position);
+                            const V3 target = (mk(P.cam.img_center_point) + (0.001f * col_mm) * mk(P.cam.right)) -
+                                              (0.001f * row_mm) * mk(P.cam.up);
+                            o = pos;
+                            d = normalize(target - pos);
+                            depth = P.max_depth;
+                            nrec = 0;
+                            word = 0;
+                            have_ray = true;
+                        }
+                    } else {
+                        ran_out = true;
+                    }
+                }
+                if (__any(ran_out)) more_work = false;
+            }
+        } else if (is_main) {
+            // ---- RayScattering::scatter for one material kind (wave-uniform branch) ----
+            o = mk(__uint_as_float(POOL(F_OX, slot)), __uint_as_float(POOL(F_OY, slot)),
+                   __uint_as_float(POOL(F_OZ, slot)));
+            d = mk(__uint_as_float(POOL(F_DX, slot)), __uint_as_float(POOL(F_DY, slot)),
+                   __uint_as_float(POOL(F_DZ, slot)));
+            rng.s0 = POOL(F_S0, slot);
+            rng.s1 = POOL(F_S1, slot);
+            item = POOL(F_ITEM, slot);
+            word = POOL(F_WORD, slot);
+            const uint32_t meta = POOL(F_META, slot);
+            depth = meta & 127u;
+            nrec = (meta >> 7) & 127u;
+            const int32_t obj = int32_t((meta >> 14) & 255u) - 1;
+            const float ht = __uint_as_float(POOL(F_T, slot));
+            const V3 p = o + ht * d;  // same expression as inside the intersection routines
+            V3 n;
+            if (uint32_t(obj) < P.n_spheres) {
+                n = p - mk(P.spheres[obj].center);  // sphere.rs:56, unnormalised
+            } else {
+                const Normal4 nn = P.meshes[uint32_t(obj) - P.n_spheres].normals[POOL(F_TRI, slot)];
+                n = mk(nn.x, nn.y, nn.z);  // mesh.rs:253-257
+            }
+            const DevMaterial m = P.materials[obj];
+            V3 nd;
+            bool ok;
+            if (kind == ST_LAMB) {  // lambertian.rs:11-24
+                const V3 target = (p + normalize(n)) + random_point_in_unit_sphere(rng);
+                nd = normalize(target - p);
+                ok = true;
+            } else if (kind == ST_METAL) {  // metal.rs:12-25
+                const V3 target = reflect(d, n);
+                nd = normalize(target + m.param * random_point_in_unit_sphere(rng));
+                ok = dot(nd, n) > 0.0f;
+            } else {  // dielectric.rs:11-59
+                ok = scatter(m, d, p, n, rng, nd);
+            }
+            if (ok) {
+                if (kind != ST_DIEL) {  // attenuation (1,1,1) is an exact identity, not recorded
+                    word |= uint32_t(obj) << (8u * (nrec & 3u));
+                    if ((nrec & 3u) == 3u) {
+                        gseq[size_t(slot) * kSeqWords + (nrec >> 2)] = word;
+                        word = 0;
+                    }
+                    ++nrec;
+                }
+                o = p;
+                d = nd;
+                depth -= 1;
+                have_ray = true;
+            } else {
+                // metal.rs:25 returned false: the path is black (lib.rs:63-66). Park it for a TERM
+                // pass with depth 0 so that the fold/store/regenerate code lives in one place.
+                POOL(F_META, slot) = pack_meta(0u, nrec, obj, 0u);
+                POOL(F_WORD, slot) = word;
+                status[slot] = ST_TERM;
+            }
+        }
+
+        // ---- closest sphere + mesh gate for the new ray (scene.rs:19-43 up to the meshes) ----
+        if (have_ray) {
+            if (STATS) ++lc.rays;
+            float closest = 3.40282347e+38f, ht = 0.0f;
+            int32_t obj = -1;
+            for (uint32_t i = 0; i < P.n_spheres; ++i) {
+                const DevSphere sp = P.spheres[i];
+                float t, dist;
+                if (sphere_hit(mk(sp.center), sp.radius, o, d, P.min_dist, P.max_dist, t, dist, P.counters)) {
+                    if (dist < closest) {
+                        closest = dist;
+                        ht = t;
+                        obj = int32_t(i);
+                    }
+                }
+            }
+            const uint32_t m = next_gated_mesh<STATS>(P, 0, o, d, lc);
+            POOL(F_OX, slot) = __float_as_uint(o.x);
+            POOL(F_OY, slot) = __float_as_uint(o.y);
+            POOL(F_OZ, slot) = __float_as_uint(o.z);
+            POOL(F_DX, slot) = __float_as_uint(d.x);
+            POOL(F_DY, slot) = __float_as_uint(d.y);
+            POOL(F_DZ, slot) = __float_as_uint(d.z);
+            POOL(F_S0, slot) = rng.s0;
+            POOL(F_S1, slot) = rng.s1;
+            POOL(F_ITEM, slot) = item;
+            POOL(F_WORD, slot) = word;
+            POOL(F_DIST, slot) = __float_as_uint(closest);
+            POOL(F_T, slot) = __float_as_uint(ht);
+            POOL(F_TRI, slot) = 0u;
+            POOL(F_META, slot) = pack_meta(depth, nrec, obj, m < P.n_meshes ? m : 0u);
+            status[slot] = m < P.n_meshes ? ST_TRAV : classify(P, obj, depth);
+        } else if (kind == ST_TERM && (is_main || is_gen)) {
+            status[slot] = ST_EMPTY;  // no work item left (or a pixel outside a ragged image edge)
+        }
+    }
+#undef POOL
+    if (STATS) {
+        atomicAdd(&P.counters->rays, (unsigned long long)lc.rays);
+        atomicAdd(&P.counters->mesh_gate_pass, (unsigned long long)lc.gate);
+        atomicAdd(&P.counters->nodes_visited, (unsigned long long)lc.nodes);
+        atomicAdd(&P.counters->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&P.counters->mesh_hits, (unsigned long long)lc.mesh_hits);
+        atomicAdd(&P.counters->samples, (unsigned long long)n_samples_done);
+        if (lane == 0) {
+            for (uint32_t k = 0; k < kNumStatus; ++k) {
+                atomicAdd(&P.counters->diag[k], (unsigned long long)dg_pass[k]);
+                atomicAdd(&P.counters->diag[6 + k], (unsigned long long)dg_lanes[k]);
+            }
+            atomicAdd(&P.counters->diag[12], (unsigned long long)dg_steps);
+            atomicAdd(&P.counters->diag[13], (unsigned long long)dg_lane_steps);
+            atomicAdd(&P.counters->diag[14], (unsigned long long)dg_refills);
+            atomicAdd(&P.counters->diag[15], (unsigned long long)dg_census);
+        }
+    }
+}

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""A/B harness for kernel tuning on the GPU box: runs bench.py once per environment variant (each in
+its own process, interleaved for several rounds) and prints the trace-kernel time per variant.
+
+    python tools/ab.py --rounds 2 "RBRT_POOL=128" "RBRT_POOL=192" "RBRT_POOL=256 RBRT_Y_LOW=32"
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("variants", nargs="+", help='space-separated KEY=VALUE lists, "-" for the default build')
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--extra", default="", help="extra bench.py arguments")
+    args = ap.parse_args()
+    res = {v: [] for v in args.variants}
+    for r in range(args.rounds):
+        for v in args.variants:
+            env = dict(os.environ)
+            if v != "-":
+                for kv in v.split():
+                    k, val = kv.split("=", 1)
+                    env[k] = val
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", str(args.steps), "--warmup", "2",
+                   "--cpu-col-stride", "0"] + args.extra.split()
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            if p.returncode != 0:
+                print(f"[{v}] FAILED rc={p.returncode}: {p.stderr[-400:]}", flush=True)
+                continue
+            j = json.loads(p.stdout.strip().splitlines()[-1])
+            res[v].append((j["roofline"]["kernel_ms"], j["value"], j["roofline"]["frac"]))
+            print(f"round {r} [{v}] kernel_ms={j['roofline']['kernel_ms']} value={j['value']} frac={j['roofline']['frac']}",
+                  flush=True)
+    print("---- summary (min / median kernel_ms) ----")
+    for v, xs in res.items():
+        if xs:
+            ks = sorted(x[0] for x in xs)
+            print(f"{v:50s} min {ks[0]:.3f}  med {ks[len(ks)//2]:.3f}  value(max) {max(x[1] for x in xs):.1f}")
+
+
+if __name__ == "__main__":
+    main()
