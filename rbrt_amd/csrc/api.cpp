@@ -18,7 +18,7 @@ hipError_t launch_trace_v1(const TraceParams& P, bool stats, hipStream_t stream)
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats,
                                    hipStream_t stream);
 size_t megakernel_gseq_bytes(uint32_t n_waves);
-size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries);
+size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
                          float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
@@ -274,7 +274,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             if (v >= 1 && v <= 64) s->y_low_water = uint32_t(v);
         }
         // resident waves per CU: LDS-limited (160 KiB per CU), at most 5 per SIMD (VGPR budget)
-        int per_cu = int((160u * 1024u) / megakernel_lds_bytes(s->pool, s->stack_entries));
+        int per_cu = int((160u * 1024u) / megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes));
         if (per_cu > 20) per_cu = 20;
         if (per_cu < 1) per_cu = 1;
         if (const char* e = std::getenv("RBRT_WAVES_PER_CU")) {
@@ -555,7 +555,7 @@ int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* s, uint64_t* out, size_t n) 
     HIP_TRY(hipDeviceSynchronize());
     DevCounters c;
     HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n && i < 16; ++i) out[i] = c.diag[i];
+    for (size_t i = 0; i < n && i < 24; ++i) out[i] = c.diag[i];
     return RBRT_OK;
 }
 

@@ -79,7 +79,8 @@ struct DevCounters {  // mirrors rbrt_hip_stats_t's counters
     // megakernel diagnostics (counting variant only; rbrt_hip_scene_debug_counters):
     // [0..5] passes per status kind, [6..11] lanes used per kind, [12] traversal wave-steps,
     // [13] active lane-steps, [14] refill rounds, [15] census rounds
-    unsigned long long diag[16];
+    // [16] cycles in traversal steps, [17] cycles in shading passes, [18] total cycles (s_memtime, summed over waves)
+    unsigned long long diag[24];
 };
 
 // Kernel arguments of one trace launch (passed by value).

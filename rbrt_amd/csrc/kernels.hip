@@ -636,8 +636,9 @@ hipError_t launch_trace_v1(const TraceParams& P, bool stats, hipStream_t stream)
 
 size_t megakernel_gseq_bytes(uint32_t n_waves) { return size_t(n_waves) * kPoolMax * kSeqWords * sizeof(uint32_t); }
 
-size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries) {
-    return (size_t(kFields) * pool + 2u * pool + size_t(stack_entries) * 64u) * sizeof(uint32_t);
+size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
+    const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw;
+    return (size_t(kFields) * pool + 2u * pool + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
 }
 
 // n_waves single-wave workgroups; each loops until the global work counter (zeroed by the caller on
@@ -645,7 +646,7 @@ size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries) {
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats,
                                    hipStream_t stream) {
     if (P.n_items == 0 || n_waves == 0) return hipSuccess;
-    const size_t lds = megakernel_lds_bytes(pool, P.stack_entries);
+    const size_t lds = megakernel_lds_bytes(pool, P.stack_entries, P.n_spheres, P.n_meshes);
 #define RBRT_LAUNCH_MK(POOLN)                                                                              \
     do {                                                                                                   \
         if (stats)                                                                                         \

@@ -18,6 +18,14 @@
 // Which lane works on which path never affects the result: a path owns its RNG stream and its
 // sample slot, and resolve_kernel adds the samples of a pixel in sample order.
 
+// Explicit address spaces: pointers that arrive inside the by-value TraceParams struct are generic
+// ("flat") to the compiler, which then emits flat_load (counts on vmcnt AND lgkmcnt, never scalar).
+// AS1 = global (per-lane gathers: nodes, triangles, normals), AS4 = constant (wave-uniform tables:
+// spheres, materials, mesh descriptors -> s_load).
+#define RBRT_AS1(T, p) ((const __attribute__((address_space(1))) T*)(p))
+#define RBRT_AS4(T, p) ((const __attribute__((address_space(4))) T*)(p))
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_S0, F_S1, F_ITEM, F_META, F_DIST, F_T, F_TRI, F_WORD, kFields };
 enum : uint32_t { ST_EMPTY = 0u, ST_TRAV = 1u, ST_TERM = 2u, ST_LAMB = 3u, ST_METAL = 4u, ST_DIEL = 5u, kNumStatus = 6u,
                   ST_BUSY = 6u /* being traversed by a lane right now */ };
@@ -31,12 +39,32 @@ __device__ __forceinline__ uint32_t pack_meta(uint32_t depth, uint32_t nrec, int
     return depth | (nrec << 7) | (uint32_t(obj + 1) << 14) | (mesh << 22);
 }
 
+// Scene constants staged in LDS at kernel start (a copy of the DevSphere / DevMaterial / DevMesh
+// arrays as dwords), so that the shading passes do not chain dependent global loads.
+constexpr uint32_t kSphDw = sizeof(DevSphere) / 4, kMatDw = sizeof(DevMaterial) / 4, kMeshDw = sizeof(DevMesh) / 4;
+static_assert(sizeof(DevSphere) == 16 && sizeof(DevMaterial) == 20 && sizeof(DevMesh) == 80, "LDS scene table layout");
+enum { MD_NODES = 0, MD_TRIS = 2, MD_NORMALS = 4, MD_BBOX_LO = 6, MD_BBOX_HI = 9, MD_CENTER = 12, MD_RADIUS = 15 };
+static_assert(offsetof(DevMesh, tris) == 8 && offsetof(DevMesh, normals) == 16 && offsetof(DevMesh, bbox_lo) == 24 &&
+                  offsetof(DevMesh, bbox_hi) == 36 && offsetof(DevMesh, center) == 48 && offsetof(DevMesh, radius) == 60,
+              "LDS scene table layout");
+struct SceneLds {
+    const float* sph;      // [n_spheres][4]: centre xyz, radius
+    const uint32_t* mat;   // [n_spheres + n_meshes][5]: albedo xyz, param, kind
+    const uint32_t* mesh;  // [n_meshes][20]: DevMesh as dwords
+};
+template <class T>
+__device__ __forceinline__ const T* lds_ptr(const uint32_t* p) {  // a 64-bit device pointer stored as two dwords
+    return reinterpret_cast<const T*>(uintptr_t(p[0]) | (uintptr_t(p[1]) << 32));
+}
+
 // First mesh with index >= m0 whose bbox gate (aabbox.rs:28-58) the ray passes, or n_meshes.
 template <bool STATS>
-__device__ __forceinline__ uint32_t next_gated_mesh(const TraceParams& P, uint32_t m0, V3 o, V3 d, LocalCounters& lc) {
+__device__ __forceinline__ uint32_t next_gated_mesh(const SceneLds& sc, uint32_t n_meshes, uint32_t m0, V3 o, V3 d,
+                                                    LocalCounters& lc) {
     uint32_t m = m0;
-    for (; m < P.n_meshes; ++m) {
-        if (bbox_gate(P.meshes[m].bbox_lo, P.meshes[m].bbox_hi, o, d)) {
+    for (; m < n_meshes; ++m) {
+        const float* md = reinterpret_cast<const float*>(sc.mesh + m * kMeshDw);
+        if (bbox_gate(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d)) {
             if (STATS) ++lc.gate;
             break;
         }
@@ -45,9 +73,9 @@ __device__ __forceinline__ uint32_t next_gated_mesh(const TraceParams& P, uint32
 }
 
 // What has to happen next to a path whose closest hit is known.
-__device__ __forceinline__ uint32_t classify(const TraceParams& P, int32_t obj, uint32_t depth) {
+__device__ __forceinline__ uint32_t classify(const SceneLds& sc, int32_t obj, uint32_t depth) {
     if (obj < 0 || depth == 0) return ST_TERM;  // lib.rs:54,68
-    return ST_LAMB + uint32_t(P.materials[obj].kind);
+    return ST_LAMB + sc.mat[uint32_t(obj) * kMatDw + 4];
 }
 
 // Culling-only slab test (never feeds the image): box grown by pad, planes through one FMA each.
@@ -78,10 +106,33 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
 #define POOL(f, s) pool[(f) * POOLN + (s)]
 
     for (uint32_t s = lane; s < uint32_t(POOLN); s += 64) status[s] = ST_EMPTY;
+    // scene tables behind the stacks
+    const uint32_t n_obj = P.n_spheres + P.n_meshes;
+    uint32_t* const sc_base = list + POOLN + P.stack_entries * 64u;
+    {
+        const uint32_t* gs = reinterpret_cast<const uint32_t*>(P.spheres);
+        const uint32_t* gm = reinterpret_cast<const uint32_t*>(P.materials);
+        const uint32_t* gh = reinterpret_cast<const uint32_t*>(P.meshes);
+        uint32_t* dst = sc_base;
+        for (uint32_t i = lane; i < P.n_spheres * kSphDw; i += 64) dst[i] = gs[i];
+        dst += P.n_spheres * kSphDw;
+        for (uint32_t i = lane; i < n_obj * kMatDw; i += 64) dst[i] = gm[i];
+        dst += n_obj * kMatDw;
+        for (uint32_t i = lane; i < P.n_meshes * kMeshDw; i += 64) dst[i] = gh[i];
+    }
+    const SceneLds sc = {reinterpret_cast<const float*>(sc_base), sc_base + P.n_spheres * kSphDw,
+                         sc_base + P.n_spheres * kSphDw + n_obj * kMatDw};
+    // work items are reserved from the global counter in chunks, the next chunk asynchronously
+    constexpr unsigned long long kChunk = 256;
+    unsigned long long res_next = 0, res_end = 0;  // wave-uniform: the chunk being handed out
+    unsigned long long pend_base = 0;              // lane 0: base of the prefetched chunk
+    bool pending = false;                          // wave-uniform: a prefetch is in flight
     LocalCounters lc = {0, 0, 0, 0, 0};
     uint32_t n_samples_done = 0;
     uint32_t dg_pass[kNumStatus] = {0, 0, 0, 0, 0, 0}, dg_lanes[kNumStatus] = {0, 0, 0, 0, 0, 0};
     uint32_t dg_steps = 0, dg_lane_steps = 0, dg_refills = 0, dg_census = 0;
+    unsigned long long dg_t_trav = 0, dg_t_shade = 0, dg_t0 = 0, dg_tk = 0;
+    if (STATS) dg_t0 = __builtin_amdgcn_s_memtime();
     bool more_work = true;  // wave-uniform: the global work counter has not run out yet
     const size_t npix = size_t(P.n_local_tiles) * 64u;
     const float eps = P.min_dist;
@@ -120,10 +171,10 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                         }
                     }
                 }
-                const uint32_t m2 = next_gated_mesh<STATS>(P, t_mesh + 1u, t_o, t_d, lc);
+                const uint32_t m2 = next_gated_mesh<STATS>(sc, P.n_meshes, t_mesh + 1u, t_o, t_d, lc);
                 const uint32_t depth = meta & 127u;
                 POOL(F_META, slot) = pack_meta(depth, (meta >> 7) & 127u, obj, m2 < P.n_meshes ? m2 : 0u);
-                status[slot] = m2 < P.n_meshes ? ST_TRAV : classify(P, obj, depth);
+                status[slot] = m2 < P.n_meshes ? ST_TRAV : classify(sc, obj, depth);
                 t_has_result = false;
             }
         }
@@ -163,12 +214,12 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                     t_d = mk(__uint_as_float(POOL(F_DX, slot)), __uint_as_float(POOL(F_DY, slot)),
                              __uint_as_float(POOL(F_DZ, slot)));
                     t_mesh = (POOL(F_META, slot) >> 22) & 255u;
-                    const DevMesh& M = P.meshes[t_mesh];
-                    t_nodes = M.nodes;
-                    t_tris = M.tris;
+                    const uint32_t* md = sc.mesh + t_mesh * kMeshDw;
+                    t_nodes = lds_ptr<BvhNode>(md + MD_NODES);
+                    t_tris = lds_ptr<BvhTri>(md + MD_TRIS);
                     // culling-only quantities: fast reciprocal / sqrt are fine here
-                    const V3 oc = t_o - mk(M.center);
-                    const float S = __builtin_amdgcn_sqrtf(dot(oc, oc)) + M.radius;
+                    const V3 oc = t_o - mk(reinterpret_cast<const float*>(md) + MD_CENTER);
+                    const float S = __builtin_amdgcn_sqrtf(dot(oc, oc)) + __uint_as_float(md[MD_RADIUS]);
                     const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t_o.x), __builtin_fabsf(t_o.y)),
                                                        __builtin_fabsf(t_o.z));
                     t_pad_base = (64.0f / 16777216.0f) * (S + omax);
@@ -205,6 +256,7 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                 ++dg_pass[ST_TRAV];
                 if (best == 0) ++dg_pass[ST_EMPTY];  // diag[0]: traversal entered because nothing else to do
                 dg_lanes[ST_EMPTY] += n_active;       // diag[6]: sum of busy lanes at entry
+                dg_tk = __builtin_amdgcn_s_memtime();
             }
             // leave as soon as enough lanes are idle to make a refill / shading pass worthwhile; when no
             // other work exists, as soon as one lane has a result (it creates shading work)
@@ -218,8 +270,8 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                 if (t_active) {
                     bool pop = true;
                     if (t_cur >= 0) {
-                        const float4* np = reinterpret_cast<const float4*>(t_nodes + t_cur);
-                        const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                        const auto* np = RBRT_AS1(f32x4, t_nodes + t_cur);
+                        const f32x4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                         if (STATS) ++lc.nodes;
                         const float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
                         const float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
@@ -243,8 +295,8 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                         const uint32_t leaf = uint32_t(~t_cur);
                         const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
                         for (uint32_t i = 0; i < count; ++i) {
-                            const float4* tp = reinterpret_cast<const float4*>(t_tris + first + i);
-                            const float4 a = tp[0], b = tp[1], c = tp[2];
+                            const auto* tp = RBRT_AS1(f32x4, t_tris + first + i);
+                            const f32x4 a = tp[0], b = tp[1], c = tp[2];
                             if (STATS) ++lc.tris;
                             float t;
                             const bool hit = tri_test(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t_o, t_d,
@@ -268,11 +320,15 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                     }
                 }
             } while (uint32_t(__popcll(__ballot(t_active))) >= keep);
+            if (STATS) dg_t_trav += __builtin_amdgcn_s_memtime() - dg_tk;
             continue;
         }
 
         // ============================ shading pass of one kind ===============================
-        if (STATS) ++dg_pass[kind];
+        if (STATS) {
+            ++dg_pass[kind];
+            dg_tk = __builtin_amdgcn_s_memtime();
+        }
         uint32_t c0 = 0, c1 = 0;
 #pragma unroll
         for (uint32_t g = 0; g < uint32_t(POOLN); g += 64) {
@@ -320,7 +376,7 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                     for (uint32_t k = nrec; k-- > 0;) {
                         const uint32_t w = (k >> 2) == (nrec >> 2) ? word : gseq[size_t(slot) * kSeqWords + (k >> 2)];
                         const uint32_t ob = (w >> (8u * (k & 3u))) & 0xFFu;
-                        color = mk(P.materials[ob].albedo) * color;
+                        color = mk(reinterpret_cast<const float*>(sc.mat + ob * kMatDw)) * color;
                     }
                 }
                 item = POOL(F_ITEM, slot);
@@ -338,14 +394,18 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
             const uint64_t want = __ballot(need_new && more_work);
             if (want) {
                 const uint32_t n_want = uint32_t(__popcll(want));
-                const uint32_t leader = uint32_t(__builtin_ctzll(want));
-                unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(P.work_counter, (unsigned long long)n_want);
-                base = (unsigned long long)__shfl(uint32_t(base), int(leader)) |
-                       ((unsigned long long)__shfl(uint32_t(base >> 32), int(leader)) << 32);
+                const unsigned long long avail = res_end - res_next;
+                unsigned long long new_base = 0;
+                if (avail < n_want) {  // take the prefetched chunk (or fetch one now, at the very start)
+                    if (!pending && lane == 0) pend_base = atomicAdd(P.work_counter, kChunk);
+                    new_base = (unsigned long long)__shfl(uint32_t(pend_base), 0) |
+                               ((unsigned long long)__shfl(uint32_t(pend_base >> 32), 0) << 32);
+                    pending = false;
+                }
                 bool ran_out = false;
                 if (need_new) {
-                    const unsigned long long it = base + lane_rank(want);
+                    const uint32_t rk = lane_rank(want);
+                    const unsigned long long it = rk < avail ? res_next + rk : new_base + (rk - avail);
                     if (it < P.n_items) {
                         item = uint32_t(it);
                         const uint32_t pp = item & 63u;
@@ -376,7 +436,18 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                         ran_out = true;
                     }
                 }
+                if (avail < n_want) {
+                    res_next = new_base + (n_want - avail);
+                    res_end = new_base + kChunk;
+                } else {
+                    res_next += n_want;
+                }
                 if (__any(ran_out)) more_work = false;
+                // reserve the next chunk now; its result is not needed before a later TERM pass
+                if (more_work && !pending && res_end - res_next < 64u) {
+                    if (lane == 0) pend_base = atomicAdd(P.work_counter, kChunk);
+                    pending = true;
+                }
             }
         } else if (is_main) {
             // ---- RayScattering::scatter for one material kind (wave-uniform branch) ----
@@ -396,12 +467,19 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
             const V3 p = o + ht * d;  // same expression as inside the intersection routines
             V3 n;
             if (uint32_t(obj) < P.n_spheres) {
-                n = p - mk(P.spheres[obj].center);  // sphere.rs:56, unnormalised
+                n = p - mk(sc.sph + uint32_t(obj) * kSphDw);  // sphere.rs:56, unnormalised
             } else {
-                const Normal4 nn = P.meshes[uint32_t(obj) - P.n_spheres].normals[POOL(F_TRI, slot)];
+                const Normal4 nn =
+                    lds_ptr<Normal4>(sc.mesh + (uint32_t(obj) - P.n_spheres) * kMeshDw + MD_NORMALS)[POOL(F_TRI, slot)];
                 n = mk(nn.x, nn.y, nn.z);  // mesh.rs:253-257
             }
-            const DevMaterial m = P.materials[obj];
+            DevMaterial m;
+            {
+                const uint32_t* mp = sc.mat + uint32_t(obj) * kMatDw;
+                m.albedo[0] = __uint_as_float(mp[0]), m.albedo[1] = __uint_as_float(mp[1]);
+                m.albedo[2] = __uint_as_float(mp[2]), m.param = __uint_as_float(mp[3]);
+                m.kind = int32_t(mp[4]);
+            }
             V3 nd;
             bool ok;
             if (kind == ST_LAMB) {  // lambertian.rs:11-24
@@ -443,9 +521,9 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
             float closest = 3.40282347e+38f, ht = 0.0f;
             int32_t obj = -1;
             for (uint32_t i = 0; i < P.n_spheres; ++i) {
-                const DevSphere sp = P.spheres[i];
+                const float* sp = sc.sph + i * kSphDw;
                 float t, dist;
-                if (sphere_hit(mk(sp.center), sp.radius, o, d, P.min_dist, P.max_dist, t, dist, P.counters)) {
+                if (sphere_hit(mk(sp), sp[3], o, d, P.min_dist, P.max_dist, t, dist, P.counters)) {
                     if (dist < closest) {
                         closest = dist;
                         ht = t;
@@ -453,7 +531,7 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                     }
                 }
             }
-            const uint32_t m = next_gated_mesh<STATS>(P, 0, o, d, lc);
+            const uint32_t m = next_gated_mesh<STATS>(sc, P.n_meshes, 0, o, d, lc);
             POOL(F_OX, slot) = __float_as_uint(o.x);
             POOL(F_OY, slot) = __float_as_uint(o.y);
             POOL(F_OZ, slot) = __float_as_uint(o.z);
@@ -468,10 +546,11 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
             POOL(F_T, slot) = __float_as_uint(ht);
             POOL(F_TRI, slot) = 0u;
             POOL(F_META, slot) = pack_meta(depth, nrec, obj, m < P.n_meshes ? m : 0u);
-            status[slot] = m < P.n_meshes ? ST_TRAV : classify(P, obj, depth);
+            status[slot] = m < P.n_meshes ? ST_TRAV : classify(sc, obj, depth);
         } else if (kind == ST_TERM && (is_main || is_gen)) {
             status[slot] = ST_EMPTY;  // no work item left (or a pixel outside a ragged image edge)
         }
+        if (STATS) dg_t_shade += __builtin_amdgcn_s_memtime() - dg_tk;
     }
 #undef POOL
     if (STATS) {
@@ -490,6 +569,9 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
             atomicAdd(&P.counters->diag[13], (unsigned long long)dg_lane_steps);
             atomicAdd(&P.counters->diag[14], (unsigned long long)dg_refills);
             atomicAdd(&P.counters->diag[15], (unsigned long long)dg_census);
+            atomicAdd(&P.counters->diag[16], dg_t_trav);
+            atomicAdd(&P.counters->diag[17], dg_t_shade);
+            atomicAdd(&P.counters->diag[18], (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
         }
     }
 }
