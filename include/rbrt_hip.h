@@ -212,7 +212,7 @@ int rbrt_hip_trace_rays(rbrt_hip_scene_t* scene, const float* rays, size_t n, fl
 int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* scene, uint64_t* out, size_t n);
 
 /* Diagnostic: run the host-side BVH builder alone (needs no device). *nodes_out / *tris_out are
- * malloc'ed copies of the 64-B node and 48-B triangle records (layout: rbrt_amd/csrc/device_types.h);
+ * malloc'ed copies of the 128-B 4-wide node and 48-B triangle records (layout: rbrt_amd/csrc/device_types.h);
  * release them with rbrt_hip_free_host. */
 int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
                             size_t* n_tris, uint32_t* max_depth, float* max_e12);

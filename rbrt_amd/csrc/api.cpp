@@ -14,10 +14,10 @@
 #include "device_types.h"
 
 namespace rbrt {
-hipError_t launch_trace_v1(const TraceParams& P, bool stats, hipStream_t stream);
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats,
                                    hipStream_t stream);
 size_t megakernel_gseq_bytes(uint32_t n_waves);
+size_t megakernel_gstack_bytes(uint32_t n_waves);
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
@@ -79,11 +79,13 @@ struct rbrt_hip_scene {
     size_t acc_bytes = 0;
     unsigned long long* d_work_counter = nullptr;
     uint32_t* d_gseq = nullptr;
+    uint32_t* d_gstack = nullptr;
+    uint32_t stack_need = 1;  // deepest BVH: 3 per level + 1
     uint32_t n_waves = 0;  // persistent megakernel grid: as many single-wave workgroups as fit the LDS
     uint32_t pool = 192;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
-    uint32_t stack_entries = 2;   // deepest BVH of the scene + 2
+    uint32_t stack_entries = kLdsStack;  // per-lane stack entries kept in LDS (RBRT_LDS_STACK)
     uint32_t y_low_water = 48;    // RBRT_Y_LOW
-    bool use_v1 = false;   // RBRT_TRACE_KERNEL=v1: the one-thread-per-path kernel (kept for A/B timing)
+    uint32_t leaf_round = 24;     // RBRT_LEAF_ROUND
     // stats / timing
     rbrt_hip_stats_t stats{};
     bool stats_pending = false;
@@ -228,7 +230,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         std::vector<Normal4> normals(m.n_total);
         for (uint32_t k = 0; k < m.n_total; ++k) normals[k] = Normal4{m.nx[k], m.ny[k], m.nz[k], 0.0f};
         DevMesh& dm = meshes[i];
-        BvhNode* d_nodes = nullptr;
+        BvhNode4* d_nodes = nullptr;
         BvhTri* d_tris = nullptr;
         Normal4* d_normals = nullptr;
         if (int rc = upload(s, bvh.nodes, &d_nodes)) return bail(rc);
@@ -249,7 +251,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         dm.max_e12 = bvh.max_e12;
         dm.n_nodes = uint32_t(bvh.nodes.size());
         dm.n_tris = uint32_t(bvh.tris.size());
-        s->stack_entries = std::max(s->stack_entries, std::min<uint32_t>(bvh.max_depth + 2u, uint32_t(kStackEntries)));
+        s->stack_need = std::max(s->stack_need, bvh.stack_need);
         s->total_nodes += bvh.nodes.size();
         s->total_tris += bvh.tris.size();
     }
@@ -269,6 +271,15 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             int v = std::atoi(e);
             if (v == 128 || v == 192 || v == 256) s->pool = uint32_t(v);
         }
+        if (const char* e = std::getenv("RBRT_LDS_STACK")) {
+            int v = std::atoi(e);
+            if (v >= 1 && v <= kStackMax) s->stack_entries = uint32_t(v);
+        }
+        if (s->stack_entries > s->stack_need) s->stack_entries = s->stack_need;
+        if (const char* e = std::getenv("RBRT_LEAF_ROUND")) {
+            int v = std::atoi(e);
+            if (v >= 1 && v <= 64) s->leaf_round = uint32_t(v);
+        }
         if (const char* e = std::getenv("RBRT_Y_LOW")) {
             int v = std::atoi(e);
             if (v >= 1 && v <= 64) s->y_low_water = uint32_t(v);
@@ -282,10 +293,15 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             if (v > 0 && v <= 32) per_cu = v;
         }
         s->n_waves = uint32_t(cus * per_cu);
-        const char* k = std::getenv("RBRT_TRACE_KERNEL");
-        s->use_v1 = k && std::strcmp(k, "v1") == 0;
         std::vector<uint32_t> zeros(megakernel_gseq_bytes(s->n_waves) / sizeof(uint32_t), 0u);
         if (int rc = upload(s, zeros, &s->d_gseq)) return bail(rc);
+        {
+            void* gp = nullptr;
+            if (hipMalloc(&gp, megakernel_gstack_bytes(s->n_waves)) != hipSuccess)
+                return bail(fail(RBRT_ERR_OOM, "hipMalloc failed for the stack overflow scratch"));
+            s->allocs.push_back(gp);
+            s->d_gstack = static_cast<uint32_t*>(gp);
+        }
         std::vector<unsigned long long> zc(8, 0ull);
         if (int rc = upload(s, zc, &s->d_work_counter)) return bail(rc);
     }
@@ -396,7 +412,9 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     P.work_counter = s->d_work_counter;
     P.gseq = s->d_gseq;
     P.stack_entries = s->stack_entries;
+    P.gstack = s->d_gstack;
     P.y_low_water = s->y_low_water;
+    P.leaf_round = s->leaf_round;
 
     ResolveParams R;
     std::memset(&R, 0, sizeof(R));
@@ -424,13 +442,9 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         P.batch = nb;
         P.n_items = uint64_t(npix) * nb;
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));
-        if (s->use_v1) {
-            HIP_TRY(launch_trace_v1(P, stats, stream));
-        } else {
-            HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(unsigned long long), stream));
-            if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));  // after the memset node
-            HIP_TRY(launch_trace_megakernel(P, s->n_waves, s->pool, stats, stream));
-        }
+        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(unsigned long long), stream));
+        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));  // after the memset node
+        HIP_TRY(launch_trace_megakernel(P, s->n_waves, s->pool, stats, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], stream));
         R.batch = nb;
         R.first_batch = b == 0;
@@ -457,7 +471,7 @@ int rbrt_hip_scene_stats(rbrt_hip_scene_t* s, rbrt_hip_stats_t* out) {
     s->stats.mesh_hits = c.mesh_hits;
     s->stats.samples = c.samples;
     s->stats.nan_discriminants = c.nan_discriminants;
-    s->stats.node_bytes = sizeof(BvhNode);
+    s->stats.node_bytes = sizeof(BvhNode4);
     s->stats.tri_bytes = sizeof(BvhTri);
     *out = s->stats;
     return RBRT_OK;
@@ -567,10 +581,10 @@ int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n
     BvhBuildResult r = build_bvh(*mesh);
     *n_nodes = r.nodes.size();
     *n_tris = r.tris.size();
-    *nodes_out = std::malloc(std::max<size_t>(1, r.nodes.size() * sizeof(BvhNode)));
+    *nodes_out = std::malloc(std::max<size_t>(1, r.nodes.size() * sizeof(BvhNode4)));
     *tris_out = std::malloc(std::max<size_t>(1, r.tris.size() * sizeof(BvhTri)));
     if (!*nodes_out || !*tris_out) return fail(RBRT_ERR_OOM, "bvh_build_host: malloc failed");
-    std::memcpy(*nodes_out, r.nodes.data(), r.nodes.size() * sizeof(BvhNode));
+    std::memcpy(*nodes_out, r.nodes.data(), r.nodes.size() * sizeof(BvhNode4));
     std::memcpy(*tris_out, r.tris.data(), r.tris.size() * sizeof(BvhTri));
     if (max_depth) *max_depth = r.max_depth;
     if (max_e12) *max_e12 = r.max_e12;

@@ -1,8 +1,10 @@
-// bvh.cpp — binned-SAH BVH2 builder (host). See bvh.h for what the structure must guarantee.
+// bvh.cpp — binned-SAH builder (host): a binary tree first, then collapsed into 4-wide nodes.
+// See bvh.h for what the structure must guarantee.
 #include "bvh.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -10,11 +12,27 @@ namespace rbrt {
 namespace {
 
 constexpr int kBins = 16;
-constexpr float kCostTraverse = 1.0f;  // one node fetch + two slab tests
-constexpr float kCostTri = 1.0f;       // one 48-B fetch + Moller-Trumbore
-// Inner nodes live at depths 0..kMaxInnerDepth; a root-to-leaf walk defers at most one child per
-// inner node, so the traversal stack never holds more than kMaxInnerDepth + 1 <= kStackEntries.
-constexpr int kMaxInnerDepth = kStackEntries - 2;
+// SAH constants. On the GPU a node visit costs a dependent ~1 us fetch, a triangle test ~60 VALU
+// instructions, so leaves are allowed to fill up (<= kLeafMax) before another level is added.
+float cost_traverse() {
+    static const float v = [] {
+        const char* e = std::getenv("RBRT_BVH_CT");
+        float x = e ? float(std::atof(e)) : 2.0f;
+        return x > 0.0f ? x : 2.0f;
+    }();
+    return v;
+}
+constexpr float kCostTri = 1.0f;
+// Binary inner nodes live at depths 0..kMaxInnerDepth; collapsing never deepens a path, so the
+// 4-wide tree is at most that deep too.
+constexpr int kMaxInnerDepth = kMaxBvhDepth;
+
+// Binary node of the intermediate tree (both child boxes in the parent).
+struct Node2 {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t child0, child1;
+    float max_e12_0, max_e12_1;
+};
 
 struct Box {
     float lo[3], hi[3];
@@ -59,6 +77,7 @@ struct ChildInfo {
 struct Builder {
     const rbrt_mesh_t& m;
     std::vector<Prim> prims;
+    std::vector<Node2> nodes2;
     BvhBuildResult out;
 
     explicit Builder(const rbrt_mesh_t& mesh) : m(mesh) {}
@@ -87,7 +106,7 @@ struct Builder {
                   [](const Prim& x, const Prim& y) { return x.idx < y.idx; });
         for (size_t i = b; i < e; ++i) out.tris.push_back(make_tri(prims[i].idx));
         ++out.n_leaves;
-        return ChildInfo{~int32_t((first << 3) | (count - 1)), box, max_e12};
+        return ChildInfo{~int32_t((first << 2) | (count - 1)), box, max_e12};
     }
 
     ChildInfo build_range(size_t b, size_t e, int depth) {
@@ -147,7 +166,7 @@ struct Builder {
         const float leaf_cost = kCostTri * float(count);
         float split_cost = std::numeric_limits<float>::infinity();
         if (best_axis >= 0 && parent_area > 0.0f)
-            split_cost = kCostTraverse + kCostTri * best_cost / parent_area;
+            split_cost = cost_traverse() + kCostTri * best_cost / parent_area;
         if (count <= size_t(kLeafMax) && leaf_cost <= split_cost) return make_leaf(b, e, box, max_e12);
 
         size_t mid = b;
@@ -172,9 +191,8 @@ struct Builder {
                                  return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
                              });
         }
-        const uint32_t node = uint32_t(out.nodes.size());
-        out.nodes.emplace_back();
-        out.max_depth = std::max(out.max_depth, uint32_t(depth));
+        const uint32_t node = uint32_t(nodes2.size());
+        nodes2.emplace_back();
         ChildInfo l = build_range(b, mid, depth + 1);
         ChildInfo r = build_range(mid, e, depth + 1);
         set_node(node, l, r);
@@ -182,7 +200,7 @@ struct Builder {
     }
 
     void set_node(uint32_t node, const ChildInfo& l, const ChildInfo& r) {
-        BvhNode& n = out.nodes[node];
+        Node2& n = nodes2[node];
         for (int k = 0; k < 3; ++k) {
             n.lo0[k] = l.box.lo[k], n.hi0[k] = l.box.hi[k];
             n.lo1[k] = r.box.lo[k], n.hi1[k] = r.box.hi[k];
@@ -201,7 +219,7 @@ struct Builder {
         out.tris.push_back(t);
         Box b;
         for (int k = 0; k < 3; ++k) b.lo[k] = b.hi[k] = 0.0f;
-        return ChildInfo{~int32_t((first << 3) | 0), b, 0.0f};
+        return ChildInfo{~int32_t((first << 2) | 0), b, 0.0f};
     }
 
     void run() {
@@ -235,16 +253,16 @@ struct Builder {
             prims.push_back(p);
         }
         out.n_indexed = uint32_t(prims.size());
-        out.nodes.reserve(prims.size() / 2 + 2);
+        nodes2.reserve(prims.size() / 2 + 2);
         out.tris.reserve(prims.size() + 2);
         if (prims.empty()) {
-            out.nodes.emplace_back();
+            nodes2.emplace_back();
             ChildInfo d0 = make_dummy();
             set_node(0, d0, d0);
         } else {
             ChildInfo root = build_range(0, prims.size(), 0);
             if (root.ref < 0) {  // whole mesh fits one leaf
-                out.nodes.emplace_back();
+                nodes2.emplace_back();
                 ChildInfo d = make_dummy();
                 set_node(0, root, d);
             }
@@ -252,6 +270,60 @@ struct Builder {
         }
         prims.clear();
         prims.shrink_to_fit();
+        out.nodes.reserve(nodes2.size() / 2 + 2);
+        collapse(0, 0);
+        out.stack_need = 3u * (out.max_depth + 1u) + 1u;
+        nodes2.clear();
+        nodes2.shrink_to_fit();
+    }
+
+    // Binary -> 4-wide: a node adopts its grandchildren, always opening the inner child with the
+    // largest surface first, until it has four children or only leaves are left.
+    uint32_t collapse(int32_t n2, uint32_t depth) {
+        struct Cand {
+            int32_t ref;
+            Box box;
+            float e12;
+        };
+        auto children_of = [&](int32_t idx, Cand& a, Cand& b) {
+            const Node2& n = nodes2[size_t(idx)];
+            a.ref = n.child0, b.ref = n.child1;
+            a.e12 = n.max_e12_0, b.e12 = n.max_e12_1;
+            for (int k = 0; k < 3; ++k) {
+                a.box.lo[k] = n.lo0[k], a.box.hi[k] = n.hi0[k];
+                b.box.lo[k] = n.lo1[k], b.box.hi[k] = n.hi1[k];
+            }
+        };
+        Cand c[4];
+        int n = 2;
+        children_of(n2, c[0], c[1]);
+        while (n < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int i = 0; i < n; ++i)
+                if (c[i].ref >= 0 && c[i].box.half_area() > best) best = c[i].box.half_area(), pick = i;
+            if (pick < 0) break;
+            Cand a, b;
+            children_of(c[pick].ref, a, b);
+            c[pick] = a;
+            c[n++] = b;
+        }
+        const uint32_t me = uint32_t(out.nodes.size());
+        out.nodes.emplace_back();
+        out.max_depth = std::max(out.max_depth, depth);
+        int32_t refs[4];
+        for (int i = 0; i < n; ++i) refs[i] = c[i].ref >= 0 ? int32_t(collapse(c[i].ref, depth + 1)) : c[i].ref;
+        BvhNode4& o = out.nodes[me];
+        const float qnan = std::numeric_limits<float>::quiet_NaN();
+        for (int i = 0; i < 4; ++i) {
+            const bool used = i < n;
+            o.lo_x[i] = used ? c[i].box.lo[0] : qnan, o.lo_y[i] = used ? c[i].box.lo[1] : qnan;
+            o.lo_z[i] = used ? c[i].box.lo[2] : qnan, o.hi_x[i] = used ? c[i].box.hi[0] : qnan;
+            o.hi_y[i] = used ? c[i].box.hi[1] : qnan, o.hi_z[i] = used ? c[i].box.hi[2] : qnan;
+            o.child[i] = used ? refs[i] : kNoChild;
+            o.max_e12[i] = used ? c[i].e12 : 0.0f;
+        }
+        return me;
     }
 };
 

@@ -1,4 +1,4 @@
-// bvh.h — host-side BVH2 builder for one triangle mesh.
+// bvh.h — host-side BVH builder (binned-SAH binary tree, collapsed to 4-wide nodes) for one triangle mesh.
 //
 // The reference has NO acceleration structure beyond one box per mesh (mesh.rs:232-243 tests every
 // triangle for every ray that passes aabbox.rs:28-58). This BVH is purely a culling structure: the
@@ -18,11 +18,12 @@
 namespace rbrt {
 
 struct BvhBuildResult {
-    std::vector<BvhNode> nodes;  // nodes[0] = root
-    std::vector<BvhTri> tris;    // leaf order
+    std::vector<BvhNode4> nodes;  // nodes[0] = root
+    std::vector<BvhTri> tris;     // leaf order
     float max_e12 = 0.0f;
-    uint32_t max_depth = 0;
-    uint32_t n_indexed = 0;  // triangles in the BVH
+    uint32_t max_depth = 0;   // depth of the deepest 4-wide node (root = 0)
+    uint32_t stack_need = 1;  // traversal stack entries that can ever be live: 3 per level + 1
+    uint32_t n_indexed = 0;   // triangles in the BVH
     uint32_t n_leaves = 0;
 };
 

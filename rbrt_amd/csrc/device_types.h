@@ -6,30 +6,30 @@
 
 namespace rbrt {
 
-// Compile-time limits of the megakernel.
-constexpr int kBlock = 256;        // threads per workgroup = 4 wave64
-constexpr int kStackEntries = 32;  // per-lane traversal stack (LDS); the builder caps the depth to fit
-constexpr int kMaxDepthBuild = 32; // max BVH2 depth (root = 0) => at most 31 deferred children
-constexpr int kMaxPathDepth = 64;  // opts.max_depth limit (reference: 50, lib.rs:99)
-constexpr int kMaxObjects = 255;   // spheres + meshes (object id is stored in one byte per bounce)
-constexpr int kLeafMax = 8;        // triangles per leaf (3-bit count field)
-constexpr int kPoolMax = 256;      // largest path pool per wave the persistent megakernel is built for
+// Compile-time limits.
+constexpr int kBlock = 256;          // threads per workgroup of the simple kernels (resolve, unpack, trace_rays)
+constexpr int kMaxBvhDepth = 20;     // deepest 4-wide node (root = 0) the builder may create
+constexpr int kStackMax = 3 * (kMaxBvhDepth + 1) + 1;  // a visit defers at most 3 children per level
+constexpr int kMaxPathDepth = 64;    // opts.max_depth limit (reference: 50, lib.rs:99)
+constexpr int kMaxObjects = 255;     // spheres + meshes (object id is stored in one byte per bounce)
+constexpr int kLeafMax = 4;          // triangles per leaf (2-bit count field)
+constexpr int kPoolMax = 256;        // largest path pool per wave the persistent megakernel is built for
+constexpr int kLdsStack = 12;        // per-lane traversal stack entries kept in LDS by the megakernel; deeper
+                                     // entries spill (exactly) to a per-wave global scratch
 
-// One BVH2 node = 64 B = half a 128-B cache line, fetched as 4 x dwordx4 by ONE lane.
-// Both child boxes live in the parent so a visit decides both children with one fetch.
-// child >= 0 : index of an inner node; child < 0 : leaf, ~child = (first_tri << 3) | (count - 1).
-// An absent child has an inverted box (lo = +inf, hi = -inf) and can never be entered.
-struct alignas(64) BvhNode {
-    float lo0[3];
-    float hi0[3];
-    float lo1[3];
-    float hi1[3];
-    int32_t child0;
-    int32_t child1;
-    float max_e12_0;  // max over subtree 0 of |e1|*|e2| (error-bound term of the culling pad)
-    float max_e12_1;
+// One 4-wide BVH node = 128 B = one cache line, fetched as 8 x dwordx4 by ONE lane: the four child boxes
+// as SoA (so the four slab tests are the same code on four registers), four child links and, per
+// child, max |e1|*|e2| of its subtree (the error-bound term of the culling pad).
+// child >= 0 : index of an inner node; child < 0 : leaf, ~child = (first_tri << 2) | (count - 1);
+// kNoChild marks an unused slot, whose box is NaN so that every slab compare fails.
+constexpr int32_t kNoChild = INT32_MIN;
+struct alignas(128) BvhNode4 {
+    float lo_x[4], lo_y[4], lo_z[4];
+    float hi_x[4], hi_y[4], hi_z[4];
+    int32_t child[4];
+    float max_e12[4];
 };
-static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
+static_assert(sizeof(BvhNode4) == 128, "node must be 128 B");
 
 // One triangle record = 48 B (3 x dwordx4), stored in leaf order. The 9 fp32 values are exactly
 // the 9 SoA streams the reference kernel reads (triangle.rs:177-187); `index` is the triangle's
@@ -61,7 +61,7 @@ struct DevMaterial {
 };
 
 struct DevMesh {
-    const BvhNode* nodes;
+    const BvhNode4* nodes;
     const BvhTri* tris;
     const Normal4* normals;  // [reference index] -> (nx, ny, nz, 0)
     float bbox_lo[3];
@@ -105,8 +105,10 @@ struct TraceParams {
     // persistent megakernel only
     unsigned long long* work_counter;  // next unclaimed work item (zeroed before every launch)
     uint32_t* gseq;                    // [n_waves][kPoolMax][kMaxPathDepth/4] scatter records beyond the 4 kept in LDS
-    uint32_t stack_entries;            // per-lane traversal stack depth = deepest BVH + 2
+    uint32_t stack_entries;            // per-lane traversal stack entries kept in LDS (<= stack_need)
+    uint32_t* gstack;                  // [n_waves][kStackMax][64] overflow of the LDS stacks
     uint32_t y_low_water;              // refill a traversal pass when fewer lanes than this are busy
+    uint32_t leaf_round;               // test deferred leaves once this many lanes hold one
 };
 
 struct ResolveParams {

@@ -162,97 +162,152 @@ __device__ __forceinline__ bool tri_test(V3 v0, V3 ea, V3 eb, V3 o, V3 d, float 
     return !(c1 || c2 || c3) && c4;
 }
 
-// Slab test of a box grown by `pad` on every side. Not part of the reference's arithmetic: it only
-// decides which triangles get tested, so FMA-free plain ops are used for simplicity, not parity.
-__device__ __forceinline__ bool slab(const float* lo, const float* hi, float pad, V3 o, V3 inv,
-                                     float eps, float best_t, float& tn_out) {
-    float t0x = ((lo[0] - pad) - o.x) * inv.x, t1x = ((hi[0] + pad) - o.x) * inv.x;
-    float t0y = ((lo[1] - pad) - o.y) * inv.y, t1y = ((hi[1] + pad) - o.y) * inv.y;
-    float t0z = ((lo[2] - pad) - o.z) * inv.z, t1z = ((hi[2] + pad) - o.z) * inv.z;
-    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                               __builtin_fminf(t0z, t1z));
-    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
-                               __builtin_fmaxf(t0z, t1z));
-    tn_out = tn;
-    return (tn <= tf) && (tf >= eps) && (tn <= best_t);
+// ---------------------------------------------------------------------------------------------
+// BVH traversal pieces shared by the megakernel and the simple per-thread path.
+//
+// None of this arithmetic reaches the image: it only decides which triangles get tested. So it may
+// use FMA and the fast reciprocal / sqrt. Why culling cannot change the result: a triangle accepted by
+// tri_test with parameter t has its point o + t*d within
+//     err <= ~18 * 2^-24 * (K*|d| + 1) * S        K = |e1||e2| / eps,  S >= |o - v0|
+// of the triangle's exact surface (|a| >= eps bounds the amplification of the rounding errors in
+// u, v and t). Child boxes are grown by pad = 64 * 2^-24 * (K_subtree*|d| + 1) * (S + |o|_inf), so
+// that point is strictly inside every ancestor's grown box (the |o|_inf term covers the o*inv
+// product of the FMA form), the slab interval contains t, and `tn <= best_t` (not <) keeps
+// equal-t candidates with a lower index reachable.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define RBRT_AS1(T, p) ((const __attribute__((address_space(1))) T*)(p))
+
+struct RayCull {
+    V3 inv, nod;  // 1/d and -(o/d)
+    float pad_base, pad_k;
+};
+
+__device__ __forceinline__ RayCull make_cull(V3 o, V3 d, const float* center, float radius, float eps_frac) {
+    RayCull rc;
+    const V3 oc = o - mk(center);
+    const float S = __builtin_amdgcn_sqrtf(dot(oc, oc)) + radius;
+    const float omax =
+        __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+    rc.pad_base = (64.0f / 16777216.0f) * (S + omax);
+    rc.pad_k = rc.pad_base * (__builtin_amdgcn_sqrtf(dot(d, d)) * eps_frac);
+    rc.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    rc.nod = mk(-(o.x * rc.inv.x), -(o.y * rc.inv.y), -(o.z * rc.inv.z));
+    return rc;
 }
 
-// Closest accepted triangle of one mesh = triangle.rs:134-262 + 392-410, found through the BVH.
-//
+constexpr uint32_t kMissKey = 0xFFFFFFFFu;
+
+// One child box of a 4-wide node: slab test of the box grown by pad. Returns the sort key of the
+// child: kMissKey when the ray misses it, else its entry distance (>= 0, two low mantissa bits
+// replaced by the child slot). An unused slot has NaN bounds, every compare fails, it misses.
+__device__ __forceinline__ uint32_t child_key(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                              float pad, const RayCull& rc, float eps, float best_t, uint32_t slot) {
+    const float t0x = __builtin_fmaf(lox - pad, rc.inv.x, rc.nod.x), t1x = __builtin_fmaf(hix + pad, rc.inv.x, rc.nod.x);
+    const float t0y = __builtin_fmaf(loy - pad, rc.inv.y, rc.nod.y), t1y = __builtin_fmaf(hiy + pad, rc.inv.y, rc.nod.y);
+    const float t0z = __builtin_fmaf(loz - pad, rc.inv.z, rc.nod.z), t1z = __builtin_fmaf(hiz + pad, rc.inv.z, rc.nod.z);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                     __builtin_fminf(t0z, t1z));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                                     __builtin_fmaxf(t0z, t1z));
+    const bool hit = (tn <= tf) && (tf >= eps) && (tn <= best_t);
+    return hit ? ((__float_as_uint(__builtin_fmaxf(tn, 0.0f)) & ~3u) | slot) : kMissKey;
+}
+
+__device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo;
+    b = hi;
+}
+
+// Fetch one 128-B node (8 x dwordx4 by this lane) and test its four children; k[] comes back sorted by
+// entry distance (misses last), c = the four child links.
+__device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull& rc, float eps, float best_t,
+                                            uint32_t k[4], f32x4& links) {
+    const auto* np = RBRT_AS1(f32x4, node);
+    const f32x4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5], me = np[7];
+    links = np[6];
+    k[0] = child_key(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, __builtin_fmaf(rc.pad_k, me.x, rc.pad_base), rc, eps, best_t, 0u);
+    k[1] = child_key(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, __builtin_fmaf(rc.pad_k, me.y, rc.pad_base), rc, eps, best_t, 1u);
+    k[2] = child_key(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, __builtin_fmaf(rc.pad_k, me.z, rc.pad_base), rc, eps, best_t, 2u);
+    k[3] = child_key(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, __builtin_fmaf(rc.pad_k, me.w, rc.pad_base), rc, eps, best_t, 3u);
+    cswap(k[0], k[1]);
+    cswap(k[2], k[3]);
+    cswap(k[0], k[2]);
+    cswap(k[1], k[3]);
+    cswap(k[1], k[2]);
+}
+__device__ __forceinline__ int32_t link_of(const f32x4& links, uint32_t key) {
+    const uint32_t s = key & 3u;
+    const float v = s == 0u ? links.x : (s == 1u ? links.y : (s == 2u ? links.z : links.w));
+    return __float_as_int(v);
+}
+
+// All triangles of one leaf (<= kLeafMax = 4), triangle.rs:189-255 + the arg-min rule of triangle.rs:400.
+// The (up to) 12 x 16-B loads are issued together so the leaf costs one memory round trip, not four;
+// slots past `count` re-read the last triangle and are masked out.
+template <bool STATS>
+__device__ __forceinline__ void leaf_test(const BvhTri* tris, int32_t leaf_ref, V3 o, V3 d, float eps, float eps_frac,
+                                          float& best_t, uint32_t& best_idx, LocalCounters& lc) {
+    const uint32_t leaf = uint32_t(~leaf_ref);
+    const uint32_t first = leaf >> 2, last = leaf & 3u;  // last = count - 1
+    f32x4 a[4], b[4], c[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const auto* tp = RBRT_AS1(f32x4, tris + first + (i < last ? i : last));
+        a[i] = tp[0], b[i] = tp[1], c[i] = tp[2];
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        if (i <= last) {
+            if (STATS) ++lc.tris;
+            float t;
+            const bool hit = tri_test(mk(a[i].x, a[i].y, a[i].z), mk(a[i].w, b[i].x, b[i].y), mk(b[i].z, b[i].w, c[i].x),
+                                      o, d, eps, eps_frac, t);
+            const uint32_t idx = __float_as_uint(c[i].y);
+            // strict < keeps the first (lowest) index among equal t
+            if (hit && (t < best_t || (t == best_t && idx < best_idx))) {
+                best_t = t;
+                best_idx = idx;
+            }
+        }
+    }
+}
+
+// Closest accepted triangle of one mesh = triangle.rs:134-262 + 392-410, found through the BVH
+// (simple one-thread-per-ray form with the whole stack in LDS; the megakernel has its own loop).
 // Result contract (what the brute-force scan returns): the smallest accepted t below the scan's
 // initial 1e6; among equal t the lowest reference index. best_t stays 1e6 when nothing is hit.
-//
-// Why culling cannot change the result: a triangle accepted by tri_test with parameter t has its
-// point o + t*d within   err <= ~18 * 2^-24 * (K*|d| + 1) * S   of the triangle's exact surface,
-// K = |e1||e2| / eps (|a| >= eps bounds the amplification of rounding errors in u, v, t), S >= |o - v0|.
-// Node boxes are grown by pad = 64 * 2^-24 * (K_subtree*|d| + 1) * S, so that point is strictly
-// inside every ancestor's grown box, the slab interval contains t, and `tn <= best_t` (not <) keeps
-// equal-t candidates with a lower index reachable.
 template <bool STATS>
 __device__ __forceinline__ void mesh_closest(const DevMesh& M, V3 o, V3 d, float eps, float eps_frac,
-                                             uint32_t* __restrict__ stack, float& best_t_out,
+                                             uint32_t* __restrict__ stack, uint32_t stride, float& best_t_out,
                                              uint32_t& best_idx_out, LocalCounters& lc) {
-    const float kPad = 64.0f / 16777216.0f;
-    const V3 oc = o - mk(M.center);
-    const float S = length(oc) + M.radius;
-    const float pad_base = kPad * S;
-    const float pad_k = pad_base * (length(d) / eps);
-    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const BvhNode* __restrict__ nodes = M.nodes;
-    const BvhTri* __restrict__ tris = M.tris;
-
+    const RayCull rc = make_cull(o, d, M.center, M.radius, eps_frac);
     float best_t = 1000000.0f;  // triangle.rs:398
     uint32_t best_idx = 0;
     int sp = 0;
     int32_t cur = 0;  // root
     for (;;) {
+        bool pop = true;
         if (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            uint32_t k[4];
+            f32x4 links;
+            node4_visit(M.nodes + cur, rc, eps, best_t, k, links);
             if (STATS) ++lc.nodes;
-            const float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
-            const float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
-            const int32_t c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            const float pad0 = pad_base + pad_k * n3.z, pad1 = pad_base + pad_k * n3.w;
-            float tn0, tn1;
-            const bool h0 = slab(lo0, hi0, pad0, o, inv, eps, best_t, tn0);
-            const bool h1 = slab(lo1, hi1, pad1, o, inv, eps, best_t, tn1);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;
-                stack[sp * kBlock] = uint32_t(swap ? c0 : c1);
-                ++sp;
-                cur = swap ? c1 : c0;
-                continue;
-            }
-            if (h0) {
-                cur = c0;
-                continue;
-            }
-            if (h1) {
-                cur = c1;
-                continue;
+            if (k[0] != kMissKey) {
+                if (k[3] != kMissKey) stack[(sp++) * stride] = uint32_t(link_of(links, k[3]));
+                if (k[2] != kMissKey) stack[(sp++) * stride] = uint32_t(link_of(links, k[2]));
+                if (k[1] != kMissKey) stack[(sp++) * stride] = uint32_t(link_of(links, k[1]));
+                cur = link_of(links, k[0]);
+                pop = false;
             }
         } else {
-            const uint32_t leaf = uint32_t(~cur);
-            const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                const float4* tp = reinterpret_cast<const float4*>(tris + first + i);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                if (STATS) ++lc.tris;
-                float t;
-                const bool hit = tri_test(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d,
-                                          eps, eps_frac, t);
-                const uint32_t idx = __float_as_uint(c.y);
-                // triangle.rs:400: strict < keeps the first (lowest) index among equal t
-                if (hit && (t < best_t || (t == best_t && idx < best_idx))) {
-                    best_t = t;
-                    best_idx = idx;
-                }
-            }
+            leaf_test<STATS>(M.tris, cur, o, d, eps, eps_frac, best_t, best_idx, lc);
         }
-        if (sp == 0) break;
-        --sp;
-        cur = int32_t(stack[sp * kBlock]);
+        if (pop) {
+            if (sp == 0) break;
+            cur = int32_t(stack[(--sp) * stride]);
+        }
     }
     best_t_out = best_t;
     best_idx_out = best_idx;
@@ -267,8 +322,8 @@ struct HitRec {
 
 // scene.rs:19-43: spheres in order, then meshes in order, strictly smaller distance wins.
 template <bool STATS>
-__device__ __forceinline__ void scene_hit(const TraceParams& P, V3 o, V3 d, uint32_t* stack, HitRec& h,
-                                          LocalCounters& lc) {
+__device__ __forceinline__ void scene_hit(const TraceParams& P, V3 o, V3 d, uint32_t* stack, uint32_t stride,
+                                          HitRec& h, LocalCounters& lc) {
     float closest = 3.40282347e+38f;  // f32::MAX
     h.obj = -1;
     h.t = 0.0f;
@@ -291,7 +346,7 @@ __device__ __forceinline__ void scene_hit(const TraceParams& P, V3 o, V3 d, uint
         if (STATS) ++lc.gate;
         float t;
         uint32_t idx;
-        mesh_closest<STATS>(M, o, d, P.min_dist, P.eps_frac, stack, t, idx, lc);
+        mesh_closest<STATS>(M, o, d, P.min_dist, P.eps_frac, stack, stride, t, idx, lc);
         if (t > P.min_dist && t < 100000.0f) {  // triangle.rs:405
             V3 p = o + t * d;                    // mesh.rs:247-249
             float dist = length(o - p);
@@ -380,130 +435,6 @@ __device__ __forceinline__ bool scatter(const DevMaterial& m, V3 in_d, V3 p, V3 
         float reflect_prob = refract(in_d, outward, ni_over_nt, refracted) ? schlick(cosine, m.param) : 1.0f;
         out_d = (rng.next_f32() < reflect_prob) ? reflected : refracted;
         return true;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// One path: cam.rs:64-82 + lib.rs:43-73 unrolled into a loop.
-//
-// The reference's recursion multiplies attenuations right to left: a1 * (a2 * (... * leaf)).
-// fp32 products do not associate, so the loop records WHICH object scattered at each bounce (one
-// byte per bounce, in LDS) and folds the product from the innermost bounce outwards at the end.
-// Dielectric bounces multiply by exactly (1,1,1) and are not recorded.
-// ---------------------------------------------------------------------------------------------
-template <bool STATS>
-__device__ __forceinline__ V3 trace_path(const TraceParams& P, uint32_t row, uint32_t col, uint32_t sample,
-                                         uint32_t* stack, uint32_t* seq, LocalCounters& lc) {
-    Rng rng;
-    rng.init(P.seed_key, row * P.cam.img_width_pix + col, sample);
-
-    // cam.rs:64-82
-    const float col_off = float(col) - float(P.cam.img_width_pix / 2);
-    const float row_off = float(row) - float(P.cam.img_height_pix / 2);
-    const float u0 = rng.next_f32();
-    const float col_mm = ((col_off + u0) - 0.5f) * P.cam.mm_per_pix_hor;
-    const float u1 = rng.next_f32();
-    const float row_mm = ((row_off + u1) - 0.5f) * P.cam.mm_per_pix_vert;
-    const V3 pos = mk(P.cam.position);
-    const V3 target =
-        (mk(P.cam.img_center_point) + (0.001f * col_mm) * mk(P.cam.right)) - (0.001f * row_mm) * mk(P.cam.up);
-    V3 o = pos;
-    V3 d = normalize(target - pos);
-
-    V3 color;
-    uint32_t nrec = 0, cur_word = 0;
-    for (uint32_t depth = P.max_depth;; --depth) {
-        HitRec h;
-        scene_hit<STATS>(P, o, d, stack, h, lc);
-        if (h.obj < 0) {  // lib.rs:68-71, with the direction as it is (not re-normalised)
-            const float t = 0.5f * (d.y + 1.0f);
-            color = t * mk(1.0f, 1.0f, 1.0f) + (1.0f - t) * mk(P.bg);
-            break;
-        }
-        if (depth == 0) {  // lib.rs:54: scatter is not even called, no draws
-            color = mk(0.0f, 0.0f, 0.0f);
-            break;
-        }
-        const V3 p = o + h.t * d;  // same expression as inside the intersection routines
-        V3 n;
-        if (uint32_t(h.obj) < P.n_spheres) {
-            n = p - mk(P.spheres[h.obj].center);  // sphere.rs:56, unnormalised
-        } else {
-            const Normal4 nn = P.meshes[uint32_t(h.obj) - P.n_spheres].normals[h.tri];  // mesh.rs:253-257
-            n = mk(nn.x, nn.y, nn.z);
-        }
-        const DevMaterial m = P.materials[h.obj];
-        V3 nd;
-        const bool ok = scatter(m, d, p, n, rng, nd);
-        if (!ok) {  // lib.rs:63-66
-            color = mk(0.0f, 0.0f, 0.0f);
-            break;
-        }
-        if (m.kind != RBRT_MAT_DIELECTRIC) {
-            cur_word |= uint32_t(h.obj) << (8u * (nrec & 3u));
-            if ((nrec & 3u) == 3u) {
-                seq[(nrec >> 2) * kBlock] = cur_word;
-                cur_word = 0;
-            }
-            ++nrec;
-        }
-        o = p;
-        d = nd;
-    }
-    if (nrec & 3u) seq[(nrec >> 2) * kBlock] = cur_word;
-    // lib.rs:62: attenuation * colorize(...), innermost first
-    for (uint32_t k = nrec; k-- > 0;) {
-        const uint32_t w = seq[(k >> 2) * kBlock];
-        const uint32_t obj = (w >> (8u * (k & 3u))) & 0xFFu;
-        const DevMaterial m = P.materials[obj];
-        color = mk(m.albedo) * color;
-    }
-    return color;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Kernels
-// ---------------------------------------------------------------------------------------------
-
-// LDS carve (dynamic): [kStackEntries][kBlock] u32 traversal stack, then [kMaxPathDepth/4][kBlock]
-// u32 scatter records. Entry-major so that the 64 lanes of a wave hit 64 consecutive banks.
-constexpr size_t kLdsBytes = size_t(kStackEntries + kMaxPathDepth / 4) * kBlock * sizeof(uint32_t);
-
-// Work item i of a batch = (local tile, sample in batch, pixel in tile):
-//   i = (tile_local * batch + s) * 64 + p, so one wave = one 8x8 tile at one sample index (coherent
-// primary rays) and neighbouring waves work on the same tile (shared BVH working set in L1/L2).
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams P) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t* stack = lds + threadIdx.x;
-    uint32_t* seq = lds + kStackEntries * kBlock + threadIdx.x;
-
-    const uint64_t item = uint64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (item >= P.n_items) return;
-    const uint32_t p = uint32_t(item & 63u);
-    const uint64_t ts = item >> 6;
-    const uint32_t s = uint32_t(ts % P.batch);
-    const uint32_t tile_local = uint32_t(ts / P.batch);
-    const uint32_t tile = tile_local * P.tile_world + P.tile_rank;
-    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    const uint32_t row = ty * RBRT_TILE + (p >> 3), col = tx * RBRT_TILE + (p & 7u);
-    if (row >= P.cam.img_height_pix || col >= P.cam.img_width_pix) return;
-
-    LocalCounters lc = {0, 0, 0, 0, 0};
-    const V3 c = trace_path<STATS>(P, row, col, P.sample_base + s, stack, seq, lc);
-
-    const size_t npix = size_t(P.n_local_tiles) * 64u;
-    float* out = P.sample_buf + (size_t(s) * npix + size_t(tile_local) * 64u + p) * 3u;
-    out[0] = c.x;
-    out[1] = c.y;
-    out[2] = c.z;
-    if (STATS) {
-        atomicAdd(&P.counters->rays, (unsigned long long)lc.rays);
-        atomicAdd(&P.counters->mesh_gate_pass, (unsigned long long)lc.gate);
-        atomicAdd(&P.counters->nodes_visited, (unsigned long long)lc.nodes);
-        atomicAdd(&P.counters->tris_tested, (unsigned long long)lc.tris);
-        atomicAdd(&P.counters->mesh_hits, (unsigned long long)lc.mesh_hits);
-        atomicAdd(&P.counters->samples, 1ull);
     }
 }
 
@@ -601,17 +532,18 @@ __global__ __launch_bounds__(kBlock) void unpack_kernel(const float* __restrict_
 }
 
 // Scene::hit for arbitrary rays (test / diagnostic hook behind rbrt_hip_trace_rays).
-__global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceParams P, const float* __restrict__ rays,
+constexpr int kRaysBlock = 128;
+__global__ __launch_bounds__(kRaysBlock) void trace_rays_kernel(const TraceParams P, const float* __restrict__ rays,
                                                             size_t n, float* out_t, int32_t* out_obj,
                                                             int32_t* out_tri, float* out_dist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* stack = lds + threadIdx.x;
-    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t i = size_t(blockIdx.x) * kRaysBlock + threadIdx.x;
     if (i >= n) return;
     const V3 o = mk(rays + 6 * i), d = mk(rays + 6 * i + 3);
     HitRec h;
     LocalCounters lc = {0, 0, 0, 0, 0};
-    scene_hit<false>(P, o, d, stack, h, lc);
+    scene_hit<false>(P, o, d, stack, uint32_t(kRaysBlock), h, lc);
     const bool hit = h.obj >= 0;
     const float nanv = __int_as_float(0x7fc00000);
     if (out_t) out_t[i] = hit ? h.t : nanv;
@@ -623,18 +555,8 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(const TraceParams P,
 // ---------------------------------------------------------------------------------------------
 // Launch wrappers (called from api.cpp, which is plain C++)
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_trace_v1(const TraceParams& P, bool stats, hipStream_t stream) {
-    const uint64_t blocks = (P.n_items + kBlock - 1) / kBlock;
-    if (blocks == 0) return hipSuccess;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    if (stats)
-        hipLaunchKernelGGL(trace_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), kLdsBytes, stream, P);
-    else
-        hipLaunchKernelGGL(trace_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), kLdsBytes, stream, P);
-    return hipGetLastError();
-}
-
 size_t megakernel_gseq_bytes(uint32_t n_waves) { return size_t(n_waves) * kPoolMax * kSeqWords * sizeof(uint32_t); }
+size_t megakernel_gstack_bytes(uint32_t n_waves) { return size_t(n_waves) * kStackMax * 64u * sizeof(uint32_t); }
 
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
     const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw;
@@ -686,8 +608,8 @@ hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height,
 hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, float* out_t, int32_t* out_obj,
                              int32_t* out_tri, float* out_dist, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(trace_rays_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock),
-                       size_t(kStackEntries) * kBlock * sizeof(uint32_t), stream, P, rays, n, out_t, out_obj,
+    hipLaunchKernelGGL(trace_rays_kernel, dim3(uint32_t((n + kRaysBlock - 1) / kRaysBlock)), dim3(kRaysBlock),
+                       size_t(kStackMax) * kRaysBlock * sizeof(uint32_t), stream, P, rays, n, out_t, out_obj,
                        out_tri, out_dist);
     return hipGetLastError();
 }

@@ -18,14 +18,6 @@
 // Which lane works on which path never affects the result: a path owns its RNG stream and its
 // sample slot, and resolve_kernel adds the samples of a pixel in sample order.
 
-// Explicit address spaces: pointers that arrive inside the by-value TraceParams struct are generic
-// ("flat") to the compiler, which then emits flat_load (counts on vmcnt AND lgkmcnt, never scalar).
-// AS1 = global (per-lane gathers: nodes, triangles, normals), AS4 = constant (wave-uniform tables:
-// spheres, materials, mesh descriptors -> s_load).
-#define RBRT_AS1(T, p) ((const __attribute__((address_space(1))) T*)(p))
-#define RBRT_AS4(T, p) ((const __attribute__((address_space(4))) T*)(p))
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_S0, F_S1, F_ITEM, F_META, F_DIST, F_T, F_TRI, F_WORD, kFields };
 enum : uint32_t { ST_EMPTY = 0u, ST_TRAV = 1u, ST_TERM = 2u, ST_LAMB = 3u, ST_METAL = 4u, ST_DIEL = 5u, kNumStatus = 6u,
                   ST_BUSY = 6u /* being traversed by a lane right now */ };
@@ -78,22 +70,6 @@ __device__ __forceinline__ uint32_t classify(const SceneLds& sc, int32_t obj, ui
     return ST_LAMB + sc.mat[uint32_t(obj) * kMatDw + 4];
 }
 
-// Culling-only slab test (never feeds the image): box grown by pad, planes through one FMA each.
-// nod = -(o * inv). See mesh_closest for why the pad makes culling result-invariant; the FMA form
-// adds an error of ~eps*|o| per plane which pad_base covers (it includes 64*eps*|o|_inf).
-__device__ __forceinline__ bool slab_fast(const float* lo, const float* hi, float pad, V3 inv, V3 nod, float eps,
-                                          float best_t, float& tn_out) {
-    const float t0x = __builtin_fmaf(lo[0] - pad, inv.x, nod.x), t1x = __builtin_fmaf(hi[0] + pad, inv.x, nod.x);
-    const float t0y = __builtin_fmaf(lo[1] - pad, inv.y, nod.y), t1y = __builtin_fmaf(hi[1] + pad, inv.y, nod.y);
-    const float t0z = __builtin_fmaf(lo[2] - pad, inv.z, nod.z), t1z = __builtin_fmaf(hi[2] + pad, inv.z, nod.z);
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                                     __builtin_fminf(t0z, t1z));
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
-                                     __builtin_fmaxf(t0z, t1z));
-    tn_out = tn;
-    return (tn <= tf) && (tf >= eps) && (tn <= best_t);
-}
-
 template <int POOLN, bool STATS>
 __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -141,13 +117,29 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
     bool t_active = false;      // this lane is in the middle of a traversal
     bool t_has_result = false;  // this lane finished a traversal that is not finalised yet
     uint32_t t_slot = 0;
-    V3 t_o = mk(0.0f, 0.0f, 0.0f), t_d = t_o, t_inv = t_o, t_nod = t_o;
-    float t_pad_base = 0.0f, t_pad_k = 0.0f, t_best = 0.0f;
+    V3 t_o = mk(0.0f, 0.0f, 0.0f), t_d = t_o;
+    RayCull t_rc = {t_o, t_o, 0.0f, 0.0f};
+    float t_best = 0.0f;
     uint32_t t_best_idx = 0, t_mesh = 0;
-    const BvhNode* t_nodes = nullptr;
+    const BvhNode4* t_nodes = nullptr;
     const BvhTri* t_tris = nullptr;
-    int t_sp = 0;
-    int32_t t_cur = 0;
+    uint32_t t_sp = 0;
+    int32_t t_cur = 0;          // node to visit next: >= 0 inner, < 0 leaf, kNoChild = none (stack ran empty)
+    int32_t t_pend = kNoChild;  // a leaf reached earlier whose triangles have not been tested yet
+    // The first P.stack_entries stack slots of a lane live in LDS, deeper ones in this wave's global scratch.
+    uint32_t* const gstack = P.gstack + size_t(blockIdx.x) * kStackMax * 64u + lane;
+    const uint32_t n_lds_stack = P.stack_entries;
+    auto push = [&](int32_t v) {
+        if (t_sp < n_lds_stack)
+            stack[t_sp * 64u] = uint32_t(v);
+        else
+            gstack[(t_sp - n_lds_stack) * 64u] = uint32_t(v);
+        ++t_sp;
+    };
+    auto pop = [&]() -> int32_t {
+        --t_sp;
+        return int32_t(t_sp < n_lds_stack ? stack[t_sp * 64u] : gstack[(t_sp - n_lds_stack) * 64u]);
+    };
 
     for (;;) {
         // ---- finalise finished traversals in a batch (mesh.rs:245-266, scene.rs:33-41) ----
@@ -215,21 +207,15 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                              __uint_as_float(POOL(F_DZ, slot)));
                     t_mesh = (POOL(F_META, slot) >> 22) & 255u;
                     const uint32_t* md = sc.mesh + t_mesh * kMeshDw;
-                    t_nodes = lds_ptr<BvhNode>(md + MD_NODES);
+                    t_nodes = lds_ptr<BvhNode4>(md + MD_NODES);
                     t_tris = lds_ptr<BvhTri>(md + MD_TRIS);
-                    // culling-only quantities: fast reciprocal / sqrt are fine here
-                    const V3 oc = t_o - mk(reinterpret_cast<const float*>(md) + MD_CENTER);
-                    const float S = __builtin_amdgcn_sqrtf(dot(oc, oc)) + __uint_as_float(md[MD_RADIUS]);
-                    const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t_o.x), __builtin_fabsf(t_o.y)),
-                                                       __builtin_fabsf(t_o.z));
-                    t_pad_base = (64.0f / 16777216.0f) * (S + omax);
-                    t_pad_k = t_pad_base * (__builtin_amdgcn_sqrtf(dot(t_d, t_d)) * P.eps_frac);
-                    t_inv = mk(__builtin_amdgcn_rcpf(t_d.x), __builtin_amdgcn_rcpf(t_d.y), __builtin_amdgcn_rcpf(t_d.z));
-                    t_nod = mk(-(t_o.x * t_inv.x), -(t_o.y * t_inv.y), -(t_o.z * t_inv.z));
+                    t_rc = make_cull(t_o, t_d, reinterpret_cast<const float*>(md) + MD_CENTER,
+                                     __uint_as_float(md[MD_RADIUS]), P.eps_frac);
                     t_best = 1000000.0f;  // triangle.rs:398
                     t_best_idx = 0;
                     t_sp = 0;
                     t_cur = 0;
+                    t_pend = kNoChild;
                     t_active = true;
                     if (STATS) ++dg_lanes[ST_TRAV];
                 }
@@ -267,57 +253,38 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                     ++dg_steps;
                     dg_lane_steps += uint32_t(__popcll(__ballot(t_active)));
                 }
-                if (t_active) {
-                    bool pop = true;
-                    if (t_cur >= 0) {
-                        const auto* np = RBRT_AS1(f32x4, t_nodes + t_cur);
-                        const f32x4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                        if (STATS) ++lc.nodes;
-                        const float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
-                        const float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
-                        const int32_t c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                        float tn0, tn1;
-                        const bool h0 = slab_fast(lo0, hi0, __builtin_fmaf(t_pad_k, n3.z, t_pad_base), t_inv, t_nod, eps,
-                                                  t_best, tn0);
-                        const bool h1 = slab_fast(lo1, hi1, __builtin_fmaf(t_pad_k, n3.w, t_pad_base), t_inv, t_nod, eps,
-                                                  t_best, tn1);
-                        if (h0 && h1) {
-                            const bool swap = tn1 < tn0;
-                            stack[t_sp * 64] = uint32_t(swap ? c0 : c1);
-                            ++t_sp;
-                            t_cur = swap ? c1 : c0;
-                            pop = false;
-                        } else if (h0 || h1) {
-                            t_cur = h0 ? c0 : c1;
-                            pop = false;
-                        }
+                // Leaves are deferred: a lane that reaches a leaf remembers it (one pending leaf per lane) and
+                // keeps walking; triangles are tested in rounds, when enough lanes hold a leaf or no lane can
+                // walk on. Testing later only delays the shrinking of t_best, it cannot change the result.
+                if (t_active && t_cur < 0 && t_cur != kNoChild && t_pend == kNoChild) {
+                    t_pend = t_cur;
+                    t_cur = t_sp != 0 ? pop() : kNoChild;
+                }
+                const bool can_walk = t_active && t_cur >= 0;
+                const uint32_t n_pend = uint32_t(__popcll(__ballot(t_active && t_pend != kNoChild)));
+                if (n_pend != 0 && (n_pend >= P.leaf_round || !__any(can_walk))) {
+                    if (t_active && t_pend != kNoChild) {
+                        leaf_test<STATS>(t_tris, t_pend, t_o, t_d, eps, P.eps_frac, t_best, t_best_idx, lc);
+                        t_pend = kNoChild;
+                    }
+                }
+                if (can_walk) {
+                    uint32_t k[4];
+                    f32x4 links;
+                    node4_visit(t_nodes + t_cur, t_rc, eps, t_best, k, links);
+                    if (STATS) ++lc.nodes;
+                    if (k[0] != kMissKey) {  // farthest first, so that the nearest is popped first
+                        if (k[3] != kMissKey) push(link_of(links, k[3]));
+                        if (k[2] != kMissKey) push(link_of(links, k[2]));
+                        if (k[1] != kMissKey) push(link_of(links, k[1]));
+                        t_cur = link_of(links, k[0]);
                     } else {
-                        const uint32_t leaf = uint32_t(~t_cur);
-                        const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-                        for (uint32_t i = 0; i < count; ++i) {
-                            const auto* tp = RBRT_AS1(f32x4, t_tris + first + i);
-                            const f32x4 a = tp[0], b = tp[1], c = tp[2];
-                            if (STATS) ++lc.tris;
-                            float t;
-                            const bool hit = tri_test(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t_o, t_d,
-                                                      eps, P.eps_frac, t);
-                            const uint32_t idx = __float_as_uint(c.y);
-                            // triangle.rs:400: strict < keeps the lowest index among equal t
-                            if (hit && (t < t_best || (t == t_best && idx < t_best_idx))) {
-                                t_best = t;
-                                t_best_idx = idx;
-                            }
-                        }
+                        t_cur = t_sp != 0 ? pop() : kNoChild;
                     }
-                    if (pop) {
-                        if (t_sp == 0) {
-                            t_active = false;
-                            t_has_result = true;
-                        } else {
-                            --t_sp;
-                            t_cur = int32_t(stack[t_sp * 64]);
-                        }
-                    }
+                }
+                if (t_active && t_cur == kNoChild && t_pend == kNoChild) {
+                    t_active = false;
+                    t_has_result = true;
                 }
             } while (uint32_t(__popcll(__ballot(t_active))) >= keep);
             if (STATS) dg_t_trav += __builtin_amdgcn_s_memtime() - dg_tk;

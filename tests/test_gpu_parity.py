@@ -208,5 +208,5 @@ def test_stats_counters(hip, oracle):
     exp, _, rays = oracle.render(cam, sc, abi.default_opts(spp=2, seed=1))
     assert st["samples"] == 64 * 48 * 2
     assert st["rays"] == rays
-    assert st["nodes_visited"] > 0 and st["tris_tested"] > 0 and st["node_bytes"] == 64
+    assert st["nodes_visited"] > 0 and st["tris_tested"] > 0 and st["node_bytes"] == 128
     assert_same_image(out.cpu().numpy(), exp, "render_device")
