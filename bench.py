@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--cpu-col-stride", type=int, default=16,
                     help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline)")
     ap.add_argument("--check", action="store_true", help="also compare the sampled columns with the GPU image")
+    ap.add_argument("--rehearse-single-gpu", action="store_true",
+                    help="N > 1 ranks all on cuda:0 with a gloo gather through host memory: exercises the sharded "
+                         "path on a one-GPU box; its numbers mean nothing")
     return ap.parse_args()
 
 
@@ -73,11 +76,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.rehearse_single_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_single_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- setup (untimed): stand-in asset, YAML through the C++ host, upload + BVH build ---------
     work = Path(tempfile.mkdtemp(prefix=f"rbrt_bench_r{rank}_"))
@@ -114,7 +122,15 @@ def main():
             scene.render_device(cam, opts, image.data_ptr(), None, stream)
             return
         scene.render_device(cam, opts, mine.data_ptr(), None, stream)
-        dist.gather(mine, gathered, dst=0)
+        if args.rehearse_single_gpu:  # gloo cannot gather device tensors: stage through the host
+            host = mine.cpu()
+            hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, hg, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    gathered[r].copy_(hg[r])
+        else:
+            dist.gather(mine, gathered, dst=0)  # RCCL over xGMI: every peer sends its tiles straight to rank 0
         if rank == 0:
             off = 0
             for r in range(world):  # drop the equal-size padding
@@ -148,7 +164,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_single_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     trace_ms, resolve_ms, n_launches = scene.kernel_ms()
@@ -159,6 +175,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    import hashlib
+    image_sha = hashlib.sha256(image.cpu().numpy().tobytes()).hexdigest()[:16]
     samples_per_step = W * H * spp
     value = samples_per_step * args.steps / elapsed / 1e6
     # dominant kernel = trace_kernel; algorithmic bytes of ONE launch on this rank (DESIGN.md "Measurement")
@@ -190,7 +208,7 @@ def main():
         "config": {"workload": f"example_scene.yaml, {args.triangles}-triangle "
                                f"{'bunny.obj' if real_asset else 'stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
-                   "setup_s_excluded": round(setup_s, 3),
+                   "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,
                    "resolve_kernel_ms": round(resolve_ms / max(1, n_launches), 4)},
         "roofline": roofline,
     }

@@ -82,9 +82,9 @@ struct rbrt_hip_scene {
     uint32_t* d_gstack = nullptr;
     uint32_t stack_need = 1;  // deepest BVH: 3 per level + 1
     uint32_t n_waves = 0;  // persistent megakernel grid: as many single-wave workgroups as fit the LDS
-    uint32_t pool = 192;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
+    uint32_t pool = 128;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
     uint32_t stack_entries = kLdsStack;  // per-lane stack entries kept in LDS (RBRT_LDS_STACK)
-    uint32_t y_low_water = 48;    // RBRT_Y_LOW
+    uint32_t y_low_water = 40;    // RBRT_Y_LOW
     uint32_t leaf_round = 24;     // RBRT_LEAF_ROUND
     // stats / timing
     rbrt_hip_stats_t stats{};

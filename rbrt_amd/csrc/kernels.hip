@@ -368,13 +368,20 @@ __device__ __forceinline__ void scene_hit(const TraceParams& P, V3 o, V3 d, uint
 // Materials
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ V3 random_point_in_unit_sphere(Rng& rng) {  // materials.rs:14-30
+    // The reference loops `while point.length() > 1.0`. With a correctly rounded sqrt,
+    // sqrt(s) > 1.0f holds exactly when s > 0x1.000002p0f (the float after 1.0): sqrt(1 + 2^-23)
+    // still rounds to 1.0, sqrt(1 + 2^-22) rounds to 1 + 2^-23. So the loop can compare the squared
+    // length and skip an IEEE square root per iteration with bit-identical accept/reject decisions
+    // (checked exhaustively around 1.0 in tests/test_oracle_kats.py).
     V3 p;
+    float s;
     do {
         float x = rng.next_f32();
         float y = rng.next_f32();
         float z = rng.next_f32();
         p = 2.0f * mk(x, y, z) - mk(1.0f, 1.0f, 1.0f);
-    } while (length(p) > 1.0f);
+        s = (p.x * p.x + p.y * p.y) + p.z * p.z;
+    } while (s > 1.00000011920928955078125f);
     return p;
 }
 

@@ -1,0 +1,56 @@
+"""Pixel-tile sharding index math (host side, numpy) — the same layout the kernels use.
+
+An image is cut into 8x8 tiles in row-major tile order; tile t belongs to rank t % world; a rank's
+packed buffer holds its tiles in ascending tile order, 64 pixel slots per tile (slot p = (y%8)*8 +
+x%8; slots outside a ragged image edge are padding). bench.py gathers the packed buffers with one
+RCCL gather and rank 0 de-interleaves them (rbrt_hip_unpack_tiles on the GPU; `unpack` here is the
+numpy restatement used by the CPU tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TILE = 8
+
+
+def n_tiles(width: int, height: int) -> int:
+    return ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE)
+
+
+def local_tiles(width: int, height: int, rank: int, world: int) -> int:
+    n = n_tiles(width, height)
+    return (n - rank + world - 1) // world if rank < n else 0
+
+
+def packed_pixels(width: int, height: int, rank: int, world: int) -> int:
+    return local_tiles(width, height, rank, world) * TILE * TILE
+
+
+def _index_maps(width: int, height: int, world: int):
+    """For every image pixel: (owner rank, slot index inside the owner's packed buffer)."""
+    tiles_x = (width + TILE - 1) // TILE
+    ys, xs = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    tile = (ys // TILE) * tiles_x + xs // TILE
+    return tile % world, (tile // world) * TILE * TILE + (ys % TILE) * TILE + xs % TILE
+
+
+def pack(image: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """image [H,W,C] -> this rank's packed buffer [packed_pixels, C] (padding slots are zero)."""
+    h, w, c = image.shape
+    out = np.zeros((packed_pixels(w, h, rank, world), c), image.dtype)
+    owner, slot = _index_maps(w, h, world)
+    mine = owner == rank
+    out[slot[mine]] = image[mine]
+    return out
+
+
+def unpack(packed_per_rank, width: int, height: int) -> np.ndarray:
+    """list of per-rank packed buffers (rank order) -> image [H,W,C]."""
+    world = len(packed_per_rank)
+    c = packed_per_rank[0].shape[1]
+    out = np.zeros((height, width, c), packed_per_rank[0].dtype)
+    owner, slot = _index_maps(width, height, world)
+    for r in range(world):
+        mine = owner == r
+        out[mine] = packed_per_rank[r][slot[mine]]
+    return out

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures from the CPU oracle (oracle/rbrt_oracle.cpp).
+
+    python tests/golden/make_golden.py
+
+The reference itself cannot run here (Rust, no toolchain; and it has no RNG seed), so the goldens
+are outputs of the build's own seeded restatement, which tests/test_oracle_kats.py pins against the
+reference's unit-test vectors. Each fixture = inputs (scene description by name + seed + size) and
+expected outputs: SHA-256 of the full fp32 radiance / RGB8 bytes plus a sub-sampled copy of the
+radiance for diagnosing a mismatch. No reference source text is stored here.
+"""
+import hashlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent.parent))
+sys.path.insert(0, str(HERE.parent))
+from oracle import pyoracle  # noqa: E402
+import scenes  # noqa: E402
+from rbrt_amd import abi  # noqa: E402
+
+CASES = {
+    # BASELINE config 1: camera + 4 spheres of example_scene.yaml, no mesh, 400x300, 8 spp, seed 1
+    "cfg1_spheres_400x300x8_seed1": dict(kind="spheres", w=400, h=300, spp=8, seed=1),
+    "header_spheres_320x160x16_seed5": dict(kind="header_spheres", w=320, h=160, spp=16, seed=5),
+    # example_scene.yaml layout with small stand-in meshes covering the padding cases N % 8 = 0,3,4,6
+    "mesh2000_160x120x4_seed2": dict(kind="mesh", n=2000, w=160, h=120, spp=4, seed=2),
+    "mesh2003_160x120x4_seed2": dict(kind="mesh", n=2003, w=160, h=120, spp=4, seed=2),
+    "mesh2004_160x120x4_seed2": dict(kind="mesh", n=2004, w=160, h=120, spp=4, seed=2),
+    "mesh2006_160x120x4_seed2": dict(kind="mesh", n=2006, w=160, h=120, spp=4, seed=2),
+}
+
+
+def build_scene(case):
+    if case["kind"] == "spheres":
+        return scenes.spheres_scene()
+    if case["kind"] == "header_spheres":
+        return scenes.spheres_scene(scenes.HEADER_SPHERES)
+    return scenes.example_scene(pyoracle, case["n"])
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    for name, case in CASES.items():
+        cam = scenes.camera(pyoracle, case["w"], case["h"])
+        sc = build_scene(case)
+        rad, rgb, rays = pyoracle.render(cam, sc, abi.default_opts(spp=case["spp"], seed=case["seed"]))
+        np.savez_compressed(HERE / f"{name}.npz", radiance_sha256=sha(rad), rgb8_sha256=sha(rgb),
+                            radiance_sub=rad[::4, ::4].copy(), rgb8_sub=rgb[::4, ::4].copy(), rays=np.int64(rays),
+                            mean=rad.mean(axis=(0, 1)))
+        print(name, sha(rad)[:16], rays)
+    # single-ray records: Scene::hit on a fixed bundle of rays through the example scene + 3001-triangle stand-in
+    sc = scenes.example_scene(pyoracle, 3001)
+    md = sc.meshes[0]
+    rng = np.random.default_rng(12345)
+    c = (md.bbox_lo + md.bbox_hi) / 2
+    R = float(np.linalg.norm(md.bbox_hi - md.bbox_lo) / 2)
+    o = np.float32([0.0, 5.0, 4.0]) + rng.normal(size=(600, 3)) * 0.5
+    tgt = np.where(rng.random((600, 1)) < 0.6, c + rng.uniform(-1, 1, (600, 3)) * R,
+                   np.float32([0, 1, -10]) + rng.uniform(-8, 8, (600, 3)))
+    d = tgt - o
+    d = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.3, 2.0, (600, 1))
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    t, obj, tri, dist = pyoracle.trace_rays(sc, rays)
+    np.savez_compressed(HERE / "rays_example3001.npz", rays=rays, t=t, obj=obj, tri=tri, dist=dist)
+    print("rays", int((obj >= 4).sum()), "mesh hits,", int((obj >= 0).sum()), "hits of 600")
+
+
+if __name__ == "__main__":
+    main()

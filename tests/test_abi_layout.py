@@ -1,0 +1,88 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/rbrt_hip.h declares, and the
+ctypes mirror (rbrt_amd/abi.py) has the same struct layout a C compiler gives the header."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+from rbrt_amd import abi, tiles
+
+ROOT = Path(__file__).resolve().parent.parent
+STRUCTS = {"rbrt_material_t": abi.Material, "rbrt_sphere_t": abi.Sphere, "rbrt_mesh_t": abi.Mesh,
+           "rbrt_scene_t": abi.Scene, "rbrt_camera_t": abi.Camera, "rbrt_render_opts_t": abi.RenderOpts,
+           "rbrt_hip_stats_t": abi.Stats}
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "rbrt_hip.h").read_text()
+    declared = set(re.findall(r"\b(rbrt_(?:hip_)?[a-z_0-9]+)\s*\(", header))
+    declared -= {"rbrt_hip_scene"}  # the opaque struct tag
+    lib = abi.load_hip()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in rbrt_hip.h but not exported"
+    assert declared == set(abi.HIP_SYMBOLS), declared ^ set(abi.HIP_SYMBOLS)
+    assert lib.rbrt_hip_abi_version() == 1
+
+
+def test_struct_layout_matches_the_c_header(tmp_path):
+    fields = []
+    for cname, cls in STRUCTS.items():
+        fields.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f, _ in cls._fields_:
+            fields.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "rbrt_hip.h"\nint main(void){' + "".join(fields) + "return 0;}"
+    (tmp_path / "layout.c").write_text(src)
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), "-o", str(tmp_path / "layout"), str(tmp_path / "layout.c")],
+                   check=True)
+    out = subprocess.run([str(tmp_path / "layout")], check=True, capture_output=True, text=True).stdout
+    got = dict(line.split() for line in out.strip().splitlines())
+    for cname, cls in STRUCTS.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got[f"{cname}.{f}"]) == getattr(cls, f).offset, f"{cname}.{f}"
+
+
+def test_defaults_match_the_reference_constants():
+    lib = abi.load_hip()
+    o = abi.RenderOpts()
+    lib.rbrt_render_opts_default(C.byref(o))
+    assert (o.spp, o.max_depth) == (5, 50)          # src/main.rs:47, lib.rs:99
+    assert (o.min_dist, o.max_dist) == (C.c_float(0.001).value, 2000.0)   # lib.rs:44-45
+    assert list(o.bg) == [C.c_float(0.05).value, C.c_float(0.05).value, C.c_float(0.8).value]  # lib.rs:89-93
+    assert (o.tile_rank, o.tile_world, o.flags) == (0, 1, 0)
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    """Without a GPU every render entry point fails loudly (this container has none)."""
+    import rbrt_amd
+    if rbrt_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    cam = abi.Camera()
+    cam.img_width_pix, cam.img_height_pix = 8, 8
+    with pytest.raises(abi.RbrtError) as e:
+        rbrt_amd.render_scene(cam, 1, abi.SceneData())
+    assert e.value.code == abi.RBRT_ERR_NO_DEVICE
+    with pytest.raises(abi.RbrtError):
+        rbrt_amd.HipScene(abi.SceneData())
+
+
+def test_invalid_arguments_are_rejected_before_touching_the_device():
+    lib = abi.load_hip()
+    h = C.c_void_p()
+    assert lib.rbrt_hip_scene_create(None, 0, C.byref(h)) == abi.RBRT_ERR_INVALID_ARG
+    sc = abi.SceneData(spheres=[((0, 0, -5), 1.0, abi.Material(7, (C.c_float * 3)(0, 0, 0), 0.0))])
+    assert lib.rbrt_hip_scene_create(sc.ptr(), 0, C.byref(h)) == abi.RBRT_ERR_INVALID_ARG  # unknown material kind
+    assert b"material" in lib.rbrt_hip_last_error()
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (8, 8), (9, 17), (100, 60), (1024, 768), (1920, 1080)])
+def test_packed_pixels_matches_python_index_math(w, h):
+    lib = abi.load_hip()
+    for world in (1, 2, 3, 8):
+        total = 0
+        for r in range(world):
+            assert lib.rbrt_hip_packed_pixels(w, h, r, world) == tiles.packed_pixels(w, h, r, world)
+            total += tiles.packed_pixels(w, h, r, world)
+        assert total == tiles.n_tiles(w, h) * 64

@@ -1,0 +1,123 @@
+"""Host-side BVH builder (no GPU): structural invariants of the 4-wide tree, and that culling through it
+can never lose the triangle the reference's brute-force scan returns."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenes
+from rbrt_amd import abi
+
+NO_CHILD = -2 ** 31
+
+
+def build(md):
+    lib = abi.load_hip()
+    nodes, tris = C.c_void_p(), C.c_void_p()
+    nn, nt, depth, me = C.c_size_t(), C.c_size_t(), C.c_uint32(), C.c_float()
+    assert lib.rbrt_hip_bvh_build_host(C.byref(md.struct), C.byref(nodes), C.byref(nn), C.byref(tris), C.byref(nt),
+                                       C.byref(depth), C.byref(me)) == 0
+    N = np.ctypeslib.as_array(C.cast(nodes, C.POINTER(C.c_float)), (nn.value, 32)).copy()
+    T = np.ctypeslib.as_array(C.cast(tris, C.POINTER(C.c_float)), (nt.value, 12)).copy()
+    lib.rbrt_hip_free_host(nodes)
+    lib.rbrt_hip_free_host(tris)
+    return N, T, depth.value, me.value
+
+
+def tri_boxes(T):
+    v0, e1, e2 = T[:, 0:3], T[:, 3:6], T[:, 6:9]
+    pts = np.stack([v0, v0 + e1, v0 + e2], 1)
+    return pts.min(1), pts.max(1)
+
+
+@pytest.mark.parametrize("n_tris", [0, 1, 5, 8, 11, 12, 14, 333, 5003])
+def test_bvh4_invariants(oracle, n_tris):
+    if n_tris == 0:
+        md = oracle.mesh_prep(np.zeros((0, 3, 3), np.float32))
+    else:
+        md = scenes.standin_mesh(oracle, n_tris, **scenes.EXAMPLE_MESH)
+    N, T, depth, max_e12 = build(md)
+    child = N[:, 24:28].view(np.int32)
+    n_tested = (md.n_total // 8) * 8
+    want = [i for i in range(n_tested) if not md.is_padding[i]]   # triangle.rs:166-167, :400
+    idx = T[:, 9].view(np.uint32)
+    real = idx != 0xFFFFFFFF
+    assert sorted(idx[real].tolist()) == want                      # every returnable triangle exactly once
+    for i in np.nonzero(real)[0]:                                  # records are bit copies of the SoA streams
+        j = idx[i]
+        assert T[i, 0] == md.arrays["v0x"][j] and T[i, 4] == md.arrays["e1y"][j] and T[i, 8] == md.arrays["e2z"][j]
+    tlo, thi = tri_boxes(T)
+    e12 = np.linalg.norm(T[:, 3:6], axis=1) * np.linalg.norm(T[:, 6:9], axis=1)
+    assert depth <= 20 and len(N) >= 1
+
+    def check(node, d):
+        """returns (lo, hi, e12) of everything below `node`; asserts the stored child boxes contain it"""
+        assert d <= depth
+        lo_all, hi_all, e_all = np.full(3, np.inf), np.full(3, -np.inf), 0.0
+        for k in range(4):
+            c = child[node, k]
+            if c == NO_CHILD:
+                assert np.isnan(N[node, [k, 4 + k, 8 + k, 12 + k, 16 + k, 20 + k]]).all()
+                continue
+            blo = N[node, [k, 4 + k, 8 + k]]
+            bhi = N[node, [12 + k, 16 + k, 20 + k]]
+            if c >= 0:
+                lo, hi, e = check(c, d + 1)
+            else:
+                first, cnt = (~c) >> 2, ((~c) & 3) + 1
+                lo, hi = tlo[first:first + cnt].min(0), thi[first:first + cnt].max(0)
+                e = e12[first:first + cnt].max()
+                assert (np.diff(idx[first:first + cnt].astype(np.int64)) > 0).all()  # ascending index inside a leaf
+            assert (blo <= lo).all() and (bhi >= hi).all()
+            assert N[node, 28 + k] >= e * (1 - 1e-6)
+            lo_all, hi_all, e_all = np.minimum(lo_all, blo), np.maximum(hi_all, bhi), max(e_all, N[node, 28 + k])
+        return lo_all, hi_all, e_all
+
+    check(0, 0)
+
+
+def test_bvh_culling_keeps_the_brute_force_winner(oracle):
+    """CPU walk of the BVH with the kernel's pad formula: the scan's winning triangle (oracle) is always
+    among the triangles of the leaves the walk reaches, for rays from near and far, unit and non-unit."""
+    sc = scenes.example_scene(oracle, 3001)
+    md = sc.meshes[0]
+    N, T, _, _ = build(md)
+    child = N[:, 24:28].view(np.int32)
+    idx = T[:, 9].view(np.uint32)
+    rng = np.random.default_rng(3)
+    c = ((md.bbox_lo + md.bbox_hi) / 2).astype(np.float64)
+    R = float(np.linalg.norm(md.bbox_hi - md.bbox_lo) / 2)
+    n = 1500
+    o = c + rng.normal(size=(n, 3)) * R * rng.choice([1.5, 4.0, 60.0], (n, 1))
+    d = (c + rng.uniform(-1, 1, (n, 3)) * R * 0.9) - o
+    d = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 3.0, (n, 1))
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    only_mesh = abi.SceneData(meshes=[md])
+    t, obj, tri, _ = oracle.trace_rays(only_mesh, rays)
+    assert (obj >= 0).sum() > 300
+    eps, radius = 0.001, np.linalg.norm((md.bbox_hi - md.bbox_lo).astype(np.float64) / 2) * 1.0001
+    for r in np.nonzero(obj >= 0)[0]:
+        oo, dd = rays[r, :3].astype(np.float64), rays[r, 3:].astype(np.float64)
+        pad_base = 64 * 2.0 ** -24 * (np.linalg.norm(oo - c) + radius + np.abs(oo).max())
+        pad_k = pad_base * np.linalg.norm(dd) / eps
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / dd
+        stack, reached = [0], set()
+        while stack:
+            node = stack.pop()
+            if node < 0:
+                first, cnt = (~node) >> 2, ((~node) & 3) + 1
+                reached.update(idx[first:first + cnt].tolist())
+                continue
+            for k in range(4):
+                if child[node, k] == NO_CHILD:
+                    continue
+                pad = pad_base + pad_k * N[node, 28 + k]
+                lo = N[node, [k, 4 + k, 8 + k]].astype(np.float64) - pad
+                hi = N[node, [12 + k, 16 + k, 20 + k]].astype(np.float64) + pad
+                with np.errstate(invalid="ignore"):
+                    t0, t1 = (lo - oo) * inv, (hi - oo) * inv
+                tn, tf = np.fmax.reduce(np.fmin(t0, t1)), np.fmin.reduce(np.fmax(t0, t1))
+                if tn <= tf and tf >= eps and tn <= t[r]:  # pruned with the FINAL best t: the hardest case
+                    stack.append(int(child[node, k]))
+        assert int(tri[r]) in reached, (r, tri[r])

@@ -1,0 +1,69 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo process groups run bench.py's exchange step — every
+rank packs ITS pixel tiles of a known image, one gather to rank 0, rank 0 de-interleaves — and the
+result must equal the image. The per-rank render itself needs a GPU and is covered by
+tests/test_gpu_parity.py::test_tile_sharding_is_partition_invariant."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from rbrt_amd import tiles
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, w, h, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)  # same image on every rank
+    image = rng.random((h, w, 3), dtype=np.float32)
+    sizes = [tiles.packed_pixels(w, h, r, world) * 3 for r in range(world)]
+    maxn = max(sizes)
+    mine = torch.zeros(maxn, dtype=torch.float32)
+    mine[:sizes[rank]] = torch.from_numpy(tiles.pack(image, rank, world).reshape(-1))
+    gathered = [torch.zeros(maxn, dtype=torch.float32) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, gathered, dst=0)          # same call shape as bench.py (equal-size, padded tail)
+    ok = True
+    if rank == 0:
+        parts = [gathered[r][:sizes[r]].numpy().reshape(-1, 3) for r in range(world)]
+        ok = bool(np.array_equal(tiles.unpack(parts, w, h), image))
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)   # bench.py's max-over-ranks timing reduction
+    ok = ok and t.item() == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 100, 60), (2, 1024, 768), (3, 33, 9)])
+def test_gather_and_unpack_over_gloo(world, w, h):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
+def test_pack_unpack_roundtrip_and_partition():
+    rng = np.random.default_rng(1)
+    for (w, h) in ((1, 1), (9, 17), (100, 60), (64, 64)):
+        img = rng.random((h, w, 3), dtype=np.float32)
+        for world in (1, 2, 3, 8):
+            parts = [tiles.pack(img, r, world) for r in range(world)]
+            assert np.array_equal(tiles.unpack(parts, w, h), img)
+            assert sum(len(p) for p in parts) == tiles.n_tiles(w, h) * 64

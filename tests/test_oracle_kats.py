@@ -224,3 +224,14 @@ def test_schlick_numpy(oracle):
         x4 = f32(x2 * x2)
         exp = f32(r0 + f32(f32(f32(1) - r0) * f32(x * x4)))
         assert oracle.lib().rbrt_oracle_kat_schlick(float(cos), float(n)) == exp
+
+
+def test_unit_sphere_rejection_threshold_equivalence():
+    """The kernel tests s > nextafter(1) instead of sqrt(s) > 1 (materials.rs:21): identical for every float."""
+    one = f32(1.0)
+    nxt = np.nextafter(one, f32(2))
+    lo, hi = f32(0.99).view(np.uint32), f32(1.01).view(np.uint32)
+    s = np.arange(lo, hi + 1, dtype=np.uint32).view(np.float32)
+    assert np.array_equal(np.sqrt(s) > one, s > nxt)
+    r = np.random.default_rng(0).uniform(0, 3.1, 2_000_000).astype(np.float32)
+    assert np.array_equal(np.sqrt(r) > one, r > nxt)
