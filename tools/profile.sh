@@ -1,0 +1,24 @@
+#!/bin/bash
+# Profiles the default bench.py workload on the GPU box (run through gpurun from the repo root):
+#   1. rocprofv3 --kernel-trace --stats         -> per-kernel durations
+#   2. separate --pmc passes (counters only, as gpurun requires): SQ activity, then the memory-side
+#      traffic counters (FETCH_SIZE and WRITE_SIZE need a pass each: MI355X_MICROARCH.md "rocprofv3 PMC slots")
+# Output under gpurun_out/profile/; tools/summarize_profile.py turns it into profiles/*.json|csv.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/profile
+rm -rf "$OUT" && mkdir -p "$OUT"
+BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-col-stride 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.err" || exit 1
+run_pmc() { # name counters...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 2 --warmup 0 --cpu-col-stride 0 \
+      > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err" || { echo "pmc pass $name failed"; tail -3 "$OUT/bench_$name.err"; }
+}
+run_pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
+run_pmc sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY
+run_pmc fetch FETCH_SIZE
+run_pmc write WRITE_SIZE
+run_pmc ea_rd TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum
+run_pmc l1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
+echo "profile done"
