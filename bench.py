@@ -111,11 +111,12 @@ def main():
 
     image = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
     if world > 1:
-        sizes = [rbrt_amd.packed_pixels(W, H, r, world) * 3 for r in range(world)]
-        maxn = max(sizes)
-        mine = torch.empty(maxn, dtype=torch.float32, device=dev)  # equal-size gather, tail unused
-        gathered = [torch.empty(maxn, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
-        packed = torch.empty(sum(sizes), dtype=torch.float32, device=dev) if rank == 0 else None
+        slot_pixels = rbrt_amd.packed_pixels(W, H, 0, world)  # rank 0 owns the most tiles: equal-size slots
+        maxn = slot_pixels * 3
+        mine = torch.empty(maxn, dtype=torch.float32, device=dev)  # this rank's tiles (tail of the slot unused)
+        # rank 0 receives straight into one buffer of `world` equal slots; the unpack kernel strides over it
+        slots = torch.empty(world * maxn, dtype=torch.float32, device=dev) if rank == 0 else None
+        gathered = list(slots.chunk(world)) if rank == 0 else None
 
     def step():
         if world == 1:
@@ -132,11 +133,8 @@ def main():
         else:
             dist.gather(mine, gathered, dst=0)  # RCCL over xGMI: every peer sends its tiles straight to rank 0
         if rank == 0:
-            off = 0
-            for r in range(world):  # drop the equal-size padding
-                packed[off:off + sizes[r]].copy_(gathered[r][:sizes[r]])
-                off += sizes[r]
-            rbrt_amd.unpack_tiles(local_rank, packed.data_ptr(), W, H, world, image.data_ptr(), None, stream)
+            rbrt_amd.unpack_tiles(local_rank, slots.data_ptr(), W, H, world, image.data_ptr(), None, stream,
+                                  rank_stride_pixels=slot_pixels)
 
     def fence():
         if world > 1:

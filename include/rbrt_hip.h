@@ -192,6 +192,13 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* scene, const rbrt_camera_t* cam,
 int rbrt_hip_unpack_tiles(int device, void* stream, const float* d_gathered, uint32_t width,
                           uint32_t height, uint32_t tile_world, float* d_radiance, uint8_t* d_rgb8);
 
+/* Same, for gathered buffers laid out in equal-size slots: rank r's tiles start at pixel slot
+ * r * rank_stride_pixels (what a gather of equal-size tensors produces; rank_stride_pixels >=
+ * rbrt_hip_packed_pixels(w, h, 0, world), the largest share). rank_stride_pixels = 0 means tightly packed. */
+int rbrt_hip_unpack_tiles_strided(int device, void* stream, const float* d_gathered, uint32_t width,
+                                  uint32_t height, uint32_t tile_world, size_t rank_stride_pixels,
+                                  float* d_radiance, uint8_t* d_rgb8);
+
 /* Counters of the last render on this scene that had RBRT_FLAG_COLLECT_STATS set. */
 int rbrt_hip_scene_stats(rbrt_hip_scene_t* scene, rbrt_hip_stats_t* out);
 

@@ -96,7 +96,8 @@ class HipScene:
         d.update({f"slots_{n}": int(buf[6 + i]) for i, n in enumerate(names)})
         d.update(trav_wave_steps=int(buf[12]), trav_lane_steps=int(buf[13]), refill_rounds=int(buf[14]),
                  sched_rounds=int(buf[15]), cycles_trav=int(buf[16]), cycles_shade=int(buf[17]),
-                 cycles_total=int(buf[18]))
+                 cycles_total=int(buf[18]), leaf_rounds=int(buf[19]), leaf_lanes=int(buf[20]),
+                 walk_rounds=int(buf[21]), walk_lanes=int(buf[22]))
         return d
 
     def trace_rays(self, rays, min_dist=0.001, max_dist=2000.0):
@@ -117,6 +118,8 @@ def packed_pixels(width: int, height: int, rank: int, world: int) -> int:
 
 
 def unpack_tiles(device: int, d_gathered: int, width: int, height: int, world: int, d_radiance: int | None,
-                 d_rgb8: int | None = None, stream: int | None = None):
-    abi.check(load_hip().rbrt_hip_unpack_tiles(device, C.c_void_p(stream or 0), C.c_void_p(d_gathered), width,
-                                               height, world, C.c_void_p(d_radiance or 0), C.c_void_p(d_rgb8 or 0)))
+                 d_rgb8: int | None = None, stream: int | None = None, rank_stride_pixels: int = 0):
+    """De-interleave gathered per-rank tiles; rank_stride_pixels > 0: equal-size slot per rank."""
+    abi.check(load_hip().rbrt_hip_unpack_tiles_strided(device, C.c_void_p(stream or 0), C.c_void_p(d_gathered), width,
+                                                       height, world, rank_stride_pixels, C.c_void_p(d_radiance or 0),
+                                                       C.c_void_p(d_rgb8 or 0)))

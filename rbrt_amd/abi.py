@@ -121,6 +121,8 @@ HIP_SYMBOLS = {
                                          C.c_void_p, C.c_void_p]),
     "rbrt_hip_unpack_tiles": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p]),
+    "rbrt_hip_unpack_tiles_strided": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_size_t, C.c_void_p, C.c_void_p]),
     "rbrt_hip_scene_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rbrt_hip_trace_rays": (C.c_int, [C.c_void_p, f32p, C.c_size_t, C.c_float, C.c_float, f32p, i32p, i32p, f32p]),
     "rbrt_hip_bvh_build_host": (C.c_int, [C.POINTER(Mesh), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -175,12 +177,13 @@ def load_hip() -> C.CDLL:
     global _hip
     if _hip is not None:
         return _hip
-    if not LIB_HIP.exists():
+    lib_path = Path(os.environ.get("RBRT_HIP_LIB", LIB_HIP))  # override: A/B builds of the same ABI
+    if not lib_path.exists():
         raise FileNotFoundError(
-            f"{LIB_HIP} is missing: build it with `make` (or __graft_entry__.build()). "
+            f"{lib_path} is missing: build it with `make` (or __graft_entry__.build()). "
             "rbrt_amd has no CPU or pure-Python render path.")
     _preload_torch_hip_runtime()
-    lib = C.CDLL(str(LIB_HIP), mode=getattr(os, "RTLD_NOW", 2))
+    lib = C.CDLL(str(lib_path), mode=getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in HIP_SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res

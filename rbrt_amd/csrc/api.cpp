@@ -21,7 +21,7 @@ size_t megakernel_gstack_bytes(uint32_t n_waves);
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
-                         float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
+                         size_t rank_stride_pixels, float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
 hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, float* out_t, int32_t* out_obj,
                              int32_t* out_tri, float* out_dist, hipStream_t stream);
 uint64_t host_splitmix64(uint64_t x);
@@ -84,8 +84,8 @@ struct rbrt_hip_scene {
     uint32_t n_waves = 0;  // persistent megakernel grid: as many single-wave workgroups as fit the LDS
     uint32_t pool = 128;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
     uint32_t stack_entries = kLdsStack;  // per-lane stack entries kept in LDS (RBRT_LDS_STACK)
-    uint32_t y_low_water = 40;    // RBRT_Y_LOW
-    uint32_t leaf_round = 24;     // RBRT_LEAF_ROUND
+    uint32_t y_low_water = 28;    // RBRT_Y_LOW
+    uint32_t leaf_round = 12;     // RBRT_LEAF_ROUND
     // stats / timing
     rbrt_hip_stats_t stats{};
     bool stats_pending = false;
@@ -269,7 +269,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("RBRT_POOL")) {
             int v = std::atoi(e);
-            if (v == 128 || v == 192 || v == 256) s->pool = uint32_t(v);
+            if (v == 96 || v == 128 || v == 160 || v == 192 || v == 256) s->pool = uint32_t(v);
         }
         if (const char* e = std::getenv("RBRT_LDS_STACK")) {
             int v = std::atoi(e);
@@ -477,13 +477,21 @@ int rbrt_hip_scene_stats(rbrt_hip_scene_t* s, rbrt_hip_stats_t* out) {
     return RBRT_OK;
 }
 
-int rbrt_hip_unpack_tiles(int device, void* stream, const float* d_gathered, uint32_t width, uint32_t height,
-                          uint32_t tile_world, float* d_radiance, uint8_t* d_rgb8) {
+int rbrt_hip_unpack_tiles_strided(int device, void* stream, const float* d_gathered, uint32_t width, uint32_t height,
+                                  uint32_t tile_world, size_t rank_stride_pixels, float* d_radiance, uint8_t* d_rgb8) {
     if (!d_gathered) return fail(RBRT_ERR_INVALID_ARG, "unpack: null input");
+    const uint32_t world = tile_world ? tile_world : 1;
+    if (rank_stride_pixels != 0 && rank_stride_pixels < rbrt_hip_packed_pixels(width, height, 0, world))
+        return fail(RBRT_ERR_INVALID_ARG, "unpack: rank stride smaller than rank 0's packed tiles");
     if (int rc = ensure_device(device)) return rc;
-    HIP_TRY(launch_unpack(d_gathered, width, height, tile_world ? tile_world : 1, d_radiance, d_rgb8,
+    HIP_TRY(launch_unpack(d_gathered, width, height, world, rank_stride_pixels, d_radiance, d_rgb8,
                           static_cast<hipStream_t>(stream)));
     return RBRT_OK;
+}
+
+int rbrt_hip_unpack_tiles(int device, void* stream, const float* d_gathered, uint32_t width, uint32_t height,
+                          uint32_t tile_world, float* d_radiance, uint8_t* d_rgb8) {
+    return rbrt_hip_unpack_tiles_strided(device, stream, d_gathered, width, height, tile_world, 0, d_radiance, d_rgb8);
 }
 
 int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const rbrt_render_opts_t* opts,

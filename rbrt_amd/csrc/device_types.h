@@ -14,7 +14,7 @@ constexpr int kMaxPathDepth = 64;    // opts.max_depth limit (reference: 50, lib
 constexpr int kMaxObjects = 255;     // spheres + meshes (object id is stored in one byte per bounce)
 constexpr int kLeafMax = 4;          // triangles per leaf (2-bit count field)
 constexpr int kPoolMax = 256;        // largest path pool per wave the persistent megakernel is built for
-constexpr int kLdsStack = 12;        // per-lane traversal stack entries kept in LDS by the megakernel; deeper
+constexpr int kLdsStack = 8;         // per-lane traversal stack entries kept in LDS by the megakernel; deeper
                                      // entries spill (exactly) to a per-wave global scratch
 
 // One 4-wide BVH node = 128 B = one cache line, fetched as 8 x dwordx4 by ONE lane: the four child boxes
@@ -80,6 +80,7 @@ struct DevCounters {  // mirrors rbrt_hip_stats_t's counters
     // [0..5] passes per status kind, [6..11] lanes used per kind, [12] traversal wave-steps,
     // [13] active lane-steps, [14] refill rounds, [15] census rounds
     // [16] cycles in traversal steps, [17] cycles in shading passes, [18] total cycles (s_memtime, summed over waves)
+    // [19] leaf rounds, [20] lanes with a leaf in those rounds, [21] node-walk rounds, [22] lanes walking in them
     unsigned long long diag[24];
 };
 
@@ -108,7 +109,7 @@ struct TraceParams {
     uint32_t stack_entries;            // per-lane traversal stack entries kept in LDS (<= stack_need)
     uint32_t* gstack;                  // [n_waves][kStackMax][64] overflow of the LDS stacks
     uint32_t y_low_water;              // refill a traversal pass when fewer lanes than this are busy
-    uint32_t leaf_round;               // test deferred leaves once this many lanes hold one
+    uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one
 };
 
 struct ResolveParams {

@@ -515,7 +515,7 @@ __host__ __device__ inline uint32_t local_tiles_of(uint32_t n_tiles, uint32_t ra
 // ranks < r; inside a block tiles are in ascending global tile order).
 __global__ __launch_bounds__(kBlock) void unpack_kernel(const float* __restrict__ gathered, uint32_t width,
                                                         uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
-                                                        uint32_t world, float* out_radiance,
+                                                        uint32_t world, size_t rank_stride_pixels, float* out_radiance,
                                                         uint8_t* out_rgb8) {
     const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
     if (i >= size_t(width) * height) return;
@@ -523,7 +523,11 @@ __global__ __launch_bounds__(kBlock) void unpack_kernel(const float* __restrict_
     const uint32_t tile = (row / RBRT_TILE) * tiles_x + col / RBRT_TILE;
     const uint32_t rank = tile % world, tile_local = tile / world;
     size_t base = 0;
-    for (uint32_t r = 0; r < rank; ++r) base += size_t(local_tiles_of(n_tiles, r, world)) * 64u;
+    if (rank_stride_pixels != 0) {  // equal-size slots per rank (what a gather of equal-size tensors produces)
+        base = size_t(rank) * rank_stride_pixels;
+    } else {                        // tightly packed
+        for (uint32_t r = 0; r < rank; ++r) base += size_t(local_tiles_of(n_tiles, r, world)) * 64u;
+    }
     const size_t src = (base + size_t(tile_local) * 64u + (row % RBRT_TILE) * RBRT_TILE + col % RBRT_TILE) * 3u;
     const float x = gathered[src], y = gathered[src + 1], z = gathered[src + 2];
     if (out_radiance) {
@@ -567,7 +571,8 @@ size_t megakernel_gstack_bytes(uint32_t n_waves) { return size_t(n_waves) * kSta
 
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
     const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw;
-    return (size_t(kFields) * pool + 2u * pool + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
+    const size_t pool_pad = (size_t(pool) + 63u) & ~size_t(63);  // status + list: one byte per (padded) slot each
+    return (size_t(kFields) * pool + pool_pad / 2u + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
 }
 
 // n_waves single-wave workgroups; each loops until the global work counter (zeroed by the caller on
@@ -583,8 +588,12 @@ hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint3
         else                                                                                               \
             hipLaunchKernelGGL((trace_megakernel<POOLN, false>), dim3(n_waves), dim3(64), lds, stream, P); \
     } while (0)
-    if (pool == 128)
+    if (pool == 96)
+        RBRT_LAUNCH_MK(96);
+    else if (pool == 128)
         RBRT_LAUNCH_MK(128);
+    else if (pool == 160)
+        RBRT_LAUNCH_MK(160);
     else if (pool == 192)
         RBRT_LAUNCH_MK(192);
     else if (pool == 256)
@@ -603,12 +612,12 @@ hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream) {
 }
 
 hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
-                         float* out_radiance, uint8_t* out_rgb8, hipStream_t stream) {
+                         size_t rank_stride_pixels, float* out_radiance, uint8_t* out_rgb8, hipStream_t stream) {
     const uint32_t tiles_x = (width + RBRT_TILE - 1) / RBRT_TILE, tiles_y = (height + RBRT_TILE - 1) / RBRT_TILE;
     const size_t n = size_t(width) * height;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(unpack_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, gathered,
-                       width, height, tiles_x, tiles_x * tiles_y, world, out_radiance, out_rgb8);
+                       width, height, tiles_x, tiles_x * tiles_y, world, rank_stride_pixels, out_radiance, out_rgb8);
     return hipGetLastError();
 }
 

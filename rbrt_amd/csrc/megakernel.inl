@@ -18,6 +18,10 @@
 // Which lane works on which path never affects the result: a path owns its RNG stream and its
 // sample slot, and resolve_kernel adds the samples of a pixel in sample order.
 
+#ifndef RBRT_MK_WAVES_PER_SIMD
+#define RBRT_MK_WAVES_PER_SIMD 4  // register budget: 512 / 4 = 128 VGPRs per lane
+#endif
+
 enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_S0, F_S1, F_ITEM, F_META, F_DIST, F_T, F_TRI, F_WORD, kFields };
 enum : uint32_t { ST_EMPTY = 0u, ST_TRAV = 1u, ST_TERM = 2u, ST_LAMB = 3u, ST_METAL = 4u, ST_DIEL = 5u, kNumStatus = 6u,
                   ST_BUSY = 6u /* being traversed by a lane right now */ };
@@ -71,20 +75,22 @@ __device__ __forceinline__ uint32_t classify(const SceneLds& sc, int32_t obj, ui
 }
 
 template <int POOLN, bool STATS>
-__global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
+__global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(const TraceParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr uint32_t kPoolPad = (uint32_t(POOLN) + 63u) & ~63u;  // census loops run in groups of 64 slots
     uint32_t* const pool = lds;
-    uint32_t* const status = pool + kFields * POOLN;
-    uint32_t* const list = status + POOLN;
+    uint8_t* const status = reinterpret_cast<uint8_t*>(pool + kFields * POOLN);  // [kPoolPad] one byte per slot
+    uint8_t* const list = status + kPoolPad;                                     // [kPoolPad] slot ids (< 256)
     const uint32_t lane = threadIdx.x;
-    uint32_t* const stack = list + POOLN + lane;
+    uint32_t* const stack_base = pool + kFields * POOLN + kPoolPad / 2u;         // 2 * kPoolPad bytes of byte arrays
+    uint32_t* const stack = stack_base + lane;
     uint32_t* const gseq = P.gseq + size_t(blockIdx.x) * kPoolMax * kSeqWords;
 #define POOL(f, s) pool[(f) * POOLN + (s)]
 
-    for (uint32_t s = lane; s < uint32_t(POOLN); s += 64) status[s] = ST_EMPTY;
+    for (uint32_t s = lane; s < kPoolPad; s += 64) status[s] = s < uint32_t(POOLN) ? ST_EMPTY : ST_BUSY;  // pad slots never match
     // scene tables behind the stacks
     const uint32_t n_obj = P.n_spheres + P.n_meshes;
-    uint32_t* const sc_base = list + POOLN + P.stack_entries * 64u;
+    uint32_t* const sc_base = stack_base + P.stack_entries * 64u;
     {
         const uint32_t* gs = reinterpret_cast<const uint32_t*>(P.spheres);
         const uint32_t* gm = reinterpret_cast<const uint32_t*>(P.materials);
@@ -108,6 +114,7 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
     uint32_t dg_pass[kNumStatus] = {0, 0, 0, 0, 0, 0}, dg_lanes[kNumStatus] = {0, 0, 0, 0, 0, 0};
     uint32_t dg_steps = 0, dg_lane_steps = 0, dg_refills = 0, dg_census = 0;
     unsigned long long dg_t_trav = 0, dg_t_shade = 0, dg_t0 = 0, dg_tk = 0;
+    uint32_t dg_leaf_rounds = 0, dg_leaf_lanes = 0, dg_walk_rounds = 0, dg_walk_lanes = 0;
     if (STATS) dg_t0 = __builtin_amdgcn_s_memtime();
     bool more_work = true;  // wave-uniform: the global work counter has not run out yet
     const size_t npix = size_t(P.n_local_tiles) * 64u;
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
         // ---- census: how many slots wait for each kind of work ---------------------------------
         uint32_t cnt[kNumStatus] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (uint32_t g = 0; g < uint32_t(POOLN); g += 64) {
+        for (uint32_t g = 0; g < kPoolPad; g += 64) {
             const uint32_t st = status[g + lane];
 #pragma unroll
             for (uint32_t k = 0; k < kNumStatus; ++k) cnt[k] += uint32_t(__popcll(__ballot(st == k)));
@@ -186,10 +193,10 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
         if (cnt[ST_TRAV] != 0 && (n_active < P.y_low_water || n_active + cnt[ST_TRAV] <= 64u)) {
             uint32_t ny = 0;
 #pragma unroll
-            for (uint32_t g = 0; g < uint32_t(POOLN); g += 64) {
+            for (uint32_t g = 0; g < kPoolPad; g += 64) {
                 const bool m = status[g + lane] == ST_TRAV;
                 const uint64_t mask = __ballot(m);
-                if (m) list[ny + lane_rank(mask)] = g + lane;
+                if (m) list[ny + lane_rank(mask)] = uint8_t(g + lane);
                 ny += uint32_t(__popcll(mask));
             }
             __syncthreads();
@@ -261,8 +268,20 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
                     t_cur = t_sp != 0 ? pop() : kNoChild;
                 }
                 const bool can_walk = t_active && t_cur >= 0;
+                // A lane is stalled when it holds a pending leaf and has reached another one (or the end of
+                // its walk): it idles through every node round until the next leaf round. A leaf round is
+                // run when enough lanes are stalled, when most lanes hold a leaf anyway, or when nobody can walk.
                 const uint32_t n_pend = uint32_t(__popcll(__ballot(t_active && t_pend != kNoChild)));
-                if (n_pend != 0 && (n_pend >= P.leaf_round || !__any(can_walk))) {
+                const uint32_t n_stalled = uint32_t(__popcll(__ballot(t_active && !can_walk)));
+                if (STATS && __any(can_walk)) {
+                    ++dg_walk_rounds;
+                    dg_walk_lanes += uint32_t(__popcll(__ballot(can_walk)));
+                }
+                if (n_pend != 0 && (n_stalled >= P.leaf_round || n_pend >= 48u || !__any(can_walk))) {
+                    if (STATS) {
+                        ++dg_leaf_rounds;
+                        dg_leaf_lanes += n_pend;
+                    }
                     if (t_active && t_pend != kNoChild) {
                         leaf_test<STATS>(t_tris, t_pend, t_o, t_d, eps, P.eps_frac, t_best, t_best_idx, lc);
                         t_pend = kNoChild;
@@ -298,19 +317,19 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
         }
         uint32_t c0 = 0, c1 = 0;
 #pragma unroll
-        for (uint32_t g = 0; g < uint32_t(POOLN); g += 64) {
+        for (uint32_t g = 0; g < kPoolPad; g += 64) {
             const bool m = status[g + lane] == kind;
             const uint64_t mask = __ballot(m);
-            if (m) list[c0 + lane_rank(mask)] = g + lane;
+            if (m) list[c0 + lane_rank(mask)] = uint8_t(g + lane);
             c0 += uint32_t(__popcll(mask));
         }
         const uint32_t n_main = c0 < 64u ? c0 : 64u;
         if (kind == ST_TERM && n_gen_slots != 0 && n_main < 64u) {
 #pragma unroll
-            for (uint32_t g = 0; g < uint32_t(POOLN); g += 64) {
+            for (uint32_t g = 0; g < kPoolPad; g += 64) {
                 const bool m = status[g + lane] == ST_EMPTY;
                 const uint64_t mask = __ballot(m);
-                if (m) list[c0 + c1 + lane_rank(mask)] = g + lane;  // c0 + c1 <= POOLN
+                if (m) list[c0 + c1 + lane_rank(mask)] = uint8_t(g + lane);  // c0 + c1 <= POOLN
                 c1 += uint32_t(__popcll(mask));
             }
         }
@@ -539,6 +558,10 @@ __global__ __launch_bounds__(64) void trace_megakernel(const TraceParams P) {
             atomicAdd(&P.counters->diag[16], dg_t_trav);
             atomicAdd(&P.counters->diag[17], dg_t_shade);
             atomicAdd(&P.counters->diag[18], (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
+            atomicAdd(&P.counters->diag[19], (unsigned long long)dg_leaf_rounds);
+            atomicAdd(&P.counters->diag[20], (unsigned long long)dg_leaf_lanes);
+            atomicAdd(&P.counters->diag[21], (unsigned long long)dg_walk_rounds);
+            atomicAdd(&P.counters->diag[22], (unsigned long long)dg_walk_lanes);
         }
     }
 }
