@@ -30,6 +30,7 @@ struct alignas(128) BvhNode4 {
     float max_e12[4];
 };
 static_assert(sizeof(BvhNode4) == 128, "node must be 128 B");
+// the traversal addresses planes by byte offset: lo_x 0, lo_y 16, lo_z 32, hi_x 48, hi_y 64, hi_z 80, child 96, max_e12 112
 
 // One triangle record = 48 B (3 x dwordx4), stored in leaf order. The 9 fp32 values are exactly
 // the 9 SoA streams the reference kernel reads (triangle.rs:177-187); `index` is the triangle's

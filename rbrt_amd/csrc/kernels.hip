@@ -180,6 +180,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct RayCull {
     V3 inv, nod;  // 1/d and -(o/d)
+    // Byte offsets inside a BvhNode4 of the planes the ray ENTERS through, per axis (lo_* where 1/d is
+    // positive, hi_* otherwise); the exit planes are at offset ^ {48, 80, 112}.
+    uint32_t near_x, near_y, near_z;
     float pad_base, pad_k;
 };
 
@@ -193,23 +196,31 @@ __device__ __forceinline__ RayCull make_cull(V3 o, V3 d, const float* center, fl
     rc.pad_k = rc.pad_base * (__builtin_amdgcn_sqrtf(dot(d, d)) * eps_frac);
     rc.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     rc.nod = mk(-(o.x * rc.inv.x), -(o.y * rc.inv.y), -(o.z * rc.inv.z));
+    rc.near_x = (__float_as_uint(rc.inv.x) >> 31) ? 48u : 0u;
+    rc.near_y = (__float_as_uint(rc.inv.y) >> 31) ? 64u : 16u;
+    rc.near_z = (__float_as_uint(rc.inv.z) >> 31) ? 80u : 32u;
     return rc;
 }
 
 constexpr uint32_t kMissKey = 0xFFFFFFFFu;
 
-// One child box of a 4-wide node: slab test of the box grown by pad. Returns the sort key of the
-// child: kMissKey when the ray misses it, else its entry distance (>= 0, two low mantissa bits
-// replaced by the child slot). An unused slot has NaN bounds, every compare fails, it misses.
-__device__ __forceinline__ uint32_t child_key(float lox, float loy, float loz, float hix, float hiy, float hiz,
-                                              float pad, const RayCull& rc, float eps, float best_t, uint32_t slot) {
-    const float t0x = __builtin_fmaf(lox - pad, rc.inv.x, rc.nod.x), t1x = __builtin_fmaf(hix + pad, rc.inv.x, rc.nod.x);
-    const float t0y = __builtin_fmaf(loy - pad, rc.inv.y, rc.nod.y), t1y = __builtin_fmaf(hiy + pad, rc.inv.y, rc.nod.y);
-    const float t0z = __builtin_fmaf(loz - pad, rc.inv.z, rc.nod.z), t1z = __builtin_fmaf(hiz + pad, rc.inv.z, rc.nod.z);
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                                     __builtin_fminf(t0z, t1z));
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
-                                     __builtin_fmaxf(t0z, t1z));
+// One child box of a 4-wide node, given its entry planes (nx, ny, nz) and exit planes (fx, fy, fz) for
+// this ray's direction signs and the signed pad (sp_k = pad with the sign of 1/d_k): growing the box
+// moves entry planes against the ray and exit planes with it; one FMA per plane gives the plane's ray
+// parameter. Returns the sort key of the child: kMissKey when the ray misses it, else its entry
+// distance (>= 0, two low mantissa bits replaced by the child slot). An unused slot has NaN planes:
+// every compare fails, it misses. A zero direction component gives inf/NaN parameters on that axis;
+// fmax/fmin ignore a NaN, so the axis can only make the test MORE permissive, which culling tolerates.
+__device__ __forceinline__ uint32_t child_key(float nx, float ny, float nz, float fx, float fy, float fz, V3 sp,
+                                              const RayCull& rc, float eps, float best_t, uint32_t slot) {
+    const float tnx = __builtin_fmaf(nx - sp.x, rc.inv.x, rc.nod.x);
+    const float tny = __builtin_fmaf(ny - sp.y, rc.inv.y, rc.nod.y);
+    const float tnz = __builtin_fmaf(nz - sp.z, rc.inv.z, rc.nod.z);
+    const float tfx = __builtin_fmaf(fx + sp.x, rc.inv.x, rc.nod.x);
+    const float tfy = __builtin_fmaf(fy + sp.y, rc.inv.y, rc.nod.y);
+    const float tfz = __builtin_fmaf(fz + sp.z, rc.inv.z, rc.nod.z);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+    const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
     const bool hit = (tn <= tf) && (tf >= eps) && (tn <= best_t);
     return hit ? ((__float_as_uint(__builtin_fmaxf(tn, 0.0f)) & ~3u) | slot) : kMissKey;
 }
@@ -221,16 +232,25 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {
 }
 
 // Fetch one 128-B node (8 x dwordx4 by this lane) and test its four children; k[] comes back sorted by
-// entry distance (misses last), c = the four child links.
+// entry distance (misses last), links = the four child links.
 __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull& rc, float eps, float best_t,
                                             uint32_t k[4], f32x4& links) {
-    const auto* np = RBRT_AS1(f32x4, node);
-    const f32x4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5], me = np[7];
-    links = np[6];
-    k[0] = child_key(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, __builtin_fmaf(rc.pad_k, me.x, rc.pad_base), rc, eps, best_t, 0u);
-    k[1] = child_key(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, __builtin_fmaf(rc.pad_k, me.y, rc.pad_base), rc, eps, best_t, 1u);
-    k[2] = child_key(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, __builtin_fmaf(rc.pad_k, me.z, rc.pad_base), rc, eps, best_t, 2u);
-    k[3] = child_key(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, __builtin_fmaf(rc.pad_k, me.w, rc.pad_base), rc, eps, best_t, 3u);
+    const char* nb = reinterpret_cast<const char*>(node);
+    const f32x4 nx = *RBRT_AS1(f32x4, nb + rc.near_x), ny = *RBRT_AS1(f32x4, nb + rc.near_y),
+                nz = *RBRT_AS1(f32x4, nb + rc.near_z);
+    const f32x4 fx = *RBRT_AS1(f32x4, nb + (rc.near_x ^ 48u)), fy = *RBRT_AS1(f32x4, nb + (rc.near_y ^ 80u)),
+                fz = *RBRT_AS1(f32x4, nb + (rc.near_z ^ 112u));
+    const f32x4 me = *RBRT_AS1(f32x4, nb + 112);
+    links = *RBRT_AS1(f32x4, nb + 96);
+    // one pad for the node: the largest of its children's error terms (siblings have similar triangles)
+    const float pad = __builtin_fmaf(rc.pad_k, __builtin_fmaxf(__builtin_fmaxf(me.x, me.y), __builtin_fmaxf(me.z, me.w)),
+                                     rc.pad_base);
+    const V3 sp = mk(__builtin_copysignf(pad, rc.inv.x), __builtin_copysignf(pad, rc.inv.y),
+                     __builtin_copysignf(pad, rc.inv.z));
+    k[0] = child_key(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, sp, rc, eps, best_t, 0u);
+    k[1] = child_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, sp, rc, eps, best_t, 1u);
+    k[2] = child_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, sp, rc, eps, best_t, 2u);
+    k[3] = child_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, sp, rc, eps, best_t, 3u);
     cswap(k[0], k[1]);
     cswap(k[2], k[3]);
     cswap(k[0], k[2]);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     bool t_has_result = false;  // this lane finished a traversal that is not finalised yet
     uint32_t t_slot = 0;
     V3 t_o = mk(0.0f, 0.0f, 0.0f), t_d = t_o;
-    RayCull t_rc = {t_o, t_o, 0.0f, 0.0f};
+    RayCull t_rc = {t_o, t_o, 0u, 16u, 32u, 0.0f, 0.0f};
     float t_best = 0.0f;
     uint32_t t_best_idx = 0, t_mesh = 0;
     const BvhNode4* t_nodes = nullptr;
