@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--cpu-col-stride", type=int, default=16,
                     help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline)")
     ap.add_argument("--check", action="store_true", help="also compare the sampled columns with the GPU image")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="WORLD",
+                    help="single process: time only rank 0's share of a WORLD-GPU run (its tiles, no gather); a "
+                         "scaling estimate for one-GPU boxes, not a benchmark result")
     ap.add_argument("--rehearse-single-gpu", action="store_true",
                     help="N > 1 ranks all on cuda:0 with a gloo gather through host memory: exercises the sharded "
                          "path on a one-GPU box; its numbers mean nothing")
@@ -106,7 +109,8 @@ def main():
     t0 = time.perf_counter()
     scene = rbrt_amd.HipScene(host_scene, device=local_rank)
     setup_s = time.perf_counter() - t0
-    opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=world)
+    emu = args.emulate_rank_of if world == 1 and args.emulate_rank_of > 1 else 0
+    opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=emu if emu else world)
     stream = torch.cuda.current_stream().cuda_stream
 
     image = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
@@ -120,7 +124,7 @@ def main():
 
     def step():
         if world == 1:
-            scene.render_device(cam, opts, image.data_ptr(), None, stream)
+            scene.render_device(cam, opts, image.data_ptr(), None, stream)  # (emulation: packed tiles, fits)
             return
         scene.render_device(cam, opts, mine.data_ptr(), None, stream)
         if args.rehearse_single_gpu:  # gloo cannot gather device tensors: stage through the host
@@ -142,7 +146,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- counting pass (untimed): the work counters behind the algorithmic-bytes figure ----------
-    stats_opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=world,
+    stats_opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=emu if emu else world,
                                   flags=abi.FLAG_COLLECT_STATS)
     n_out = rbrt_amd.packed_pixels(W, H, rank, world) * 3 if world > 1 else W * H * 3
     scratch = torch.empty(n_out, dtype=torch.float32, device=dev)
@@ -176,6 +180,8 @@ def main():
     import hashlib
     image_sha = hashlib.sha256(image.cpu().numpy().tobytes()).hexdigest()[:16]
     samples_per_step = W * H * spp
+    if emu:
+        samples_per_step = rbrt_amd.packed_pixels(W, H, 0, emu) * spp
     value = samples_per_step * args.steps / elapsed / 1e6
     # dominant kernel = trace_kernel; algorithmic bytes of ONE launch on this rank (DESIGN.md "Measurement")
     local_pixels = (rbrt_amd.packed_pixels(W, H, rank, world) if world > 1 else W * H)
@@ -207,6 +213,7 @@ def main():
                                f"{'bunny.obj' if real_asset else 'stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
                    "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,
+                   **({"EMULATION_rank0_share_of_world": emu} if emu else {}),
                    "resolve_kernel_ms": round(resolve_ms / max(1, n_launches), 4)},
         "roofline": roofline,
     }

@@ -97,7 +97,7 @@ class HipScene:
         d.update(trav_wave_steps=int(buf[12]), trav_lane_steps=int(buf[13]), refill_rounds=int(buf[14]),
                  sched_rounds=int(buf[15]), cycles_trav=int(buf[16]), cycles_shade=int(buf[17]),
                  cycles_total=int(buf[18]), leaf_rounds=int(buf[19]), leaf_lanes=int(buf[20]),
-                 walk_rounds=int(buf[21]), walk_lanes=int(buf[22]))
+                 walk_rounds=int(buf[21]), walk_lanes=int(buf[22]), waves_gave_up=int(buf[23]))
         return d
 
     def trace_rays(self, rays, min_dist=0.001, max_dist=2000.0):

@@ -17,6 +17,9 @@ namespace rbrt {
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats,
                                    hipStream_t stream);
 size_t megakernel_gseq_bytes(uint32_t n_waves);
+size_t megakernel_wg_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
+int megakernel_wg_waves();
+hipError_t launch_trace_megakernel_wg(const TraceParams& P, uint32_t n_wg, uint32_t pool, bool stats, hipStream_t stream);
 size_t megakernel_gstack_bytes(uint32_t n_waves);
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
@@ -86,6 +89,9 @@ struct rbrt_hip_scene {
     uint32_t stack_entries = kLdsStack;  // per-lane stack entries kept in LDS (RBRT_LDS_STACK)
     uint32_t y_low_water = 28;    // RBRT_Y_LOW
     uint32_t leaf_round = 12;     // RBRT_LEAF_ROUND
+    uint32_t shade_min = 48;      // RBRT_SHADE_MIN
+    bool use_wg = false;          // RBRT_KERNEL=wg: one pool per 4-wave workgroup
+    uint32_t wg_pool = 448, n_wg = 0;
     // stats / timing
     rbrt_hip_stats_t stats{};
     bool stats_pending = false;
@@ -293,11 +299,31 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             if (v > 0 && v <= 32) per_cu = v;
         }
         s->n_waves = uint32_t(cus * per_cu);
-        std::vector<uint32_t> zeros(megakernel_gseq_bytes(s->n_waves) / sizeof(uint32_t), 0u);
+        if (const char* e = std::getenv("RBRT_KERNEL")) s->use_wg = std::strcmp(e, "wg") == 0;
+        if (const char* e = std::getenv("RBRT_WG_POOL")) {
+            int v = std::atoi(e);
+            if (v == 384 || v == 448 || v == 512 || v == 640) s->wg_pool = uint32_t(v);
+        }
+        if (const char* e = std::getenv("RBRT_SHADE_MIN")) {
+            int v = std::atoi(e);
+            if (v >= 0 && v <= 64) s->shade_min = uint32_t(v);
+        }
+        {
+            int wg_per_cu = int((160u * 1024u) / megakernel_wg_lds_bytes(s->wg_pool, s->stack_entries, s->n_spheres, s->n_meshes));
+            if (wg_per_cu > 16 / megakernel_wg_waves()) wg_per_cu = 16 / megakernel_wg_waves();
+            if (wg_per_cu < 1) wg_per_cu = 1;
+            if (const char* e = std::getenv("RBRT_WG_PER_CU")) {
+                int v = std::atoi(e);
+                if (v > 0 && v <= 8) wg_per_cu = v;
+            }
+            s->n_wg = uint32_t(cus * wg_per_cu);
+        }
+        const uint32_t scratch_waves = uint32_t(cus) * 32u;  // both kernel variants index scratch by wave / workgroup
+        std::vector<uint32_t> zeros(megakernel_gseq_bytes(scratch_waves) / sizeof(uint32_t), 0u);
         if (int rc = upload(s, zeros, &s->d_gseq)) return bail(rc);
         {
             void* gp = nullptr;
-            if (hipMalloc(&gp, megakernel_gstack_bytes(s->n_waves)) != hipSuccess)
+            if (hipMalloc(&gp, megakernel_gstack_bytes(scratch_waves)) != hipSuccess)
                 return bail(fail(RBRT_ERR_OOM, "hipMalloc failed for the stack overflow scratch"));
             s->allocs.push_back(gp);
             s->d_gstack = static_cast<uint32_t*>(gp);
@@ -415,6 +441,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     P.gstack = s->d_gstack;
     P.y_low_water = s->y_low_water;
     P.leaf_round = s->leaf_round;
+    P.shade_min = s->shade_min;
 
     ResolveParams R;
     std::memset(&R, 0, sizeof(R));
@@ -444,7 +471,10 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(unsigned long long), stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));  // after the memset node
-        HIP_TRY(launch_trace_megakernel(P, s->n_waves, s->pool, stats, stream));
+        if (s->use_wg)
+            HIP_TRY(launch_trace_megakernel_wg(P, s->n_wg, s->wg_pool, stats, stream));
+        else
+            HIP_TRY(launch_trace_megakernel(P, s->n_waves, s->pool, stats, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], stream));
         R.batch = nb;
         R.first_batch = b == 0;

@@ -82,6 +82,7 @@ struct DevCounters {  // mirrors rbrt_hip_stats_t's counters
     // [13] active lane-steps, [14] refill rounds, [15] census rounds
     // [16] cycles in traversal steps, [17] cycles in shading passes, [18] total cycles (s_memtime, summed over waves)
     // [19] leaf rounds, [20] lanes with a leaf in those rounds, [21] node-walk rounds, [22] lanes walking in them
+    // [23] waves that gave up on a bounded wait (must stay 0)
     unsigned long long diag[24];
 };
 
@@ -111,6 +112,7 @@ struct TraceParams {
     uint32_t* gstack;                  // [n_waves][kStackMax][64] overflow of the LDS stacks
     uint32_t y_low_water;              // refill a traversal pass when fewer lanes than this are busy
     uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one
+    uint32_t shade_min;                // workgroup-pool kernel: let a shading queue fill to this depth while lanes can traverse
 };
 
 struct ResolveParams {

@@ -466,6 +466,7 @@ __device__ __forceinline__ bool scatter(const DevMaterial& m, V3 in_d, V3 p, V3 
 }
 
 #include "megakernel.inl"
+#include "megakernel_wg.inl"
 
 // lib.rs:116-122: (sqrt(c) * 256) as u8 — Rust's float->int cast saturates and maps NaN to 0.
 __device__ __forceinline__ uint8_t quantise(float c) {
@@ -621,6 +622,41 @@ hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint3
     else
         return hipErrorInvalidValue;
 #undef RBRT_LAUNCH_MK
+    return hipGetLastError();
+}
+
+constexpr int kWgWaves = 4;
+size_t megakernel_wg_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
+    const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw;
+    const size_t qent = (size_t(kNumStatus) * pool + 1u) / 2u;
+    return (size_t(kFields) * pool + 16u + qent + size_t(kWgWaves) * stack_entries * 64u + scene) * sizeof(uint32_t);
+}
+int megakernel_wg_waves() { return kWgWaves; }
+
+// n_wg workgroups of kWgWaves waves, each workgroup with one shared pool of `pool` path slots.
+hipError_t launch_trace_megakernel_wg(const TraceParams& P, uint32_t n_wg, uint32_t pool, bool stats, hipStream_t stream) {
+    if (P.n_items == 0 || n_wg == 0) return hipSuccess;
+    const size_t lds = megakernel_wg_lds_bytes(pool, P.stack_entries, P.n_spheres, P.n_meshes);
+#define RBRT_LAUNCH_WG(POOLN)                                                                                        \
+    do {                                                                                                             \
+        if (stats)                                                                                                   \
+            hipLaunchKernelGGL((trace_megakernel_wg<kWgWaves, POOLN, true>), dim3(n_wg), dim3(64 * kWgWaves), lds,   \
+                               stream, P);                                                                           \
+        else                                                                                                         \
+            hipLaunchKernelGGL((trace_megakernel_wg<kWgWaves, POOLN, false>), dim3(n_wg), dim3(64 * kWgWaves), lds,  \
+                               stream, P);                                                                           \
+    } while (0)
+    if (pool == 384)
+        RBRT_LAUNCH_WG(384);
+    else if (pool == 448)
+        RBRT_LAUNCH_WG(448);
+    else if (pool == 512)
+        RBRT_LAUNCH_WG(512);
+    else if (pool == 640)
+        RBRT_LAUNCH_WG(640);
+    else
+        return hipErrorInvalidValue;
+#undef RBRT_LAUNCH_WG
     return hipGetLastError();
 }
 
