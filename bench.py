@@ -111,6 +111,8 @@ def main():
     setup_s = time.perf_counter() - t0
     emu = args.emulate_rank_of if world == 1 and args.emulate_rank_of > 1 else 0
     opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=emu if emu else world)
+    if os.environ.get("RBRT_BENCH_MAX_DEPTH"):  # diagnosis only (changes the image)
+        opts.max_depth = int(os.environ["RBRT_BENCH_MAX_DEPTH"])
     stream = torch.cuda.current_stream().cuda_stream
 
     image = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None

@@ -89,15 +89,17 @@ class HipScene:
 
     def debug_counters(self) -> dict:
         """Pass statistics of the megakernel from the last counting render (diagnostic)."""
-        buf = (C.c_uint64 * 24)()
-        abi.check(self._lib.rbrt_hip_scene_debug_counters(self._h, buf, 24))
+        buf = (C.c_uint64 * 32)()
+        abi.check(self._lib.rbrt_hip_scene_debug_counters(self._h, buf, 32))
         names = ("empty", "trav", "term", "lamb", "metal", "diel")
         d = {f"passes_{n}": int(buf[i]) for i, n in enumerate(names)}
         d.update({f"slots_{n}": int(buf[6 + i]) for i, n in enumerate(names)})
         d.update(trav_wave_steps=int(buf[12]), trav_lane_steps=int(buf[13]), refill_rounds=int(buf[14]),
                  sched_rounds=int(buf[15]), cycles_trav=int(buf[16]), cycles_shade=int(buf[17]),
                  cycles_total=int(buf[18]), leaf_rounds=int(buf[19]), leaf_lanes=int(buf[20]),
-                 walk_rounds=int(buf[21]), walk_lanes=int(buf[22]), waves_gave_up=int(buf[23]))
+                 walk_rounds=int(buf[21]), walk_lanes=int(buf[22]), waves_gave_up=int(buf[23]),
+                 rt_first_start=int(buf[24]), rt_last_workout=int(buf[25]), rt_last_end=int(buf[26]),
+                 rt_sum_wave_time=int(buf[27]), rt_first_workout=int(buf[28]))
         return d
 
     def trace_rays(self, rays, min_dist=0.001, max_dist=2000.0):

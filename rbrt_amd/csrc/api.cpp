@@ -2,6 +2,7 @@
 // Host C++ only (compiled by hipcc for the HIP runtime headers); no torch, no Python.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -83,6 +84,16 @@ struct rbrt_hip_scene {
     unsigned long long* d_work_counter = nullptr;
     uint32_t* d_gseq = nullptr;
     uint32_t* d_gstack = nullptr;
+    // host copy of what the tile-cost heuristic needs, and the cached tile order
+    std::vector<rbrt_sphere_t> h_spheres;
+    struct HostMesh {
+        float lo[3], hi[3];
+        int32_t kind;
+    };
+    std::vector<HostMesh> h_meshes;
+    uint32_t* d_tile_order = nullptr;
+    size_t tile_order_cap = 0;
+    std::vector<unsigned char> tile_order_key;
     uint32_t stack_need = 1;  // deepest BVH: 3 per level + 1
     uint32_t n_waves = 0;  // persistent megakernel grid: as many single-wave workgroups as fit the LDS
     uint32_t pool = 128;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
@@ -148,6 +159,72 @@ int fill_trace_params(const rbrt_hip_scene* s, const rbrt_camera_t* cam, const r
     P.meshes = s->d_meshes;
     P.counters = s->d_counters;
     return RBRT_OK;
+}
+
+
+// Scheduling heuristic only (never affects the image): order this rank's tiles so that the ones whose
+// paths are expected to be long (they look at glass or metal, or at a mesh) are handed out FIRST. A path
+// is a serial chain of up to 51 bounces (~20 us each when it runs alone), so one long path that starts
+// late keeps the kernel alive for ~1 ms after everything else has finished; started first it overlaps
+// with the bulk of the work. The tiles are then dealt round-robin to the kWorkShards counter shards so
+// that every shard starts with its share of costly tiles.
+std::vector<uint32_t> compute_tile_order(const rbrt_hip_scene* s, const rbrt_camera_t& cam, uint32_t tiles_x,
+                                         uint32_t n_tiles, uint32_t rank, uint32_t world, uint32_t n_local) {
+    struct Scored {
+        uint32_t tile_local;
+        float score;
+    };
+    std::vector<Scored> v(n_local);
+    const double px = cam.position[0], py = cam.position[1], pz = cam.position[2];
+    for (uint32_t tl = 0; tl < n_local; ++tl) {
+        const uint32_t tile = tl * world + rank;
+        const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
+        const double col = tx * RBRT_TILE + 0.5 * RBRT_TILE, row = ty * RBRT_TILE + 0.5 * RBRT_TILE;
+        const double col_mm = (col - double(cam.img_width_pix / 2)) * cam.mm_per_pix_hor;
+        const double row_mm = (row - double(cam.img_height_pix / 2)) * cam.mm_per_pix_vert;
+        double d[3], o[3] = {px, py, pz};
+        for (int c = 0; c < 3; ++c)
+            d[c] = (cam.img_center_point[c] + 0.001 * col_mm * cam.right[c] - 0.001 * row_mm * cam.up[c]) - cam.position[c];
+        float score = 0.0f;
+        for (const auto& m : s->h_meshes) {  // the mesh gate with a margin of one tile
+            double tn = -1e300, tf = 1e300;
+            for (int c = 0; c < 3; ++c) {
+                const double inv = 1.0 / d[c];
+                double t0 = (m.lo[c] - o[c]) * inv, t1 = (m.hi[c] - o[c]) * inv;
+                if (t0 > t1) std::swap(t0, t1);
+                if (t0 == t0 && t0 > tn) tn = t0;
+                if (t1 == t1 && t1 < tf) tf = t1;
+            }
+            if (tf >= 0.0 && tn <= tf * 1.05 + 1e-9)
+                score += m.kind == RBRT_MAT_DIELECTRIC ? 64.0f : (m.kind == RBRT_MAT_METAL ? 8.0f : 4.0f);
+        }
+        for (const auto& sp : s->h_spheres) {
+            const double l[3] = {o[0] - sp.center[0], o[1] - sp.center[1], o[2] - sp.center[2]};
+            const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const double b = 2.0 * (d[0] * l[0] + d[1] * l[1] + d[2] * l[2]);
+            const double r = double(sp.radius) * 1.1;
+            const double c = l[0] * l[0] + l[1] * l[1] + l[2] * l[2] - r * r;
+            if (b * b - 4.0 * a * c >= 0.0 && -b + std::sqrt(b * b - 4.0 * a * c) > 0.0)
+                score += sp.mat.kind == RBRT_MAT_DIELECTRIC ? 16.0f : (sp.mat.kind == RBRT_MAT_METAL ? 6.0f : 1.0f);
+        }
+        v[tl] = Scored{tl, score};
+    }
+    static const bool sort_tiles = [] {
+        const char* e = std::getenv("RBRT_TILE_ORDER");
+        return !(e && e[0] == '0');
+    }();
+    if (!sort_tiles) {
+        std::vector<uint32_t> ident(n_local);
+        for (uint32_t i = 0; i < n_local; ++i) ident[i] = i;
+        return ident;
+    }
+    std::stable_sort(v.begin(), v.end(), [](const Scored& a, const Scored& b) { return a.score > b.score; });
+    std::vector<uint32_t> order;
+    order.reserve(n_local);
+    for (uint32_t k = 0; k < kWorkShards; ++k)
+        for (uint32_t j = k; j < n_local; j += kWorkShards) order.push_back(v[j].tile_local);
+    (void)n_tiles;
+    return order;
 }
 
 }  // namespace
@@ -216,6 +293,13 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         return rc;
     };
 
+    s->h_spheres.assign(scene->spheres, scene->spheres + scene->n_spheres);
+    for (uint32_t i = 0; i < scene->n_meshes; ++i) {
+        rbrt_hip_scene::HostMesh hm;
+        for (int c = 0; c < 3; ++c) hm.lo[c] = scene->meshes[i].bbox_lo[c], hm.hi[c] = scene->meshes[i].bbox_hi[c];
+        hm.kind = scene->meshes[i].mat.kind;
+        s->h_meshes.push_back(hm);
+    }
     std::vector<DevSphere> spheres(scene->n_spheres);
     std::vector<DevMaterial> mats(scene->n_spheres + scene->n_meshes);
     auto put_mat = [&](size_t k, const rbrt_material_t& m) {
@@ -328,7 +412,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             s->allocs.push_back(gp);
             s->d_gstack = static_cast<uint32_t*>(gp);
         }
-        std::vector<unsigned long long> zc(8, 0ull);
+        std::vector<unsigned long long> zc(size_t(kWorkShards) * kWorkCounterStride, 0ull);
         if (int rc = upload(s, zc, &s->d_work_counter)) return bail(rc);
     }
     *out = s;
@@ -341,6 +425,7 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->d_sample_buf) (void)hipFree(s->d_sample_buf);
     if (s->d_acc) (void)hipFree(s->d_acc);
+    if (s->d_tile_order) (void)hipFree(s->d_tile_order);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     delete s;
     return RBRT_OK;
@@ -427,6 +512,11 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     const bool stats = (o->flags & RBRT_FLAG_COLLECT_STATS) != 0;
     if (stats) {
         HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DevCounters), stream));
+        {   // the two atomicMin slots start at all-ones
+            const unsigned long long ones = ~0ull;
+            HIP_TRY(hipMemcpyAsync(&s->d_counters->diag[24], &ones, sizeof(ones), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(&s->d_counters->diag[28], &ones, sizeof(ones), hipMemcpyHostToDevice, stream));
+        }
         s->stats_pending = true;
     }
 
@@ -435,6 +525,30 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     P.tiles_x = tiles_x, P.tiles_y = tiles_y, P.n_tiles = n_tiles;
     P.tile_rank = o->tile_rank, P.tile_world = world, P.n_local_tiles = n_local;
     P.sample_buf = s->d_sample_buf;
+    {   // tile order: recomputed only when the camera / sharding changes
+        std::vector<unsigned char> key(sizeof(rbrt_camera_t) + 2 * sizeof(uint32_t));
+        std::memcpy(key.data(), cam, sizeof(rbrt_camera_t));
+        std::memcpy(key.data() + sizeof(rbrt_camera_t), &o->tile_rank, sizeof(uint32_t));
+        std::memcpy(key.data() + sizeof(rbrt_camera_t) + sizeof(uint32_t), &world, sizeof(uint32_t));
+        if (key != s->tile_order_key || !s->d_tile_order) {
+            const std::vector<uint32_t> order = compute_tile_order(s, *cam, tiles_x, n_tiles, o->tile_rank, world, n_local);
+            if (order.size() > s->tile_order_cap) {
+                if (s->d_tile_order) {
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    HIP_TRY(hipFree(s->d_tile_order));
+                    s->d_tile_order = nullptr;
+                }
+                void* p = nullptr;
+                HIP_TRY(hipMalloc(&p, order.size() * sizeof(uint32_t)));
+                s->d_tile_order = static_cast<uint32_t*>(p);
+                s->tile_order_cap = order.size();
+            }
+            HIP_TRY(hipStreamSynchronize(stream));  // a previous launch may still be reading the old order
+            HIP_TRY(hipMemcpy(s->d_tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            s->tile_order_key = key;
+        }
+        P.tile_order = s->d_tile_order;
+    }
     P.work_counter = s->d_work_counter;
     P.gseq = s->d_gseq;
     P.stack_entries = s->stack_entries;
@@ -469,7 +583,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         P.batch = nb;
         P.n_items = uint64_t(npix) * nb;
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));
-        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(unsigned long long) * kWorkShards * kWorkCounterStride, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));  // after the memset node
         if (s->use_wg)
             HIP_TRY(launch_trace_megakernel_wg(P, s->n_wg, s->wg_pool, stats, stream));
@@ -607,7 +721,7 @@ int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* s, uint64_t* out, size_t n) 
     HIP_TRY(hipDeviceSynchronize());
     DevCounters c;
     HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n && i < 24; ++i) out[i] = c.diag[i];
+    for (size_t i = 0; i < n && i < 32; ++i) out[i] = c.diag[i];
     return RBRT_OK;
 }
 

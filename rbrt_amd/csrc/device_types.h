@@ -14,6 +14,8 @@ constexpr int kMaxPathDepth = 64;    // opts.max_depth limit (reference: 50, lib
 constexpr int kMaxObjects = 255;     // spheres + meshes (object id is stored in one byte per bounce)
 constexpr int kLeafMax = 4;          // triangles per leaf (2-bit count field)
 constexpr int kPoolMax = 256;        // largest path pool per wave the persistent megakernel is built for
+constexpr uint32_t kWorkShards = 8;         // work-item counters (one per XCD)
+constexpr uint32_t kWorkCounterStride = 16;  // in u64: each counter on its own 128-B line
 constexpr int kLdsStack = 8;         // per-lane traversal stack entries kept in LDS by the megakernel; deeper
                                      // entries spill (exactly) to a per-wave global scratch
 
@@ -83,7 +85,8 @@ struct DevCounters {  // mirrors rbrt_hip_stats_t's counters
     // [16] cycles in traversal steps, [17] cycles in shading passes, [18] total cycles (s_memtime, summed over waves)
     // [19] leaf rounds, [20] lanes with a leaf in those rounds, [21] node-walk rounds, [22] lanes walking in them
     // [23] waves that gave up on a bounded wait (must stay 0)
-    unsigned long long diag[24];
+    // [24] min wave start, [25] max time work ran out, [26] max wave end, [27] sum of (end - start) (s_memrealtime, 100 MHz)
+    unsigned long long diag[32];
 };
 
 // Kernel arguments of one trace launch (passed by value).
@@ -103,10 +106,11 @@ struct TraceParams {
     uint32_t sample_base;   // first sample index of this batch
     uint32_t batch;         // samples in this batch
     uint64_t n_items;       // n_local_tiles * 64 * batch
+    const uint32_t* tile_order;  // [n_local_tiles] local tile ids, estimated-costly first (scheduling only)
     float* sample_buf;      // [batch][n_local_tiles*64][3]
     DevCounters* counters;
     // persistent megakernel only
-    unsigned long long* work_counter;  // next unclaimed work item (zeroed before every launch)
+    unsigned long long* work_counter;  // [kWorkShards * kWorkCounterStride] next unclaimed item per shard (zeroed before every launch)
     uint32_t* gseq;                    // [n_waves][kPoolMax][kMaxPathDepth/4] scatter records beyond the 4 kept in LDS
     uint32_t stack_entries;            // per-lane traversal stack entries kept in LDS (<= stack_need)
     uint32_t* gstack;                  // [n_waves][kStackMax][64] overflow of the LDS stacks

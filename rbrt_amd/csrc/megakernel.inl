@@ -74,6 +74,59 @@ __device__ __forceinline__ uint32_t classify(const SceneLds& sc, int32_t obj, ui
     return ST_LAMB + sc.mat[uint32_t(obj) * kMatDw + 4];
 }
 
+// Work items (tile, sample, pixel) are handed out in chunks of 64 from kWorkShards global counters, each
+// covering a contiguous eighth of the item range. A wave starts on the shard of its XCD (blocks that share
+// an L2 then work on neighbouring tiles and the counters do not all sit on one address: a single word
+// saturates near 90 atomics/us, MI355X_MICROARCH.md "dequeue"), and moves on to the next shard when its
+// own is exhausted, so every item is handed out exactly once whatever the placement is. The next chunk is
+// requested one TERM pass ahead, so the atomic's latency is off the critical path.
+constexpr uint32_t kWorkChunk = 64;
+struct WorkSource {
+    uint32_t res_next = 0, res_end = 0;  // wave-uniform: the chunk being handed out (global item numbers)
+    uint32_t shard = 0;                  // wave-uniform: shard to draw from next
+    uint32_t pend_shard = 0;             // wave-uniform: shard of the request in flight
+    uint32_t n_dry = 0;                  // wave-uniform: consecutive shards found exhausted
+    unsigned long long pend_base = 0;    // lane 0: result of the request in flight
+    bool pending = false;                // wave-uniform
+
+    __device__ __forceinline__ void init(const TraceParams& P) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        shard = xcc % kWorkShards;
+    }
+    __device__ __forceinline__ uint32_t shard_lo(const TraceParams& P, uint32_t k) const {
+        if (k >= kWorkShards) return uint32_t(P.n_items);
+        return uint32_t((P.n_items / kWorkChunk) * k / kWorkShards) * kWorkChunk;
+    }
+    __device__ __forceinline__ void prefetch(const TraceParams& P, uint32_t lane) {
+        if (pending) return;
+        if (lane == 0) pend_base = atomicAdd(P.work_counter + shard * kWorkCounterStride, (unsigned long long)kWorkChunk);
+        pend_shard = shard;
+        pending = true;
+    }
+    // Blocks until a chunk is in hand: [lo, hi) global items. Returns false when every shard is exhausted.
+    __device__ __forceinline__ bool next_chunk(const TraceParams& P, uint32_t lane, uint32_t& lo, uint32_t& hi) {
+        for (;;) {
+            prefetch(P, lane);
+            const unsigned long long local = (unsigned long long)__shfl(int(uint32_t(pend_base)), 0) |
+                                             ((unsigned long long)__shfl(int(uint32_t(pend_base >> 32)), 0) << 32);
+            pending = false;
+            const unsigned long long base = shard_lo(P, pend_shard), end = shard_lo(P, pend_shard + 1u);
+            if (base + local < end) {
+                lo = uint32_t(base + local);
+                hi = uint32_t(base + local + kWorkChunk < end ? base + local + kWorkChunk : end);
+                n_dry = 0;
+                return true;
+            }
+            shard = (pend_shard + 1u) % kWorkShards;  // this shard is exhausted: move on
+            if (++n_dry >= kWorkShards) {
+                lo = hi = 0;
+                return false;
+            }
+        }
+    }
+};
+
 template <int POOLN, bool STATS>
 __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(const TraceParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -105,17 +158,19 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     const SceneLds sc = {reinterpret_cast<const float*>(sc_base), sc_base + P.n_spheres * kSphDw,
                          sc_base + P.n_spheres * kSphDw + n_obj * kMatDw};
     // work items are reserved from the global counter in chunks, the next chunk asynchronously
-    constexpr unsigned long long kChunk = 256;
-    unsigned long long res_next = 0, res_end = 0;  // wave-uniform: the chunk being handed out
-    unsigned long long pend_base = 0;              // lane 0: base of the prefetched chunk
-    bool pending = false;                          // wave-uniform: a prefetch is in flight
+    WorkSource work;
+    work.init(P);
     LocalCounters lc = {0, 0, 0, 0, 0};
     uint32_t n_samples_done = 0;
     uint32_t dg_pass[kNumStatus] = {0, 0, 0, 0, 0, 0}, dg_lanes[kNumStatus] = {0, 0, 0, 0, 0, 0};
     uint32_t dg_steps = 0, dg_lane_steps = 0, dg_refills = 0, dg_census = 0;
     unsigned long long dg_t_trav = 0, dg_t_shade = 0, dg_t0 = 0, dg_tk = 0;
     uint32_t dg_leaf_rounds = 0, dg_leaf_lanes = 0, dg_walk_rounds = 0, dg_walk_lanes = 0;
-    if (STATS) dg_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long dg_rt0 = 0, dg_rt_workout = 0;
+    if (STATS) {
+        dg_t0 = __builtin_amdgcn_s_memtime();
+        dg_rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     bool more_work = true;  // wave-uniform: the global work counter has not run out yet
     const size_t npix = size_t(P.n_local_tiles) * 64u;
     const float eps = P.min_dist;
@@ -365,38 +420,33 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         color = mk(reinterpret_cast<const float*>(sc.mat + ob * kMatDw)) * color;
                     }
                 }
-                item = POOL(F_ITEM, slot);
-                const uint32_t pp = item & 63u;
-                const uint32_t ts = item >> 6;
-                const uint32_t s = ts % P.batch, tile_local = ts / P.batch;
-                float* out = P.sample_buf + (size_t(s) * npix + size_t(tile_local) * 64u + pp) * 3u;
+                item = POOL(F_ITEM, slot);  // index of this path's sample in the sample buffer
+                float* out = P.sample_buf + size_t(item) * 3u;
                 out[0] = color.x;
                 out[1] = color.y;
                 out[2] = color.z;
                 if (STATS) ++n_samples_done;
                 need_new = true;
             }
-            // ---- new paths (cam.rs:64-82); work items come from one global counter ----
+            // ---- new paths (cam.rs:64-82); work items come from the sharded global counters ----
             const uint64_t want = __ballot(need_new && more_work);
             if (want) {
                 const uint32_t n_want = uint32_t(__popcll(want));
-                const unsigned long long avail = res_end - res_next;
-                unsigned long long new_base = 0;
-                if (avail < n_want) {  // take the prefetched chunk (or fetch one now, at the very start)
-                    if (!pending && lane == 0) pend_base = atomicAdd(P.work_counter, kChunk);
-                    new_base = (unsigned long long)__shfl(uint32_t(pend_base), 0) |
-                               ((unsigned long long)__shfl(uint32_t(pend_base >> 32), 0) << 32);
-                    pending = false;
+                const uint32_t avail = work.res_end - work.res_next;
+                uint32_t new_lo = 0, new_hi = 0;
+                if (avail < n_want) {
+                    more_work = work.next_chunk(P, lane, new_lo, new_hi);
+                    if (STATS && !more_work) dg_rt_workout = __builtin_amdgcn_s_memrealtime();
                 }
-                bool ran_out = false;
                 if (need_new) {
                     const uint32_t rk = lane_rank(want);
-                    const unsigned long long it = rk < avail ? res_next + rk : new_base + (rk - avail);
-                    if (it < P.n_items) {
-                        item = uint32_t(it);
-                        const uint32_t pp = item & 63u;
-                        const uint32_t ts = item >> 6;
-                        const uint32_t s = ts % P.batch, tile_local = ts / P.batch;
+                    const uint32_t it = rk < avail ? work.res_next + rk : new_lo + (rk - avail);
+                    if (rk < avail || it < new_hi) {
+                        const uint32_t pp = it & 63u;
+                        const uint32_t ts = it >> 6;
+                        const uint32_t s = ts % P.batch;
+                        const uint32_t tile_local = P.tile_order[ts / P.batch];  // costly tiles are handed out first
+                        item = s * uint32_t(npix) + tile_local * 64u + pp;       // < 2^32: the host sizes batches so
                         const uint32_t tile = tile_local * P.tile_world + P.tile_rank;
                         const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
                         const uint32_t row = ty * RBRT_TILE + (pp >> 3), col = tx * RBRT_TILE + (pp & 7u);
@@ -418,22 +468,16 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                             word = 0;
                             have_ray = true;
                         }
-                    } else {
-                        ran_out = true;
                     }
                 }
                 if (avail < n_want) {
-                    res_next = new_base + (n_want - avail);
-                    res_end = new_base + kChunk;
+                    work.res_next = new_lo + (n_want - avail) < new_hi ? new_lo + (n_want - avail) : new_hi;
+                    work.res_end = new_hi;
                 } else {
-                    res_next += n_want;
+                    work.res_next += n_want;
                 }
-                if (__any(ran_out)) more_work = false;
                 // reserve the next chunk now; its result is not needed before a later TERM pass
-                if (more_work && !pending && res_end - res_next < 64u) {
-                    if (lane == 0) pend_base = atomicAdd(P.work_counter, kChunk);
-                    pending = true;
-                }
+                if (more_work && work.res_end - work.res_next < 64u) work.prefetch(P, lane);
             }
         } else if (is_main) {
             // ---- RayScattering::scatter for one material kind (wave-uniform branch) ----
@@ -562,6 +606,12 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             atomicAdd(&P.counters->diag[20], (unsigned long long)dg_leaf_lanes);
             atomicAdd(&P.counters->diag[21], (unsigned long long)dg_walk_rounds);
             atomicAdd(&P.counters->diag[22], (unsigned long long)dg_walk_lanes);
+            const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+            atomicMin(&P.counters->diag[24], dg_rt0);
+            atomicMax(&P.counters->diag[25], dg_rt_workout);
+            atomicMax(&P.counters->diag[26], rt1);
+            atomicAdd(&P.counters->diag[27], rt1 - dg_rt0);
+            atomicMin(&P.counters->diag[28], dg_rt_workout ? dg_rt_workout : rt1);
         }
     }
 }

@@ -113,10 +113,8 @@ __global__ __launch_bounds__(64 * WAVES, RBRT_MK_WAVES_PER_SIMD) void trace_mega
         return n;
     };
 
-    constexpr unsigned long long kChunk = 256;
-    unsigned long long res_next = 0, res_end = 0;  // wave-uniform: the chunk of work items being handed out
-    unsigned long long pend_base = 0;              // lane 0: base of the prefetched chunk
-    bool pending = false;                          // wave-uniform: a prefetch is in flight
+    WorkSource work;
+    work.init(P);
     LocalCounters lc = {0, 0, 0, 0, 0};
     uint32_t n_samples_done = 0;
     uint32_t dg_pass[kNumStatus] = {0, 0, 0, 0, 0, 0}, dg_lanes[kNumStatus] = {0, 0, 0, 0, 0, 0};
@@ -357,38 +355,30 @@ __global__ __launch_bounds__(64 * WAVES, RBRT_MK_WAVES_PER_SIMD) void trace_mega
                         color = mk(reinterpret_cast<const float*>(sc.mat + ob * kMatDw)) * color;
                     }
                 }
-                item = WPOOL(F_ITEM, slot);
-                const uint32_t pp = item & 63u;
-                const uint32_t ts = item >> 6;
-                const uint32_t s = ts % P.batch, tile_local = ts / P.batch;
-                float* out = P.sample_buf + (size_t(s) * npix + size_t(tile_local) * 64u + pp) * 3u;
+                item = WPOOL(F_ITEM, slot);  // index of this path's sample in the sample buffer
+                float* out = P.sample_buf + size_t(item) * 3u;
                 out[0] = color.x;
                 out[1] = color.y;
                 out[2] = color.z;
                 if (STATS) ++n_samples_done;
                 need_new = true;
             }
-            // ---- new paths (cam.rs:64-82); work items come from one global counter ----
+            // ---- new paths (cam.rs:64-82); work items come from the sharded global counters ----
             const uint64_t want = __ballot(need_new && more_work);
             if (want) {
                 const uint32_t n_want = uint32_t(__popcll(want));
-                const unsigned long long avail = res_end - res_next;
-                unsigned long long new_base = 0;
-                if (avail < n_want) {  // take the prefetched chunk (or fetch one now, at the very start)
-                    if (!pending && lane == 0) pend_base = atomicAdd(P.work_counter, kChunk);
-                    new_base = (unsigned long long)__shfl(uint32_t(pend_base), 0) |
-                               ((unsigned long long)__shfl(uint32_t(pend_base >> 32), 0) << 32);
-                    pending = false;
-                }
-                bool ran_out = false;
+                const uint32_t avail = work.res_end - work.res_next;
+                uint32_t new_lo = 0, new_hi = 0;
+                if (avail < n_want) more_work = work.next_chunk(P, lane, new_lo, new_hi);
                 if (need_new) {
                     const uint32_t rk = lane_rank(want);
-                    const unsigned long long it = rk < avail ? res_next + rk : new_base + (rk - avail);
-                    if (it < P.n_items) {
-                        item = uint32_t(it);
-                        const uint32_t pp = item & 63u;
-                        const uint32_t ts = item >> 6;
-                        const uint32_t s = ts % P.batch, tile_local = ts / P.batch;
+                    const uint32_t it = rk < avail ? work.res_next + rk : new_lo + (rk - avail);
+                    if (rk < avail || it < new_hi) {
+                        const uint32_t pp = it & 63u;
+                        const uint32_t ts = it >> 6;
+                        const uint32_t s = ts % P.batch;
+                        const uint32_t tile_local = P.tile_order[ts / P.batch];  // costly tiles are handed out first
+                        item = s * uint32_t(npix) + tile_local * 64u + pp;       // < 2^32: the host sizes batches so
                         const uint32_t tile = tile_local * P.tile_world + P.tile_rank;
                         const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
                         const uint32_t row = ty * RBRT_TILE + (pp >> 3), col = tx * RBRT_TILE + (pp & 7u);
@@ -410,22 +400,16 @@ __global__ __launch_bounds__(64 * WAVES, RBRT_MK_WAVES_PER_SIMD) void trace_mega
                             word = 0;
                             have_ray = true;
                         }
-                    } else {
-                        ran_out = true;
                     }
                 }
                 if (avail < n_want) {
-                    res_next = new_base + (n_want - avail);
-                    res_end = new_base + kChunk;
+                    work.res_next = new_lo + (n_want - avail) < new_hi ? new_lo + (n_want - avail) : new_hi;
+                    work.res_end = new_hi;
                 } else {
-                    res_next += n_want;
+                    work.res_next += n_want;
                 }
-                if (__any(ran_out)) more_work = false;
                 // reserve the next chunk now; its result is not needed before a later TERM pass
-                if (more_work && !pending && res_end - res_next < 64u) {
-                    if (lane == 0) pend_base = atomicAdd(P.work_counter, kChunk);
-                    pending = true;
-                }
+                if (more_work && work.res_end - work.res_next < 64u) work.prefetch(P, lane);
             }
         } else if (is_main) {
             // ---- RayScattering::scatter for one material kind (wave-uniform branch) ----
