@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--spp", type=int, default=50)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--vary-seed", type=int, default=0, help="1: every step renders a new frame (seed + step number)")
     ap.add_argument("--triangles", type=int, default=69451)
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
     ap.add_argument("--cpu-col-stride", type=int, default=16,
@@ -124,7 +125,12 @@ def main():
         slots = torch.empty(world * maxn, dtype=torch.float32, device=dev) if rank == 0 else None
         gathered = list(slots.chunk(world)) if rank == 0 else None
 
+    step_no = [0]
+
     def step():
+        if args.vary_seed:
+            step_no[0] += 1
+            opts.seed = args.seed + step_no[0]
         if world == 1:
             scene.render_device(cam, opts, image.data_ptr(), None, stream)  # (emulation: packed tiles, fits)
             return

@@ -89,8 +89,8 @@ class HipScene:
 
     def debug_counters(self) -> dict:
         """Pass statistics of the megakernel from the last counting render (diagnostic)."""
-        buf = (C.c_uint64 * 32)()
-        abi.check(self._lib.rbrt_hip_scene_debug_counters(self._h, buf, 32))
+        buf = (C.c_uint64 * 64)()
+        abi.check(self._lib.rbrt_hip_scene_debug_counters(self._h, buf, 64))
         names = ("empty", "trav", "term", "lamb", "metal", "diel")
         d = {f"passes_{n}": int(buf[i]) for i, n in enumerate(names)}
         d.update({f"slots_{n}": int(buf[6 + i]) for i, n in enumerate(names)})
@@ -99,7 +99,15 @@ class HipScene:
                  cycles_total=int(buf[18]), leaf_rounds=int(buf[19]), leaf_lanes=int(buf[20]),
                  walk_rounds=int(buf[21]), walk_lanes=int(buf[22]), waves_gave_up=int(buf[23]),
                  rt_first_start=int(buf[24]), rt_last_workout=int(buf[25]), rt_last_end=int(buf[26]),
-                 rt_sum_wave_time=int(buf[27]), rt_first_workout=int(buf[28]))
+                 rt_sum_wave_time=int(buf[27]), rt_first_workout=int(buf[28]),
+                 path_len_hist=[int(buf[32 + i]) for i in range(8)],     # bounces 0, 1, 2-3, 4-7, ... 64+
+                 long_path_objects=[int(buf[40 + i]) for i in range(8)], # bounces of paths >= 16, per object id
+                 long_path_total=int(buf[48]), long_path_dielectric=int(buf[47]), shade_extra_rounds=int(buf[29]),
+                 drain_slowest=dict(us=int(buf[50]) >> 44, rounds=(int(buf[50]) >> 32) & 0xFFF,
+                                    trav_steps=(int(buf[50]) >> 16) & 0xFFFF, passes=int(buf[50]) & 0xFFFF),
+                 queue_given=int(buf[55]), queue_taken=int(buf[56]),
+                 drain_sum=dict(rounds=int(buf[51]), trav_steps=int(buf[52]), passes=int(buf[53]),
+                                lane_steps=int(buf[54])))
         return d
 
     def trace_rays(self, rays, min_dist=0.001, max_dist=2000.0):

@@ -84,6 +84,11 @@ struct rbrt_hip_scene {
     unsigned long long* d_work_counter = nullptr;
     uint32_t* d_gseq = nullptr;
     uint32_t* d_gstack = nullptr;
+    uint32_t* d_q_entries = nullptr;  // hand-over queue of the drain phase
+    uint32_t* d_q_seq = nullptr;
+    uint32_t q_epoch = 0;
+    uint32_t collect_every = 8;       // RBRT_COLLECT_EVERY (0 = off)
+    bool poison_samples = false;      // RBRT_POISON_SAMPLES
     // host copy of what the tile-cost heuristic needs, and the cached tile order
     std::vector<rbrt_sphere_t> h_spheres;
     struct HostMesh {
@@ -92,8 +97,10 @@ struct rbrt_hip_scene {
     };
     std::vector<HostMesh> h_meshes;
     uint32_t* d_tile_order = nullptr;
+    uint32_t* d_tile_cost = nullptr;  // rays of each tile's long paths, summed over the frames so far
     size_t tile_order_cap = 0;
     std::vector<unsigned char> tile_order_key;
+    uint32_t cost_frames = 0;         // frames that have fed d_tile_cost under the current key
     uint32_t stack_need = 1;  // deepest BVH: 3 per level + 1
     uint32_t n_waves = 0;  // persistent megakernel grid: as many single-wave workgroups as fit the LDS
     uint32_t pool = 128;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
@@ -101,6 +108,8 @@ struct rbrt_hip_scene {
     uint32_t y_low_water = 28;    // RBRT_Y_LOW
     uint32_t leaf_round = 12;     // RBRT_LEAF_ROUND
     uint32_t shade_min = 48;      // RBRT_SHADE_MIN
+    uint32_t shade_rounds = 4;    // RBRT_SHADE_ROUNDS
+    uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
     bool use_wg = false;          // RBRT_KERNEL=wg: one pool per 4-wave workgroup
     uint32_t wg_pool = 448, n_wg = 0;
     // stats / timing
@@ -169,10 +178,12 @@ int fill_trace_params(const rbrt_hip_scene* s, const rbrt_camera_t* cam, const r
 // with the bulk of the work. The tiles are then dealt round-robin to the kWorkShards counter shards so
 // that every shard starts with its share of costly tiles.
 std::vector<uint32_t> compute_tile_order(const rbrt_hip_scene* s, const rbrt_camera_t& cam, uint32_t tiles_x,
-                                         uint32_t n_tiles, uint32_t rank, uint32_t world, uint32_t n_local) {
+                                         uint32_t n_tiles, uint32_t rank, uint32_t world, uint32_t n_local,
+                                         const uint32_t* measured) {
     struct Scored {
         uint32_t tile_local;
         float score;
+        uint32_t measured;
     };
     std::vector<Scored> v(n_local);
     const double px = cam.position[0], py = cam.position[1], pz = cam.position[2];
@@ -207,7 +218,7 @@ std::vector<uint32_t> compute_tile_order(const rbrt_hip_scene* s, const rbrt_cam
             if (b * b - 4.0 * a * c >= 0.0 && -b + std::sqrt(b * b - 4.0 * a * c) > 0.0)
                 score += sp.mat.kind == RBRT_MAT_DIELECTRIC ? 16.0f : (sp.mat.kind == RBRT_MAT_METAL ? 6.0f : 1.0f);
         }
-        v[tl] = Scored{tl, score};
+        v[tl] = Scored{tl, score, measured ? measured[tl] : 0u};
     }
     static const bool sort_tiles = [] {
         const char* e = std::getenv("RBRT_TILE_ORDER");
@@ -218,7 +229,25 @@ std::vector<uint32_t> compute_tile_order(const rbrt_hip_scene* s, const rbrt_cam
         for (uint32_t i = 0; i < n_local; ++i) ident[i] = i;
         return ident;
     }
-    std::stable_sort(v.begin(), v.end(), [](const Scored& a, const Scored& b) { return a.score > b.score; });
+    // measured long-path work of earlier frames first (when there is any), the geometric guess as tie-break
+    const auto costlier = [](const Scored& a, const Scored& b) {
+        return a.measured != b.measured ? a.measured > b.measured : a.score > b.score;
+    };
+    static const bool bands = [] {
+        const char* e = std::getenv("RBRT_TILE_DEAL");
+        return e && e[0] == 'b';
+    }();
+    if (bands) {  // every shard keeps its contiguous band of the image (L2 locality) and orders it costly-first
+        std::vector<uint32_t> order;
+        order.reserve(n_local);
+        for (uint32_t k = 0; k < kWorkShards; ++k) {
+            const auto b = v.begin() + size_t(n_local) * k / kWorkShards, e = v.begin() + size_t(n_local) * (k + 1) / kWorkShards;
+            std::stable_sort(b, e, costlier);
+            for (auto it = b; it != e; ++it) order.push_back(it->tile_local);
+        }
+        return order;
+    }
+    std::stable_sort(v.begin(), v.end(), costlier);
     std::vector<uint32_t> order;
     order.reserve(n_local);
     for (uint32_t k = 0; k < kWorkShards; ++k)
@@ -392,6 +421,14 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             int v = std::atoi(e);
             if (v >= 0 && v <= 64) s->shade_min = uint32_t(v);
         }
+        if (const char* e = std::getenv("RBRT_SHADE_ROUNDS")) {
+            int v = std::atoi(e);
+            if (v >= 1 && v <= int(kMaxShadeRounds)) s->shade_rounds = uint32_t(v);
+        }
+        if (const char* e = std::getenv("RBRT_SHADE_CONT_MIN")) {
+            int v = std::atoi(e);
+            if (v >= 1 && v <= 64) s->shade_cont_min = uint32_t(v);
+        }
         {
             int wg_per_cu = int((160u * 1024u) / megakernel_wg_lds_bytes(s->wg_pool, s->stack_entries, s->n_spheres, s->n_meshes));
             if (wg_per_cu > 16 / megakernel_wg_waves()) wg_per_cu = 16 / megakernel_wg_waves();
@@ -412,8 +449,28 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             s->allocs.push_back(gp);
             s->d_gstack = static_cast<uint32_t*>(gp);
         }
-        std::vector<unsigned long long> zc(size_t(kWorkShards) * kWorkCounterStride, 0ull);
+        // work counters, then the three counters of the hand-over queue (zeroed together before every launch)
+        std::vector<unsigned long long> zc(size_t(kWorkShards) * kWorkCounterStride + 3u * kQueueCtrStride / 2u, 0ull);
         if (int rc = upload(s, zc, &s->d_work_counter)) return bail(rc);
+        if (const char* e = std::getenv("RBRT_POISON_SAMPLES")) s->poison_samples = e[0] == '1';
+        if (const char* e = std::getenv("RBRT_COLLECT_EVERY")) {
+            int v = std::atoi(e);
+            if (v >= 0 && v <= 512) s->collect_every = uint32_t(v);
+        }
+        {   // every path is handed over at most once, so n_waves * pool entries are enough
+            const size_t n_entries = size_t(s->n_waves) * s->pool;
+            void* qp = nullptr;
+            if (hipMalloc(&qp, n_entries * kQueueEntryDw * sizeof(uint32_t)) != hipSuccess)
+                return bail(fail(RBRT_ERR_OOM, "hipMalloc failed for the hand-over queue"));
+            s->allocs.push_back(qp);
+            s->d_q_entries = static_cast<uint32_t*>(qp);
+            if (hipMemset(qp, 0, n_entries * kQueueEntryDw * sizeof(uint32_t)) != hipSuccess)  // ready flags
+                return bail(fail(RBRT_ERR_HIP, "hipMemset failed for the hand-over queue"));
+            if (hipMalloc(&qp, n_entries * (kMaxPathDepth / 4) * sizeof(uint32_t)) != hipSuccess)
+                return bail(fail(RBRT_ERR_OOM, "hipMalloc failed for the hand-over queue records"));
+            s->allocs.push_back(qp);
+            s->d_q_seq = static_cast<uint32_t*>(qp);
+        }
     }
     *out = s;
     return RBRT_OK;
@@ -426,6 +483,7 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     if (s->d_sample_buf) (void)hipFree(s->d_sample_buf);
     if (s->d_acc) (void)hipFree(s->d_acc);
     if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+    if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     delete s;
     return RBRT_OK;
@@ -530,32 +588,64 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         std::memcpy(key.data(), cam, sizeof(rbrt_camera_t));
         std::memcpy(key.data() + sizeof(rbrt_camera_t), &o->tile_rank, sizeof(uint32_t));
         std::memcpy(key.data() + sizeof(rbrt_camera_t) + sizeof(uint32_t), &world, sizeof(uint32_t));
-        if (key != s->tile_order_key || !s->d_tile_order) {
-            const std::vector<uint32_t> order = compute_tile_order(s, *cam, tiles_x, n_tiles, o->tile_rank, world, n_local);
-            if (order.size() > s->tile_order_cap) {
-                if (s->d_tile_order) {
-                    HIP_TRY(hipStreamSynchronize(stream));
-                    HIP_TRY(hipFree(s->d_tile_order));
-                    s->d_tile_order = nullptr;
-                }
+        static const bool feedback = [] {
+            const char* e = std::getenv("RBRT_TILE_FEEDBACK");
+            return !(e && e[0] == '0');
+        }();
+        const bool rekey = key != s->tile_order_key || !s->d_tile_order;
+        // Feedback: the kernel sums the rays of each tile's long paths into d_tile_cost; after 1, 2, 4, ...
+        // 64 frames under the same camera and sharding the order is rebuilt from those sums.
+        const bool refresh = !rekey && feedback && s->cost_frames >= 1 && s->cost_frames <= 64 &&
+                             (s->cost_frames & (s->cost_frames - 1)) == 0;
+        if (rekey || refresh) {
+            if (n_local > s->tile_order_cap) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (s->d_tile_order) HIP_TRY(hipFree(s->d_tile_order));
+                if (s->d_tile_cost) HIP_TRY(hipFree(s->d_tile_cost));
+                s->d_tile_order = s->d_tile_cost = nullptr;
                 void* p = nullptr;
-                HIP_TRY(hipMalloc(&p, order.size() * sizeof(uint32_t)));
+                HIP_TRY(hipMalloc(&p, size_t(n_local) * sizeof(uint32_t)));
                 s->d_tile_order = static_cast<uint32_t*>(p);
-                s->tile_order_cap = order.size();
+                HIP_TRY(hipMalloc(&p, size_t(n_local) * sizeof(uint32_t)));
+                s->d_tile_cost = static_cast<uint32_t*>(p);
+                s->tile_order_cap = n_local;
             }
-            HIP_TRY(hipStreamSynchronize(stream));  // a previous launch may still be reading the old order
+            HIP_TRY(hipStreamSynchronize(stream));  // a previous launch may still be using both arrays
+            std::vector<uint32_t> measured;
+            if (refresh) {
+                measured.resize(n_local);
+                HIP_TRY(hipMemcpy(measured.data(), s->d_tile_cost, size_t(n_local) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            } else {
+                HIP_TRY(hipMemset(s->d_tile_cost, 0, size_t(n_local) * sizeof(uint32_t)));
+                s->cost_frames = 0;
+            }
+            const std::vector<uint32_t> order = compute_tile_order(s, *cam, tiles_x, n_tiles, o->tile_rank, world, n_local,
+                                                                   refresh ? measured.data() : nullptr);
             HIP_TRY(hipMemcpy(s->d_tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             s->tile_order_key = key;
         }
+        P.tile_cost = feedback && s->cost_frames < 64 ? s->d_tile_cost : nullptr;
+        P.cost_min_bounces = 8;
+        if (P.tile_cost) ++s->cost_frames;
         P.tile_order = s->d_tile_order;
     }
     P.work_counter = s->d_work_counter;
     P.gseq = s->d_gseq;
     P.stack_entries = s->stack_entries;
     P.gstack = s->d_gstack;
+    P.q_entries = s->d_q_entries;
+    P.q_seq = s->d_q_seq;
+    P.q_ctr = reinterpret_cast<uint32_t*>(s->d_work_counter + size_t(kWorkShards) * kWorkCounterStride);
+    P.collect_every = s->collect_every;
+    P.q_capacity = uint32_t(size_t(s->n_waves) * s->pool);
+    P.n_donors = 0;
+    if (s->collect_every != 0)
+        for (uint32_t b = 0; b < s->n_waves; ++b) P.n_donors += ((b >> 3) % s->collect_every) != 0 ? 1u : 0u;
     P.y_low_water = s->y_low_water;
     P.leaf_round = s->leaf_round;
     P.shade_min = s->shade_min;
+    P.shade_rounds = s->shade_rounds;
+    P.shade_cont_min = s->shade_cont_min;
 
     ResolveParams R;
     std::memset(&R, 0, sizeof(R));
@@ -583,7 +673,12 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         P.batch = nb;
         P.n_items = uint64_t(npix) * nb;
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));
-        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(unsigned long long) * kWorkShards * kWorkCounterStride, stream));
+        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0,
+                               sizeof(unsigned long long) * (size_t(kWorkShards) * kWorkCounterStride + 3u * kQueueCtrStride / 2u), stream));
+        if (++s->q_epoch == 0) s->q_epoch = 1;  // ready flags of earlier launches never match
+        // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
+        if (s->poison_samples) HIP_TRY(hipMemsetAsync(s->d_sample_buf, 0xFF, s->sample_buf_bytes, stream));
+        P.q_epoch = s->q_epoch;
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));  // after the memset node
         if (s->use_wg)
             HIP_TRY(launch_trace_megakernel_wg(P, s->n_wg, s->wg_pool, stats, stream));
@@ -618,6 +713,8 @@ int rbrt_hip_scene_stats(rbrt_hip_scene_t* s, rbrt_hip_stats_t* out) {
     s->stats.node_bytes = sizeof(BvhNode4);
     s->stats.tri_bytes = sizeof(BvhTri);
     *out = s->stats;
+    if (c.diag[23] || c.diag[57])
+        return fail(RBRT_ERR_HIP, "the trace kernel detected corrupt internal state (hand-over queue / path slot)");
     return RBRT_OK;
 }
 
@@ -708,6 +805,8 @@ int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const r
     TRY_OR_CLEAN(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     cleanup();
 #undef TRY_OR_CLEAN
+    if (c.diag[23] || c.diag[57])
+        return fail(RBRT_ERR_HIP, "the trace kernel detected corrupt internal state (hand-over queue / path slot)");
     if (c.nan_discriminants)
         return fail(RBRT_ERR_NAN, "a sphere discriminant was NaN (the reference panics: sphere.rs:33); "
                                   "those rays were treated as misses");
@@ -721,7 +820,7 @@ int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* s, uint64_t* out, size_t n) 
     HIP_TRY(hipDeviceSynchronize());
     DevCounters c;
     HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n && i < 32; ++i) out[i] = c.diag[i];
+    for (size_t i = 0; i < n && i < 64; ++i) out[i] = c.diag[i];
     return RBRT_OK;
 }
 

@@ -164,14 +164,30 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     uint32_t n_samples_done = 0;
     uint32_t dg_pass[kNumStatus] = {0, 0, 0, 0, 0, 0}, dg_lanes[kNumStatus] = {0, 0, 0, 0, 0, 0};
     uint32_t dg_steps = 0, dg_lane_steps = 0, dg_refills = 0, dg_census = 0;
+    uint32_t dg_dr_rounds = 0, dg_dr_steps = 0, dg_dr_passes = 0, dg_dr_lane_steps = 0;  // after the work ran out
     unsigned long long dg_t_trav = 0, dg_t_shade = 0, dg_t0 = 0, dg_tk = 0;
-    uint32_t dg_leaf_rounds = 0, dg_leaf_lanes = 0, dg_walk_rounds = 0, dg_walk_lanes = 0;
+    uint32_t dg_leaf_rounds = 0, dg_leaf_lanes = 0, dg_walk_rounds = 0, dg_walk_lanes = 0, dg_shade_rounds = 0;
     unsigned long long dg_rt0 = 0, dg_rt_workout = 0;
     if (STATS) {
         dg_t0 = __builtin_amdgcn_s_memtime();
         dg_rt0 = __builtin_amdgcn_s_memrealtime();
     }
     bool more_work = true;  // wave-uniform: the global work counter has not run out yet
+    // Hand-over queue (drain phase). When the work items run out every wave still holds up to POOLN paths,
+    // and finishing them alone means hundreds of scheduling rounds at a handful of busy lanes -- on all
+    // waves at once, which made the end of a launch cost as much as a quarter of it. Instead, all waves
+    // but the collectors append their waiting paths (state, records, status) to a global queue as soon as
+    // they have no work items left, finish only their running traversals and leave; the collectors refill
+    // their pools from the queue and keep working at full width. Donors never wait for anybody; collectors
+    // wait until every donor has left and the queue is empty. A path moves at most once, and moving it
+    // does not change its state, so the image is unaffected.
+    const bool q_on = P.collect_every != 0;
+    const bool is_collector = q_on && ((blockIdx.x >> 3) % P.collect_every) == 0;
+    const bool is_donor = q_on && !is_collector;
+    bool q_done = !is_collector;  // collector: the queue is empty and no donor can append any more
+    uint32_t dg_q_given = 0, dg_q_taken = 0, q_idle_spins = 0;
+    bool q_broken = false;  // the queue overflowed (cannot happen): stop using it
+    auto q_load = [&](uint32_t i) { return __hip_atomic_load(P.q_ctr + i * kQueueCtrStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); };
     const size_t npix = size_t(P.n_local_tiles) * 64u;
     const float eps = P.min_dist;
 
@@ -241,8 +257,120 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 #pragma unroll
             for (uint32_t k = 0; k < kNumStatus; ++k) cnt[k] += uint32_t(__popcll(__ballot(st == k)));
         }
-        if (STATS) ++dg_census;
+        if (STATS) ++dg_census, dg_dr_rounds += more_work ? 0u : 1u;
         uint32_t n_active = uint32_t(__popcll(__ballot(t_active)));
+
+        // ---- drain phase: donors append their waiting paths to the queue, collectors take from it ----
+        if (!more_work && is_donor && !q_broken) {
+            const uint32_t n_give = cnt[ST_TRAV] + cnt[ST_LAMB] + cnt[ST_METAL] + cnt[ST_DIEL];
+            if (n_give != 0) {
+                uint32_t ng = 0;
+#pragma unroll
+                for (uint32_t g = 0; g < kPoolPad; g += 64) {
+                    const uint32_t st = status[g + lane];
+                    const bool m = st == ST_TRAV || st == ST_LAMB || st == ST_METAL || st == ST_DIEL;
+                    const uint64_t mask = __ballot(m);
+                    if (m) list[ng + lane_rank(mask)] = uint8_t(g + lane);
+                    ng += uint32_t(__popcll(mask));
+                }
+                __syncthreads();
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.q_ctr, ng);  // tail: reserves entries [base, base + ng)
+                base = uint32_t(__shfl(int(base), 0));
+                if (base + ng > P.q_capacity) {  // cannot happen (a path moves once); never write out of bounds
+                    if (lane == 0) atomicAdd(&P.counters->diag[23], 1ull << 32);
+                    q_broken = true;  // this wave finishes its paths itself
+                    ng = 0;
+                }
+                for (uint32_t i = lane; i < ng; i += 64) {
+                    const uint32_t slot = list[i];
+                    uint32_t* e = P.q_entries + size_t(base + i) * kQueueEntryDw;
+#pragma unroll
+                    for (uint32_t f = 0; f < uint32_t(kFields); ++f) e[f] = POOL(f, slot);
+                    e[kFields] = status[slot];
+                    const uint32_t n_words = ((POOL(F_META, slot) >> 7) & 127u) >> 2;
+                    for (uint32_t w = 0; w < n_words; ++w)
+                        P.q_seq[size_t(base + i) * kSeqWords + w] = gseq[size_t(slot) * kSeqWords + w];
+                    __threadfence();  // the entry is complete before its flag says so
+                    __hip_atomic_store(e + kFields + 1, P.q_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    status[slot] = ST_EMPTY;
+                }
+                __syncthreads();
+                if (STATS) dg_q_given += ng;
+                if (!q_broken) {
+                    cnt[ST_EMPTY] += ng;
+                    cnt[ST_TRAV] = cnt[ST_LAMB] = cnt[ST_METAL] = cnt[ST_DIEL] = 0;
+                }
+            }
+        } else if (!more_work && !q_done && (cnt[ST_EMPTY] >= 32u || cnt[ST_EMPTY] + n_active >= uint32_t(POOLN))) {
+            const uint32_t want = cnt[ST_EMPTY] < 64u ? cnt[ST_EMPTY] : 64u;
+            // one attempt per scheduling round, straight-line: lane 0 reads the three counters (donors-gone
+            // first: if every donor has left, the tail read after it is final), everybody decides the same way
+            uint32_t gone = 0, t = 0, h = 0;
+            if (lane == 0) {
+                gone = q_load(2);
+                t = q_load(0);
+                h = q_load(1);
+            }
+            gone = uint32_t(__shfl(int(gone), 0));
+            t = uint32_t(__shfl(int(t), 0));
+            h = uint32_t(__shfl(int(h), 0));
+            const uint32_t n_take = h < t ? (want < t - h ? want : t - h) : 0u;
+            uint32_t won = 0;
+            if (n_take != 0 && lane == 0) won = atomicCAS(P.q_ctr + kQueueCtrStride, h, h + n_take) == h ? 1u : 0u;
+            won = uint32_t(__shfl(int(won), 0));
+            const uint32_t base = h;
+            const uint32_t got = won != 0 ? n_take : (h >= t && gone == P.n_donors ? ~0u : 0u);
+            if (got == ~0u) {
+                q_done = true;
+            } else if (got != 0) {
+                uint32_t ne = 0;
+#pragma unroll
+                for (uint32_t g = 0; g < kPoolPad; g += 64) {
+                    const bool m = status[g + lane] == ST_EMPTY;
+                    const uint64_t mask = __ballot(m);
+                    if (m) list[ne + lane_rank(mask)] = uint8_t(g + lane);
+                    ne += uint32_t(__popcll(mask));
+                }
+                __syncthreads();
+                uint32_t took = ST_EMPTY;
+                if (lane < got) {
+                    const uint32_t slot = list[lane];
+                    const uint32_t* e = P.q_entries + size_t(base + lane) * kQueueEntryDw;
+                    // the entry was reserved by a running donor; it is written within microseconds
+                    uint32_t spins = 0;
+                    while (__hip_atomic_load(e + kFields + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != P.q_epoch &&
+                           ++spins < (1u << 22))
+                        __builtin_amdgcn_s_sleep(8);
+                    if (spins >= (1u << 22)) atomicAdd(&P.counters->diag[23], 1ull);  // never seen; tests check it
+                    __threadfence();
+#pragma unroll
+                    for (uint32_t f = 0; f < uint32_t(kFields); ++f) POOL(f, slot) = e[f];
+                    const uint32_t n_words = ((e[F_META] >> 7) & 127u) >> 2;
+                    for (uint32_t w = 0; w < n_words; ++w)
+                        gseq[size_t(slot) * kSeqWords + w] = P.q_seq[size_t(base + lane) * kSeqWords + w];
+                    took = e[kFields];
+                    {   // sanity of what arrived (diagnostic while the queue is new): drop anything malformed
+                        const uint32_t m = e[F_META];
+                        const uint32_t ob = (m >> 14) & 255u;
+                        const uint32_t nr = (m >> 7) & 127u;
+                        bool bad = took < ST_TRAV || took > ST_DIEL || ob > P.n_spheres + P.n_meshes || (m & 127u) > P.max_depth ||
+                                   (took >= ST_LAMB && ob == 0u) || nr > P.max_depth || e[F_ITEM] >= P.n_items;
+                        if (!bad && took >= ST_LAMB) bad = classify(sc, int32_t(ob) - 1, m & 127u) != took;
+                        if (bad) {
+                            atomicAdd(&P.counters->diag[23], 1ull << 16);
+                            took = ST_EMPTY;
+                        }
+                    }
+                    status[slot] = uint8_t(took);
+                }
+                __syncthreads();
+                if (STATS) dg_q_taken += got;
+#pragma unroll
+                for (uint32_t k = ST_TRAV; k < kNumStatus; ++k) cnt[k] += uint32_t(__popcll(__ballot(took == k)));
+                cnt[ST_EMPTY] -= got;
+            }
+        }
 
         // ---- idle lanes take parked rays (in batches: only when enough lanes are idle) ----
         if (cnt[ST_TRAV] != 0 && (n_active < P.y_low_water || n_active + cnt[ST_TRAV] <= 64u)) {
@@ -294,7 +422,16 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (cnt[ST_LAMB] > best) kind = ST_LAMB, best = cnt[ST_LAMB];
         if (cnt[ST_METAL] > best) kind = ST_METAL, best = cnt[ST_METAL];
         if (cnt[ST_DIEL] > best) kind = ST_DIEL, best = cnt[ST_DIEL];
-        if (best == 0 && n_active == 0) break;  // nothing waits, nothing runs, no work left
+        if (best == 0 && n_active == 0 && cnt[ST_TRAV] == 0) {
+            if (q_done || more_work) break;  // nothing waits, nothing runs, no work left
+            // collector: donors are still finishing their traversals (bounded: ~2 s, then fail loudly)
+            if (++q_idle_spins > (1u << 20)) {
+                if (lane == 0) atomicAdd(&P.counters->diag[23], 1ull);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(64);
+            continue;
+        }
 
         // Traverse while the lanes are well filled; shade when they are not (that is what parks new
         // rays) or when shading work has piled up to a full wave.
@@ -313,6 +450,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             do {
                 if (STATS) {
                     ++dg_steps;
+                    if (!more_work) ++dg_dr_steps, dg_dr_lane_steps += uint32_t(__popcll(__ballot(t_active)));
                     dg_lane_steps += uint32_t(__popcll(__ballot(t_active)));
                 }
                 // Leaves are deferred: a lane that reaches a leaf remembers it (one pending leaf per lane) and
@@ -368,6 +506,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         // ============================ shading pass of one kind ===============================
         if (STATS) {
             ++dg_pass[kind];
+            if (!more_work) ++dg_dr_passes;
             dg_tk = __builtin_amdgcn_s_memtime();
         }
         uint32_t c0 = 0, c1 = 0;
@@ -421,6 +560,28 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     }
                 }
                 item = POOL(F_ITEM, slot);  // index of this path's sample in the sample buffer
+                if (STATS) {  // path-length histogram; bounces = scatter events, recorded or not
+                    const uint32_t bounces = P.max_depth - (meta & 127u);
+                    atomicAdd(&P.counters->diag[32 + (31 - __clz(int(bounces + 1u)))], 1ull);
+                    if (bounces >= 16u) {
+                        atomicAdd(&P.counters->diag[48], (unsigned long long)bounces);
+                        atomicAdd(&P.counters->diag[47], (unsigned long long)(bounces - nrec));  // dielectric ones
+                        for (uint32_t k = 0; k < nrec; ++k) {
+                            const uint32_t w = (k >> 2) == (nrec >> 2) ? word : gseq[size_t(slot) * kSeqWords + (k >> 2)];
+                            atomicAdd(&P.counters->diag[40 + (((w >> (8u * (k & 3u))) & 0xFFu) % 7u)], 1ull);
+                        }
+                    }
+                }
+                if (P.tile_cost && nrec >= P.cost_min_bounces)  // rare: feeds the next frame's tile order
+                    atomicAdd(&P.tile_cost[(item % uint32_t(npix)) >> 6], nrec + 1u);
+                if (item >= P.n_items) {  // corrupt path state: never store out of bounds, fail the render loudly
+                    if (atomicAdd(&P.counters->diag[57], 1ull) == 0ull) {
+                        P.counters->diag[58] = item;
+                        P.counters->diag[59] = ((unsigned long long)blockIdx.x << 32) | (slot << 8) | lane;
+                        P.counters->diag[60] = meta;
+                    }
+                    item = 0;
+                }
                 float* out = P.sample_buf + size_t(item) * 3u;
                 out[0] = color.x;
                 out[1] = color.y;
@@ -479,8 +640,19 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 // reserve the next chunk now; its result is not needed before a later TERM pass
                 if (more_work && work.res_end - work.res_next < 64u) work.prefetch(P, lane);
             }
-        } else if (is_main) {
-            // ---- RayScattering::scatter for one material kind (wave-uniform branch) ----
+        }
+        // ---- RayScattering::scatter, then the closest sphere + mesh gate for the new ray ----
+        // In the first round every lane shades the pass's kind (wave-uniform branches). A lane whose new
+        // ray passes no mesh gate already knows its next hit; when that needs shading again it may stay
+        // in registers for further rounds (any kind, per-lane branches) instead of waiting in the pool
+        // for a later pass: chains of sphere-only bounces (a ray caught between a sphere and the ground
+        // makes 30-50 of them) then cost a few us per bounce instead of one scheduling round each.
+        uint32_t lk = kind;
+        bool scat = kind != ST_TERM && is_main;
+        int32_t s_obj = -1;
+        float s_ht = 0.0f;
+        uint32_t s_tri = 0;
+        if (scat) {
             o = mk(__uint_as_float(POOL(F_OX, slot)), __uint_as_float(POOL(F_OY, slot)),
                    __uint_as_float(POOL(F_OZ, slot)));
             d = mk(__uint_as_float(POOL(F_DX, slot)), __uint_as_float(POOL(F_DY, slot)),
@@ -492,97 +664,125 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             const uint32_t meta = POOL(F_META, slot);
             depth = meta & 127u;
             nrec = (meta >> 7) & 127u;
-            const int32_t obj = int32_t((meta >> 14) & 255u) - 1;
-            const float ht = __uint_as_float(POOL(F_T, slot));
-            const V3 p = o + ht * d;  // same expression as inside the intersection routines
-            V3 n;
-            if (uint32_t(obj) < P.n_spheres) {
-                n = p - mk(sc.sph + uint32_t(obj) * kSphDw);  // sphere.rs:56, unnormalised
-            } else {
-                const Normal4 nn =
-                    lds_ptr<Normal4>(sc.mesh + (uint32_t(obj) - P.n_spheres) * kMeshDw + MD_NORMALS)[POOL(F_TRI, slot)];
-                n = mk(nn.x, nn.y, nn.z);  // mesh.rs:253-257
-            }
-            DevMaterial m;
-            {
-                const uint32_t* mp = sc.mat + uint32_t(obj) * kMatDw;
-                m.albedo[0] = __uint_as_float(mp[0]), m.albedo[1] = __uint_as_float(mp[1]);
-                m.albedo[2] = __uint_as_float(mp[2]), m.param = __uint_as_float(mp[3]);
-                m.kind = int32_t(mp[4]);
-            }
-            V3 nd;
-            bool ok;
-            if (kind == ST_LAMB) {  // lambertian.rs:11-24
-                const V3 target = (p + normalize(n)) + random_point_in_unit_sphere(rng);
-                nd = normalize(target - p);
-                ok = true;
-            } else if (kind == ST_METAL) {  // metal.rs:12-25
-                const V3 target = reflect(d, n);
-                nd = normalize(target + m.param * random_point_in_unit_sphere(rng));
-                ok = dot(nd, n) > 0.0f;
-            } else {  // dielectric.rs:11-59
-                ok = scatter(m, d, p, n, rng, nd);
-            }
-            if (ok) {
-                if (kind != ST_DIEL) {  // attenuation (1,1,1) is an exact identity, not recorded
-                    word |= uint32_t(obj) << (8u * (nrec & 3u));
-                    if ((nrec & 3u) == 3u) {
-                        gseq[size_t(slot) * kSeqWords + (nrec >> 2)] = word;
-                        word = 0;
-                    }
-                    ++nrec;
-                }
-                o = p;
-                d = nd;
-                depth -= 1;
-                have_ray = true;
-            } else {
-                // metal.rs:25 returned false: the path is black (lib.rs:63-66). Park it for a TERM
-                // pass with depth 0 so that the fold/store/regenerate code lives in one place.
-                POOL(F_META, slot) = pack_meta(0u, nrec, obj, 0u);
-                POOL(F_WORD, slot) = word;
-                status[slot] = ST_TERM;
-            }
+            s_obj = int32_t((meta >> 14) & 255u) - 1;
+            s_ht = __uint_as_float(POOL(F_T, slot));
+            s_tri = POOL(F_TRI, slot);
         }
-
-        // ---- closest sphere + mesh gate for the new ray (scene.rs:19-43 up to the meshes) ----
-        if (have_ray) {
-            if (STATS) ++lc.rays;
-            float closest = 3.40282347e+38f, ht = 0.0f;
-            int32_t obj = -1;
-            for (uint32_t i = 0; i < P.n_spheres; ++i) {
-                const float* sp = sc.sph + i * kSphDw;
-                float t, dist;
-                if (sphere_hit(mk(sp), sp[3], o, d, P.min_dist, P.max_dist, t, dist, P.counters)) {
-                    if (dist < closest) {
-                        closest = dist;
-                        ht = t;
-                        obj = int32_t(i);
+        for (uint32_t round = 1;; ++round) {
+            if (scat) {
+                const V3 p = o + s_ht * d;  // same expression as inside the intersection routines
+                V3 n;
+                if (uint32_t(s_obj) < P.n_spheres) {
+                    n = p - mk(sc.sph + uint32_t(s_obj) * kSphDw);  // sphere.rs:56, unnormalised
+                } else {
+                    const Normal4 nn =
+                        lds_ptr<Normal4>(sc.mesh + (uint32_t(s_obj) - P.n_spheres) * kMeshDw + MD_NORMALS)[s_tri];
+                    n = mk(nn.x, nn.y, nn.z);  // mesh.rs:253-257
+                }
+                DevMaterial m;
+                {
+                    const uint32_t* mp = sc.mat + uint32_t(s_obj) * kMatDw;
+                    m.albedo[0] = __uint_as_float(mp[0]), m.albedo[1] = __uint_as_float(mp[1]);
+                    m.albedo[2] = __uint_as_float(mp[2]), m.param = __uint_as_float(mp[3]);
+                    m.kind = int32_t(mp[4]);
+                }
+                V3 nd;
+                bool ok;
+                if (lk == ST_LAMB) {  // lambertian.rs:11-24
+                    const V3 target = (p + normalize(n)) + random_point_in_unit_sphere(rng);
+                    nd = normalize(target - p);
+                    ok = true;
+                } else if (lk == ST_METAL) {  // metal.rs:12-25
+                    const V3 target = reflect(d, n);
+                    nd = normalize(target + m.param * random_point_in_unit_sphere(rng));
+                    ok = dot(nd, n) > 0.0f;
+                } else {  // dielectric.rs:11-59
+                    ok = scatter(m, d, p, n, rng, nd);
+                }
+                if (ok) {
+                    if (lk != ST_DIEL) {  // attenuation (1,1,1) is an exact identity, not recorded
+                        word |= uint32_t(s_obj) << (8u * (nrec & 3u));
+                        if ((nrec & 3u) == 3u) {
+                            gseq[size_t(slot) * kSeqWords + (nrec >> 2)] = word;
+                            word = 0;
+                        }
+                        ++nrec;
                     }
+                    o = p;
+                    d = nd;
+                    depth -= 1;
+                    have_ray = true;
+                } else {
+                    // metal.rs:25 returned false: the path is black (lib.rs:63-66). Park it for a TERM
+                    // pass with depth 0 so that the fold/store/regenerate code lives in one place.
+                    // (a path started in this very pass has nothing of its own in the pool yet: F_ITEM too)
+                    POOL(F_META, slot) = pack_meta(0u, nrec, s_obj, 0u);
+                    POOL(F_WORD, slot) = word;
+                    POOL(F_ITEM, slot) = item;
+                    status[slot] = ST_TERM;
                 }
             }
-            const uint32_t m = next_gated_mesh<STATS>(sc, P.n_meshes, 0, o, d, lc);
-            POOL(F_OX, slot) = __float_as_uint(o.x);
-            POOL(F_OY, slot) = __float_as_uint(o.y);
-            POOL(F_OZ, slot) = __float_as_uint(o.z);
-            POOL(F_DX, slot) = __float_as_uint(d.x);
-            POOL(F_DY, slot) = __float_as_uint(d.y);
-            POOL(F_DZ, slot) = __float_as_uint(d.z);
-            POOL(F_S0, slot) = rng.s0;
-            POOL(F_S1, slot) = rng.s1;
-            POOL(F_ITEM, slot) = item;
-            POOL(F_WORD, slot) = word;
-            POOL(F_DIST, slot) = __float_as_uint(closest);
-            POOL(F_T, slot) = __float_as_uint(ht);
-            POOL(F_TRI, slot) = 0u;
-            POOL(F_META, slot) = pack_meta(depth, nrec, obj, m < P.n_meshes ? m : 0u);
-            status[slot] = m < P.n_meshes ? ST_TRAV : classify(sc, obj, depth);
-        } else if (kind == ST_TERM && (is_main || is_gen)) {
-            status[slot] = ST_EMPTY;  // no work item left (or a pixel outside a ragged image edge)
+            scat = false;
+            // closest sphere + mesh gate for the new ray (scene.rs:19-43 up to the meshes)
+            uint32_t gated = 0, next = ST_TERM;
+            float closest = 3.40282347e+38f;
+            if (have_ray) {
+                if (STATS) ++lc.rays;
+                s_obj = -1;
+                s_ht = 0.0f;
+                for (uint32_t i = 0; i < P.n_spheres; ++i) {
+                    const float* sp = sc.sph + i * kSphDw;
+                    float t, dist;
+                    if (sphere_hit(mk(sp), sp[3], o, d, P.min_dist, P.max_dist, t, dist, P.counters)) {
+                        if (dist < closest) {
+                            closest = dist;
+                            s_ht = t;
+                            s_obj = int32_t(i);
+                        }
+                    }
+                }
+                gated = next_gated_mesh<STATS>(sc, P.n_meshes, 0, o, d, lc);
+                next = gated < P.n_meshes ? uint32_t(ST_TRAV) : classify(sc, s_obj, depth);
+            }
+            // stay in registers? only sphere hits that need shading, while enough lanes do (or the wave
+            // has no other work left), and for a bounded number of rounds
+            const bool cand = have_ray && next >= ST_LAMB;
+            const uint32_t n_cand = uint32_t(__popcll(__ballot(cand)));
+            const bool go = n_cand != 0 && round < kMaxShadeRounds &&
+                            (more_work ? (round < P.shade_rounds && n_cand >= P.shade_cont_min) : true);
+            if (have_ray && !(cand && go)) {
+                POOL(F_OX, slot) = __float_as_uint(o.x);
+                POOL(F_OY, slot) = __float_as_uint(o.y);
+                POOL(F_OZ, slot) = __float_as_uint(o.z);
+                POOL(F_DX, slot) = __float_as_uint(d.x);
+                POOL(F_DY, slot) = __float_as_uint(d.y);
+                POOL(F_DZ, slot) = __float_as_uint(d.z);
+                POOL(F_S0, slot) = rng.s0;
+                POOL(F_S1, slot) = rng.s1;
+                POOL(F_ITEM, slot) = item;
+                POOL(F_WORD, slot) = word;
+                POOL(F_DIST, slot) = __float_as_uint(closest);
+                POOL(F_T, slot) = __float_as_uint(s_ht);
+                POOL(F_TRI, slot) = 0u;
+                POOL(F_META, slot) = pack_meta(depth, nrec, s_obj, gated < P.n_meshes ? gated : 0u);
+                status[slot] = uint8_t(next);
+            } else if (round == 1 && kind == ST_TERM && !have_ray && (is_main || is_gen)) {
+                status[slot] = ST_EMPTY;  // no work item left (or a pixel outside a ragged image edge)
+            }
+            if (!go) break;
+            scat = cand;
+            have_ray = false;
+            lk = next;
+            s_tri = 0;
+            if (STATS) dg_lanes[kind] += n_cand, ++dg_shade_rounds;
         }
         if (STATS) dg_t_shade += __builtin_amdgcn_s_memtime() - dg_tk;
     }
 #undef POOL
+    if (is_donor && lane == 0) {  // after this wave's last append
+        __threadfence();
+        __hip_atomic_fetch_add(P.q_ctr + 2 * kQueueCtrStride, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (STATS) {
         atomicAdd(&P.counters->rays, (unsigned long long)lc.rays);
         atomicAdd(&P.counters->mesh_gate_pass, (unsigned long long)lc.gate);
@@ -595,6 +795,19 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 atomicAdd(&P.counters->diag[k], (unsigned long long)dg_pass[k]);
                 atomicAdd(&P.counters->diag[6 + k], (unsigned long long)dg_lanes[k]);
             }
+            {   // the wave with the longest drain phase: [us:20 | rounds:12 | steps:16 | passes:16]
+                const unsigned long long rt_now = __builtin_amdgcn_s_memrealtime();
+                const unsigned long long us = dg_rt_workout ? (rt_now - dg_rt_workout) / 100ull : 0ull;
+                const unsigned long long packed = (us << 44) | ((unsigned long long)(dg_dr_rounds & 0xFFFu) << 32) |
+                                                  ((unsigned long long)(dg_dr_steps & 0xFFFFu) << 16) | (dg_dr_passes & 0xFFFFu);
+                atomicMax(&P.counters->diag[50], packed);
+                atomicAdd(&P.counters->diag[51], (unsigned long long)dg_dr_rounds);
+                atomicAdd(&P.counters->diag[52], (unsigned long long)dg_dr_steps);
+                atomicAdd(&P.counters->diag[53], (unsigned long long)dg_dr_passes);
+                atomicAdd(&P.counters->diag[54], (unsigned long long)dg_dr_lane_steps);
+            }
+            atomicAdd(&P.counters->diag[55], (unsigned long long)dg_q_given);
+            atomicAdd(&P.counters->diag[56], (unsigned long long)dg_q_taken);
             atomicAdd(&P.counters->diag[12], (unsigned long long)dg_steps);
             atomicAdd(&P.counters->diag[13], (unsigned long long)dg_lane_steps);
             atomicAdd(&P.counters->diag[14], (unsigned long long)dg_refills);
@@ -604,6 +817,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             atomicAdd(&P.counters->diag[18], (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
             atomicAdd(&P.counters->diag[19], (unsigned long long)dg_leaf_rounds);
             atomicAdd(&P.counters->diag[20], (unsigned long long)dg_leaf_lanes);
+            atomicAdd(&P.counters->diag[29], (unsigned long long)dg_shade_rounds);
             atomicAdd(&P.counters->diag[21], (unsigned long long)dg_walk_rounds);
             atomicAdd(&P.counters->diag[22], (unsigned long long)dg_walk_lanes);
             const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();

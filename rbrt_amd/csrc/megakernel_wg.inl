@@ -356,6 +356,8 @@ __global__ __launch_bounds__(64 * WAVES, RBRT_MK_WAVES_PER_SIMD) void trace_mega
                     }
                 }
                 item = WPOOL(F_ITEM, slot);  // index of this path's sample in the sample buffer
+                if (P.tile_cost && nrec >= P.cost_min_bounces)  // rare: feeds the next frame's tile order
+                    atomicAdd(&P.tile_cost[(item % uint32_t(npix)) >> 6], nrec + 1u);
                 float* out = P.sample_buf + size_t(item) * 3u;
                 out[0] = color.x;
                 out[1] = color.y;

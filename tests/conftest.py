@@ -1,7 +1,12 @@
+import os
 import sys
 from pathlib import Path
 
 import pytest
+
+# GPU tests: fill the sample buffer with NaN bit patterns before every trace launch, so that a (pixel, sample)
+# the kernel fails to write cannot hide behind a previous render's value or a zero-initialised allocation.
+os.environ.setdefault("RBRT_POISON_SAMPLES", "1")
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
