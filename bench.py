@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--spp", type=int, default=50)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="frame pipeline depth (rbrt_hip_scene_set_pipeline): consecutive steps' trace launches overlap "
+                         "on this many internal streams")
     ap.add_argument("--vary-seed", type=int, default=0, help="1: every step renders a new frame (seed + step number)")
     ap.add_argument("--triangles", type=int, default=69451)
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
@@ -127,9 +130,11 @@ def main():
 
     step_no = [0]
 
+    scene.set_pipeline(args.pipeline)
+
     def step():
+        step_no[0] += 1
         if args.vary_seed:
-            step_no[0] += 1
             opts.seed = args.seed + step_no[0]
         if world == 1:
             scene.render_device(cam, opts, image.data_ptr(), None, stream)  # (emulation: packed tiles, fits)

@@ -202,6 +202,14 @@ int rbrt_hip_unpack_tiles_strided(int device, void* stream, const float* d_gathe
 /* Counters of the last render on this scene that had RBRT_FLAG_COLLECT_STATS set. */
 int rbrt_hip_scene_stats(rbrt_hip_scene_t* scene, rbrt_hip_stats_t* out);
 
+/* Frame pipeline depth of a scene handle (1..4, default 2 or $RBRT_PIPELINE). With depth d > 1 consecutive
+ * trace launches -- the sample batches of one render and successive rbrt_hip_render_device calls -- alternate
+ * over d internal streams and d sets of work buffers, so that a launch's last, poorly filled waves overlap
+ * with the start of the next launch; the per-pixel resolve (and with it every write to the caller's output
+ * buffers) stays on the caller's stream, in call order. No counterpart in the reference (its render_scene
+ * is one blocking call, lib.rs:75-124); results are identical for every depth. */
+int rbrt_hip_scene_set_pipeline(rbrt_hip_scene_t* scene, uint32_t depth);
+
 /* Test / diagnostic hook for Scene::hit (scene.rs:19-43): closest hit of n rays against the
  * resident scene. Host arrays. rays = n x {ox,oy,oz,dx,dy,dz}. Outputs (each may be NULL):
  *   out_t[n]      ray parameter of the winning object (NaN on miss)

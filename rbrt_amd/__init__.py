@@ -73,6 +73,10 @@ class HipScene:
         abi.check(self._lib.rbrt_hip_render_device(self._h, C.byref(cam), C.byref(opts), C.c_void_p(stream or 0),
                                                    C.c_void_p(d_radiance or 0), C.c_void_p(d_rgb8 or 0)))
 
+    def set_pipeline(self, depth: int):
+        """Overlap consecutive trace launches over `depth` internal streams (rbrt_hip_scene_set_pipeline)."""
+        abi.check(self._lib.rbrt_hip_scene_set_pipeline(self._h, int(depth)))
+
     def set_timing(self, on: bool = True):
         abi.check(self._lib.rbrt_hip_scene_set_timing(self._h, int(on)))
 
@@ -105,7 +109,6 @@ class HipScene:
                  long_path_total=int(buf[48]), long_path_dielectric=int(buf[47]), shade_extra_rounds=int(buf[29]),
                  drain_slowest=dict(us=int(buf[50]) >> 44, rounds=(int(buf[50]) >> 32) & 0xFFF,
                                     trav_steps=(int(buf[50]) >> 16) & 0xFFFF, passes=int(buf[50]) & 0xFFFF),
-                 queue_given=int(buf[55]), queue_taken=int(buf[56]),
                  drain_sum=dict(rounds=int(buf[51]), trav_steps=int(buf[52]), passes=int(buf[53]),
                                 lane_steps=int(buf[54])))
         return d

@@ -135,6 +135,7 @@ HIP_SYMBOLS = {
     "rbrt_hip_last_error": (C.c_char_p, []),
     "rbrt_hip_abi_version": (C.c_int, []),
     "rbrt_hip_scene_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "rbrt_hip_scene_set_pipeline": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rbrt_hip_scene_kernel_ms": (C.c_int, [C.c_void_p, f32p, f32p, C.POINTER(C.c_uint32)]),
 }
 

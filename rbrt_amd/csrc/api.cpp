@@ -77,17 +77,28 @@ struct rbrt_hip_scene {
     DevMesh* d_meshes = nullptr;
     DevCounters* d_counters = nullptr;
     // workspace, grown on demand
-    float* d_sample_buf = nullptr;
-    size_t sample_buf_bytes = 0;
+    // Frame pipeline: consecutive trace launches (the batches of one render, or successive renders) alternate
+    // over `pipeline` lanes. Every lane has its own sample buffer, work counters and per-wave scratch, and --
+    // when pipeline > 1 -- its own stream, so that the next launch's waves move in while the previous launch
+    // is still finishing its last, poorly filled waves (its drain, up to a third of a short launch). The
+    // resolve of a launch stays on the caller's stream, after an event; pipeline == 1 runs everything on the
+    // caller's stream.
+    struct Lane {
+        hipStream_t stream = nullptr;  // null: the caller's stream (pipeline == 1)
+        float* d_sample_buf = nullptr;
+        size_t sample_buf_bytes = 0;
+        unsigned long long* d_work_counter = nullptr;
+        uint32_t* d_gseq = nullptr;
+        uint32_t* d_gstack = nullptr;
+        hipEvent_t ev_traced = nullptr, ev_resolved = nullptr;
+        bool in_use = false;  // ev_resolved has been recorded at least once
+    };
+    std::vector<Lane> lanes;
+    uint32_t pipeline = 2;   // RBRT_PIPELINE / rbrt_hip_scene_set_pipeline
+    uint32_t scratch_waves = 0;
+    uint32_t next_lane = 0;
     float* d_acc = nullptr;
     size_t acc_bytes = 0;
-    unsigned long long* d_work_counter = nullptr;
-    uint32_t* d_gseq = nullptr;
-    uint32_t* d_gstack = nullptr;
-    uint32_t* d_q_entries = nullptr;  // hand-over queue of the drain phase
-    uint32_t* d_q_seq = nullptr;
-    uint32_t q_epoch = 0;
-    uint32_t collect_every = 8;       // RBRT_COLLECT_EVERY (0 = off)
     bool poison_samples = false;      // RBRT_POISON_SAMPLES
     // host copy of what the tile-cost heuristic needs, and the cached tile order
     std::vector<rbrt_sphere_t> h_spheres;
@@ -142,6 +153,33 @@ int upload(rbrt_hip_scene* s, const std::vector<T>& host, T** out) {
     s->allocs.push_back(d);
     if (!host.empty()) HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<T*>(d);
+    return RBRT_OK;
+}
+
+constexpr uint32_t kMaxPipeline = 4;
+
+// Brings s->lanes to s->pipeline entries (streams, events, counters and per-wave scratch of each lane).
+int ensure_lanes(rbrt_hip_scene* s) {
+    while (s->lanes.size() < s->pipeline) {
+        rbrt_hip_scene::Lane L;
+        void* p = nullptr;
+        const size_t counter_bytes = sizeof(unsigned long long) * kWorkShards * kWorkCounterStride;
+        HIP_TRY(hipMalloc(&p, counter_bytes));
+        s->allocs.push_back(p);
+        L.d_work_counter = static_cast<unsigned long long*>(p);
+        HIP_TRY(hipMemset(p, 0, counter_bytes));
+        HIP_TRY(hipMalloc(&p, megakernel_gseq_bytes(s->scratch_waves)));
+        s->allocs.push_back(p);
+        L.d_gseq = static_cast<uint32_t*>(p);
+        HIP_TRY(hipMemset(p, 0, megakernel_gseq_bytes(s->scratch_waves)));
+        HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
+        s->allocs.push_back(p);
+        L.d_gstack = static_cast<uint32_t*>(p);
+        HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_traced, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_resolved, hipEventDisableTiming));
+        s->lanes.push_back(L);
+    }
     return RBRT_OK;
 }
 
@@ -439,38 +477,13 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             }
             s->n_wg = uint32_t(cus * wg_per_cu);
         }
-        const uint32_t scratch_waves = uint32_t(cus) * 32u;  // both kernel variants index scratch by wave / workgroup
-        std::vector<uint32_t> zeros(megakernel_gseq_bytes(scratch_waves) / sizeof(uint32_t), 0u);
-        if (int rc = upload(s, zeros, &s->d_gseq)) return bail(rc);
-        {
-            void* gp = nullptr;
-            if (hipMalloc(&gp, megakernel_gstack_bytes(scratch_waves)) != hipSuccess)
-                return bail(fail(RBRT_ERR_OOM, "hipMalloc failed for the stack overflow scratch"));
-            s->allocs.push_back(gp);
-            s->d_gstack = static_cast<uint32_t*>(gp);
-        }
-        // work counters, then the three counters of the hand-over queue (zeroed together before every launch)
-        std::vector<unsigned long long> zc(size_t(kWorkShards) * kWorkCounterStride + 3u * kQueueCtrStride / 2u, 0ull);
-        if (int rc = upload(s, zc, &s->d_work_counter)) return bail(rc);
-        if (const char* e = std::getenv("RBRT_POISON_SAMPLES")) s->poison_samples = e[0] == '1';
-        if (const char* e = std::getenv("RBRT_COLLECT_EVERY")) {
+        s->scratch_waves = uint32_t(cus) * 32u;  // both kernel variants index scratch by wave / workgroup
+        if (const char* e = std::getenv("RBRT_PIPELINE")) {
             int v = std::atoi(e);
-            if (v >= 0 && v <= 512) s->collect_every = uint32_t(v);
+            if (v >= 1 && v <= int(kMaxPipeline)) s->pipeline = uint32_t(v);
         }
-        {   // every path is handed over at most once, so n_waves * pool entries are enough
-            const size_t n_entries = size_t(s->n_waves) * s->pool;
-            void* qp = nullptr;
-            if (hipMalloc(&qp, n_entries * kQueueEntryDw * sizeof(uint32_t)) != hipSuccess)
-                return bail(fail(RBRT_ERR_OOM, "hipMalloc failed for the hand-over queue"));
-            s->allocs.push_back(qp);
-            s->d_q_entries = static_cast<uint32_t*>(qp);
-            if (hipMemset(qp, 0, n_entries * kQueueEntryDw * sizeof(uint32_t)) != hipSuccess)  // ready flags
-                return bail(fail(RBRT_ERR_HIP, "hipMemset failed for the hand-over queue"));
-            if (hipMalloc(&qp, n_entries * (kMaxPathDepth / 4) * sizeof(uint32_t)) != hipSuccess)
-                return bail(fail(RBRT_ERR_OOM, "hipMalloc failed for the hand-over queue records"));
-            s->allocs.push_back(qp);
-            s->d_q_seq = static_cast<uint32_t*>(qp);
-        }
+        if (int rc = ensure_lanes(s)) return bail(rc);
+        if (const char* e = std::getenv("RBRT_POISON_SAMPLES")) s->poison_samples = e[0] == '1';
     }
     *out = s;
     return RBRT_OK;
@@ -479,8 +492,14 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
 int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     if (!s) return RBRT_OK;
     (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();  // lane streams included
+    for (auto& L : s->lanes) {
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.ev_traced) (void)hipEventDestroy(L.ev_traced);
+        if (L.ev_resolved) (void)hipEventDestroy(L.ev_resolved);
+        if (L.d_sample_buf) (void)hipFree(L.d_sample_buf);
+    }
     for (void* p : s->allocs) (void)hipFree(p);
-    if (s->d_sample_buf) (void)hipFree(s->d_sample_buf);
     if (s->d_acc) (void)hipFree(s->d_acc);
     if (s->d_tile_order) (void)hipFree(s->d_tile_order);
     if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
@@ -546,19 +565,15 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     if (batch < 1) batch = 1;
     if (batch > o->spp) batch = o->spp;
     const size_t need = batch * per_sample;
-    if (need > s->sample_buf_bytes) {
-        if (s->d_sample_buf) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            HIP_TRY(hipFree(s->d_sample_buf));
-            s->d_sample_buf = nullptr, s->sample_buf_bytes = 0;
-        }
-        void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, need));
-        s->d_sample_buf = static_cast<float*>(p), s->sample_buf_bytes = need;
-    }
+    if (int rc = ensure_lanes(s)) return rc;
+    const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (auto& L : s->lanes) HIP_TRY(hipStreamSynchronize(L.stream));
+        return RBRT_OK;
+    };
     if (per_sample > s->acc_bytes) {
         if (s->d_acc) {
-            HIP_TRY(hipStreamSynchronize(stream));
+            if (int rc = sync_lanes()) return rc;
             HIP_TRY(hipFree(s->d_acc));
             s->d_acc = nullptr, s->acc_bytes = 0;
         }
@@ -582,7 +597,6 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     fill_trace_params(s, cam, o, P);
     P.tiles_x = tiles_x, P.tiles_y = tiles_y, P.n_tiles = n_tiles;
     P.tile_rank = o->tile_rank, P.tile_world = world, P.n_local_tiles = n_local;
-    P.sample_buf = s->d_sample_buf;
     {   // tile order: recomputed only when the camera / sharding changes
         std::vector<unsigned char> key(sizeof(rbrt_camera_t) + 2 * sizeof(uint32_t));
         std::memcpy(key.data(), cam, sizeof(rbrt_camera_t));
@@ -599,7 +613,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
                              (s->cost_frames & (s->cost_frames - 1)) == 0;
         if (rekey || refresh) {
             if (n_local > s->tile_order_cap) {
-                HIP_TRY(hipStreamSynchronize(stream));
+                if (int rc = sync_lanes()) return rc;
                 if (s->d_tile_order) HIP_TRY(hipFree(s->d_tile_order));
                 if (s->d_tile_cost) HIP_TRY(hipFree(s->d_tile_cost));
                 s->d_tile_order = s->d_tile_cost = nullptr;
@@ -610,7 +624,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
                 s->d_tile_cost = static_cast<uint32_t*>(p);
                 s->tile_order_cap = n_local;
             }
-            HIP_TRY(hipStreamSynchronize(stream));  // a previous launch may still be using both arrays
+            if (int rc = sync_lanes()) return rc;  // a previous launch may still be using both arrays
             std::vector<uint32_t> measured;
             if (refresh) {
                 measured.resize(n_local);
@@ -629,18 +643,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         if (P.tile_cost) ++s->cost_frames;
         P.tile_order = s->d_tile_order;
     }
-    P.work_counter = s->d_work_counter;
-    P.gseq = s->d_gseq;
     P.stack_entries = s->stack_entries;
-    P.gstack = s->d_gstack;
-    P.q_entries = s->d_q_entries;
-    P.q_seq = s->d_q_seq;
-    P.q_ctr = reinterpret_cast<uint32_t*>(s->d_work_counter + size_t(kWorkShards) * kWorkCounterStride);
-    P.collect_every = s->collect_every;
-    P.q_capacity = uint32_t(size_t(s->n_waves) * s->pool);
-    P.n_donors = 0;
-    if (s->collect_every != 0)
-        for (uint32_t b = 0; b < s->n_waves; ++b) P.n_donors += ((b >> 3) % s->collect_every) != 0 ? 1u : 0u;
     P.y_low_water = s->y_low_water;
     P.leaf_round = s->leaf_round;
     P.shade_min = s->shade_min;
@@ -652,7 +655,6 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     R.width = W, R.height = H, R.tiles_x = tiles_x, R.n_tiles = n_tiles;
     R.tile_rank = o->tile_rank, R.tile_world = world, R.n_local_tiles = n_local;
     R.inv_spp = 1.0f / float(o->spp);  // lib.rs:101
-    R.sample_buf = s->d_sample_buf;
     R.acc = s->d_acc;
     R.out_radiance = d_radiance;
     R.out_rgb8 = d_rgb8;
@@ -669,32 +671,71 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     for (size_t b = 0; b < n_batches; ++b) {
         const uint32_t base = uint32_t(b * batch);
         const uint32_t nb = uint32_t(std::min<size_t>(batch, o->spp - base));
+        // counting launches run alone on lane 0: their counters are reset and read on the caller's stream
+        rbrt_hip_scene::Lane& L = s->lanes[stats ? 0 : s->next_lane++ % s->pipeline];
+        const bool piped = s->pipeline > 1 && !stats;
+        hipStream_t ts = piped ? L.stream : stream;  // the trace launch's stream
+        if (need > L.sample_buf_bytes) {
+            if (L.d_sample_buf) {
+                if (int rc = sync_lanes()) return rc;
+                HIP_TRY(hipFree(L.d_sample_buf));
+                L.d_sample_buf = nullptr, L.sample_buf_bytes = 0;
+            }
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, need));
+            L.d_sample_buf = static_cast<float*>(p), L.sample_buf_bytes = need;
+        }
+        if (piped) {
+            // this lane's sample buffer is free once the resolve of its previous launch has run
+            if (L.in_use) HIP_TRY(hipStreamWaitEvent(L.stream, L.ev_resolved, 0));
+        } else if (s->pipeline > 1) {
+            if (int rc = sync_lanes()) return rc;  // a counting launch: nothing else in flight
+        }
         P.sample_base = base;
         P.batch = nb;
         P.n_items = uint64_t(npix) * nb;
-        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));
-        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0,
-                               sizeof(unsigned long long) * (size_t(kWorkShards) * kWorkCounterStride + 3u * kQueueCtrStride / 2u), stream));
-        if (++s->q_epoch == 0) s->q_epoch = 1;  // ready flags of earlier launches never match
+        P.sample_buf = L.d_sample_buf;
+        P.work_counter = L.d_work_counter;
+        P.gseq = L.d_gseq;
+        P.gstack = L.d_gstack;
+        HIP_TRY(hipMemsetAsync(L.d_work_counter, 0, sizeof(unsigned long long) * kWorkShards * kWorkCounterStride, ts));
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
-        if (s->poison_samples) HIP_TRY(hipMemsetAsync(s->d_sample_buf, 0xFF, s->sample_buf_bytes, stream));
-        P.q_epoch = s->q_epoch;
-        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], stream));  // after the memset node
+        if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
+        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
         if (s->use_wg)
-            HIP_TRY(launch_trace_megakernel_wg(P, s->n_wg, s->wg_pool, stats, stream));
+            HIP_TRY(launch_trace_megakernel_wg(P, s->n_wg, s->wg_pool, stats, ts));
         else
-            HIP_TRY(launch_trace_megakernel(P, s->n_waves, s->pool, stats, stream));
-        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], stream));
+            HIP_TRY(launch_trace_megakernel(P, s->n_waves, s->pool, stats, ts));
+        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
+        if (piped) {
+            HIP_TRY(hipEventRecord(L.ev_traced, ts));
+            HIP_TRY(hipStreamWaitEvent(stream, L.ev_traced, 0));
+        }
+        R.sample_buf = L.d_sample_buf;
         R.batch = nb;
         R.first_batch = b == 0;
         R.last_batch = b + 1 == n_batches;
         HIP_TRY(launch_resolve(R, stream));
+        if (s->pipeline > 1) {  // (also after a counting launch: it used lane 0's buffers on the caller's stream)
+            HIP_TRY(hipEventRecord(L.ev_resolved, stream));
+            L.in_use = true;
+        }
         if (s->timing) {
             HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 2], stream));
             s->events_used = ev0 + 3 * (b + 1);
         }
     }
     return RBRT_OK;
+}
+
+int rbrt_hip_scene_set_pipeline(rbrt_hip_scene_t* s, uint32_t depth) {
+    if (!s) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: null scene");
+    if (depth < 1 || depth > kMaxPipeline) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: depth must be 1..4");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    s->pipeline = depth;
+    s->next_lane = 0;
+    return ensure_lanes(s);
 }
 
 int rbrt_hip_scene_stats(rbrt_hip_scene_t* s, rbrt_hip_stats_t* out) {
@@ -713,8 +754,8 @@ int rbrt_hip_scene_stats(rbrt_hip_scene_t* s, rbrt_hip_stats_t* out) {
     s->stats.node_bytes = sizeof(BvhNode4);
     s->stats.tri_bytes = sizeof(BvhTri);
     *out = s->stats;
-    if (c.diag[23] || c.diag[57])
-        return fail(RBRT_ERR_HIP, "the trace kernel detected corrupt internal state (hand-over queue / path slot)");
+    if (c.diag[57])
+        return fail(RBRT_ERR_HIP, "the trace kernel detected corrupt internal state (a path slot without a valid sample index)");
     return RBRT_OK;
 }
 
@@ -805,8 +846,8 @@ int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const r
     TRY_OR_CLEAN(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     cleanup();
 #undef TRY_OR_CLEAN
-    if (c.diag[23] || c.diag[57])
-        return fail(RBRT_ERR_HIP, "the trace kernel detected corrupt internal state (hand-over queue / path slot)");
+    if (c.diag[57])
+        return fail(RBRT_ERR_HIP, "the trace kernel detected corrupt internal state (a path slot without a valid sample index)");
     if (c.nan_discriminants)
         return fail(RBRT_ERR_NAN, "a sphere discriminant was NaN (the reference panics: sphere.rs:33); "
                                   "those rays were treated as misses");

@@ -16,8 +16,6 @@ constexpr int kLeafMax = 4;          // triangles per leaf (2-bit count field)
 constexpr int kPoolMax = 256;        // largest path pool per wave the persistent megakernel is built for
 constexpr uint32_t kWorkShards = 8;         // work-item counters (one per XCD)
 constexpr uint32_t kWorkCounterStride = 16;  // in u64: each counter on its own 128-B line
-constexpr uint32_t kQueueEntryDw = 16;   // hand-over queue entry: 14 state dwords, status, ready flag
-constexpr uint32_t kQueueCtrStride = 32;  // dwords between the queue's counters (one 128 B line each)
 constexpr uint32_t kMaxShadeRounds = 64;  // hard bound of register-resident shading rounds per pass
 constexpr int kLdsStack = 8;         // per-lane traversal stack entries kept in LDS by the megakernel; deeper
                                      // entries spill (exactly) to a per-wave global scratch
@@ -119,15 +117,6 @@ struct TraceParams {
     uint32_t* gseq;                    // [n_waves][kPoolMax][kMaxPathDepth/4] scatter records beyond the 4 kept in LDS
     uint32_t stack_entries;            // per-lane traversal stack entries kept in LDS (<= stack_need)
     uint32_t* gstack;                  // [n_waves][kStackMax][64] overflow of the LDS stacks
-    // Drain phase (megakernel.inl "hand-over queue"): once the work items have run out, most waves hand their
-    // waiting paths to a few collector waves instead of each finishing a nearly empty pool.
-    uint32_t* q_entries;               // [n_waves * pool][kQueueEntryDw] path state + status + ready flag
-    uint32_t* q_seq;                   // [n_waves * pool][kMaxPathDepth/4] scatter records of an entry
-    uint32_t* q_ctr;                   // tail at [0], head at [kQueueCtrStride], donors done at [2 * kQueueCtrStride]
-    uint32_t q_epoch;                  // value of a written entry's ready flag in this launch
-    uint32_t q_capacity;               // entries in q_entries / q_seq
-    uint32_t collect_every;            // waves with (blockIdx / 8) % collect_every == 0 collect; 0 = no hand-over
-    uint32_t n_donors;                 // number of waves in the grid that are not collectors
     uint32_t y_low_water;              // refill a traversal pass when fewer lanes than this are busy
     uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one
     uint32_t shade_min;                // workgroup-pool kernel: let a shading queue fill to this depth while lanes can traverse

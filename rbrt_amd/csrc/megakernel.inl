@@ -173,21 +173,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         dg_rt0 = __builtin_amdgcn_s_memrealtime();
     }
     bool more_work = true;  // wave-uniform: the global work counter has not run out yet
-    // Hand-over queue (drain phase). When the work items run out every wave still holds up to POOLN paths,
-    // and finishing them alone means hundreds of scheduling rounds at a handful of busy lanes -- on all
-    // waves at once, which made the end of a launch cost as much as a quarter of it. Instead, all waves
-    // but the collectors append their waiting paths (state, records, status) to a global queue as soon as
-    // they have no work items left, finish only their running traversals and leave; the collectors refill
-    // their pools from the queue and keep working at full width. Donors never wait for anybody; collectors
-    // wait until every donor has left and the queue is empty. A path moves at most once, and moving it
-    // does not change its state, so the image is unaffected.
-    const bool q_on = P.collect_every != 0;
-    const bool is_collector = q_on && ((blockIdx.x >> 3) % P.collect_every) == 0;
-    const bool is_donor = q_on && !is_collector;
-    bool q_done = !is_collector;  // collector: the queue is empty and no donor can append any more
-    uint32_t dg_q_given = 0, dg_q_taken = 0, q_idle_spins = 0;
-    bool q_broken = false;  // the queue overflowed (cannot happen): stop using it
-    auto q_load = [&](uint32_t i) { return __hip_atomic_load(P.q_ctr + i * kQueueCtrStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); };
     const size_t npix = size_t(P.n_local_tiles) * 64u;
     const float eps = P.min_dist;
 
@@ -260,118 +245,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (STATS) ++dg_census, dg_dr_rounds += more_work ? 0u : 1u;
         uint32_t n_active = uint32_t(__popcll(__ballot(t_active)));
 
-        // ---- drain phase: donors append their waiting paths to the queue, collectors take from it ----
-        if (!more_work && is_donor && !q_broken) {
-            const uint32_t n_give = cnt[ST_TRAV] + cnt[ST_LAMB] + cnt[ST_METAL] + cnt[ST_DIEL];
-            if (n_give != 0) {
-                uint32_t ng = 0;
-#pragma unroll
-                for (uint32_t g = 0; g < kPoolPad; g += 64) {
-                    const uint32_t st = status[g + lane];
-                    const bool m = st == ST_TRAV || st == ST_LAMB || st == ST_METAL || st == ST_DIEL;
-                    const uint64_t mask = __ballot(m);
-                    if (m) list[ng + lane_rank(mask)] = uint8_t(g + lane);
-                    ng += uint32_t(__popcll(mask));
-                }
-                __syncthreads();
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(P.q_ctr, ng);  // tail: reserves entries [base, base + ng)
-                base = uint32_t(__shfl(int(base), 0));
-                if (base + ng > P.q_capacity) {  // cannot happen (a path moves once); never write out of bounds
-                    if (lane == 0) atomicAdd(&P.counters->diag[23], 1ull << 32);
-                    q_broken = true;  // this wave finishes its paths itself
-                    ng = 0;
-                }
-                for (uint32_t i = lane; i < ng; i += 64) {
-                    const uint32_t slot = list[i];
-                    uint32_t* e = P.q_entries + size_t(base + i) * kQueueEntryDw;
-#pragma unroll
-                    for (uint32_t f = 0; f < uint32_t(kFields); ++f) e[f] = POOL(f, slot);
-                    e[kFields] = status[slot];
-                    const uint32_t n_words = ((POOL(F_META, slot) >> 7) & 127u) >> 2;
-                    for (uint32_t w = 0; w < n_words; ++w)
-                        P.q_seq[size_t(base + i) * kSeqWords + w] = gseq[size_t(slot) * kSeqWords + w];
-                    __threadfence();  // the entry is complete before its flag says so
-                    __hip_atomic_store(e + kFields + 1, P.q_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    status[slot] = ST_EMPTY;
-                }
-                __syncthreads();
-                if (STATS) dg_q_given += ng;
-                if (!q_broken) {
-                    cnt[ST_EMPTY] += ng;
-                    cnt[ST_TRAV] = cnt[ST_LAMB] = cnt[ST_METAL] = cnt[ST_DIEL] = 0;
-                }
-            }
-        } else if (!more_work && !q_done && (cnt[ST_EMPTY] >= 32u || cnt[ST_EMPTY] + n_active >= uint32_t(POOLN))) {
-            const uint32_t want = cnt[ST_EMPTY] < 64u ? cnt[ST_EMPTY] : 64u;
-            // one attempt per scheduling round, straight-line: lane 0 reads the three counters (donors-gone
-            // first: if every donor has left, the tail read after it is final), everybody decides the same way
-            uint32_t gone = 0, t = 0, h = 0;
-            if (lane == 0) {
-                gone = q_load(2);
-                t = q_load(0);
-                h = q_load(1);
-            }
-            gone = uint32_t(__shfl(int(gone), 0));
-            t = uint32_t(__shfl(int(t), 0));
-            h = uint32_t(__shfl(int(h), 0));
-            const uint32_t n_take = h < t ? (want < t - h ? want : t - h) : 0u;
-            uint32_t won = 0;
-            if (n_take != 0 && lane == 0) won = atomicCAS(P.q_ctr + kQueueCtrStride, h, h + n_take) == h ? 1u : 0u;
-            won = uint32_t(__shfl(int(won), 0));
-            const uint32_t base = h;
-            const uint32_t got = won != 0 ? n_take : (h >= t && gone == P.n_donors ? ~0u : 0u);
-            if (got == ~0u) {
-                q_done = true;
-            } else if (got != 0) {
-                uint32_t ne = 0;
-#pragma unroll
-                for (uint32_t g = 0; g < kPoolPad; g += 64) {
-                    const bool m = status[g + lane] == ST_EMPTY;
-                    const uint64_t mask = __ballot(m);
-                    if (m) list[ne + lane_rank(mask)] = uint8_t(g + lane);
-                    ne += uint32_t(__popcll(mask));
-                }
-                __syncthreads();
-                uint32_t took = ST_EMPTY;
-                if (lane < got) {
-                    const uint32_t slot = list[lane];
-                    const uint32_t* e = P.q_entries + size_t(base + lane) * kQueueEntryDw;
-                    // the entry was reserved by a running donor; it is written within microseconds
-                    uint32_t spins = 0;
-                    while (__hip_atomic_load(e + kFields + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != P.q_epoch &&
-                           ++spins < (1u << 22))
-                        __builtin_amdgcn_s_sleep(8);
-                    if (spins >= (1u << 22)) atomicAdd(&P.counters->diag[23], 1ull);  // never seen; tests check it
-                    __threadfence();
-#pragma unroll
-                    for (uint32_t f = 0; f < uint32_t(kFields); ++f) POOL(f, slot) = e[f];
-                    const uint32_t n_words = ((e[F_META] >> 7) & 127u) >> 2;
-                    for (uint32_t w = 0; w < n_words; ++w)
-                        gseq[size_t(slot) * kSeqWords + w] = P.q_seq[size_t(base + lane) * kSeqWords + w];
-                    took = e[kFields];
-                    {   // sanity of what arrived (diagnostic while the queue is new): drop anything malformed
-                        const uint32_t m = e[F_META];
-                        const uint32_t ob = (m >> 14) & 255u;
-                        const uint32_t nr = (m >> 7) & 127u;
-                        bool bad = took < ST_TRAV || took > ST_DIEL || ob > P.n_spheres + P.n_meshes || (m & 127u) > P.max_depth ||
-                                   (took >= ST_LAMB && ob == 0u) || nr > P.max_depth || e[F_ITEM] >= P.n_items;
-                        if (!bad && took >= ST_LAMB) bad = classify(sc, int32_t(ob) - 1, m & 127u) != took;
-                        if (bad) {
-                            atomicAdd(&P.counters->diag[23], 1ull << 16);
-                            took = ST_EMPTY;
-                        }
-                    }
-                    status[slot] = uint8_t(took);
-                }
-                __syncthreads();
-                if (STATS) dg_q_taken += got;
-#pragma unroll
-                for (uint32_t k = ST_TRAV; k < kNumStatus; ++k) cnt[k] += uint32_t(__popcll(__ballot(took == k)));
-                cnt[ST_EMPTY] -= got;
-            }
-        }
-
         // ---- idle lanes take parked rays (in batches: only when enough lanes are idle) ----
         if (cnt[ST_TRAV] != 0 && (n_active < P.y_low_water || n_active + cnt[ST_TRAV] <= 64u)) {
             uint32_t ny = 0;
@@ -422,16 +295,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (cnt[ST_LAMB] > best) kind = ST_LAMB, best = cnt[ST_LAMB];
         if (cnt[ST_METAL] > best) kind = ST_METAL, best = cnt[ST_METAL];
         if (cnt[ST_DIEL] > best) kind = ST_DIEL, best = cnt[ST_DIEL];
-        if (best == 0 && n_active == 0 && cnt[ST_TRAV] == 0) {
-            if (q_done || more_work) break;  // nothing waits, nothing runs, no work left
-            // collector: donors are still finishing their traversals (bounded: ~2 s, then fail loudly)
-            if (++q_idle_spins > (1u << 20)) {
-                if (lane == 0) atomicAdd(&P.counters->diag[23], 1ull);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(64);
-            continue;
-        }
+        if (best == 0 && n_active == 0) break;  // nothing waits, nothing runs, no work left
 
         // Traverse while the lanes are well filled; shade when they are not (that is what parks new
         // rays) or when shading work has piled up to a full wave.
@@ -779,10 +643,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (STATS) dg_t_shade += __builtin_amdgcn_s_memtime() - dg_tk;
     }
 #undef POOL
-    if (is_donor && lane == 0) {  // after this wave's last append
-        __threadfence();
-        __hip_atomic_fetch_add(P.q_ctr + 2 * kQueueCtrStride, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (STATS) {
         atomicAdd(&P.counters->rays, (unsigned long long)lc.rays);
         atomicAdd(&P.counters->mesh_gate_pass, (unsigned long long)lc.gate);
@@ -806,8 +666,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 atomicAdd(&P.counters->diag[53], (unsigned long long)dg_dr_passes);
                 atomicAdd(&P.counters->diag[54], (unsigned long long)dg_dr_lane_steps);
             }
-            atomicAdd(&P.counters->diag[55], (unsigned long long)dg_q_given);
-            atomicAdd(&P.counters->diag[56], (unsigned long long)dg_q_taken);
             atomicAdd(&P.counters->diag[12], (unsigned long long)dg_steps);
             atomicAdd(&P.counters->diag[13], (unsigned long long)dg_lane_steps);
             atomicAdd(&P.counters->diag[14], (unsigned long long)dg_refills);

@@ -194,6 +194,33 @@ def test_batched_accumulation_matches_single_batch(hip, oracle, monkeypatch):
     assert_same_image(a, exp, "13 spp")
 
 
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipelined_launches_match_unpipelined(hip, oracle, monkeypatch, depth):
+    """Frame pipeline (rbrt_hip_scene_set_pipeline): sample batches and successive frames overlap on internal
+    streams; every frame must still be the oracle's image, whatever is in flight around it."""
+    import torch
+    cam = scenes.camera(oracle, 160, 120)
+    sc = scenes.example_scene(oracle, 2003)
+    exp = {seed: oracle.render(cam, sc, abi.default_opts(spp=6, seed=seed))[0] for seed in (3, 4, 5)}
+    monkeypatch.setenv("RBRT_HIP_WORKSPACE_MB", "1")  # 160*120*12 B = 230 KB/sample -> 4 samples per batch -> 2 batches
+    with hip.HipScene(sc) as hs:
+        hs.set_pipeline(depth)
+        imgs = [torch.full((120, 160, 3), float("nan"), dtype=torch.float32, device="cuda") for _ in range(6)]
+        seeds = [3, 4, 5, 3, 5, 4]
+        for img, seed in zip(imgs, seeds):  # six frames queued back to back, no synchronisation in between
+            hs.render_device(cam, abi.default_opts(spp=6, seed=seed), img.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        for k, (img, seed) in enumerate(zip(imgs, seeds)):
+            assert_same_image(img.cpu().numpy(), exp[seed], f"pipelined frame {k} (seed {seed})")
+        # a counting launch in between runs alone and leaves the pipeline usable
+        hs.render_device(cam, abi.default_opts(spp=6, seed=3, flags=abi.FLAG_COLLECT_STATS), imgs[0].data_ptr(), None, None)
+        hs.render_device(cam, abi.default_opts(spp=6, seed=4), imgs[1].data_ptr(), None, None)
+        torch.cuda.synchronize()
+        assert hs.stats()["samples"] == 160 * 120 * 6
+        assert_same_image(imgs[0].cpu().numpy(), exp[3], "counting frame")
+        assert_same_image(imgs[1].cpu().numpy(), exp[4], "frame after the counting frame")
+
+
 def test_stats_counters(hip, oracle):
     import torch
     cam = scenes.camera(oracle, 64, 48)
