@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--vary-seed", type=int, default=0, help="1: every step renders a new frame (seed + step number)")
     ap.add_argument("--triangles", type=int, default=69451)
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
-    ap.add_argument("--cpu-col-stride", type=int, default=16,
+    ap.add_argument("--cpu-col-stride", type=int, default=8,
                     help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline)")
     ap.add_argument("--check", action="store_true", help="also compare the sampled columns with the GPU image")
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="WORLD",
@@ -225,6 +225,8 @@ def main():
         "config": {"workload": f"example_scene.yaml, {args.triangles}-triangle "
                                f"{'bunny.obj' if real_asset else 'stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
+                   "pipeline": f"{args.pipeline} trace launches in flight (consecutive steps overlap; roofline.kernel_ms is "
+                               f"one launch, first wave to last)" if args.pipeline > 1 else "1 (no overlap between steps)",
                    "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,
                    **({"EMULATION_rank0_share_of_world": emu} if emu else {}),
                    "resolve_kernel_ms": round(resolve_ms / max(1, n_launches), 4)},

@@ -176,6 +176,7 @@ __device__ __forceinline__ bool tri_test(V3 v0, V3 ea, V3 eb, V3 o, V3 d, float 
 // equal-t candidates with a lower index reachable.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define RBRT_AS1(T, p) ((const __attribute__((address_space(1))) T*)(p))
 
 struct RayCull {
@@ -271,11 +272,12 @@ __device__ __forceinline__ void leaf_test(const BvhTri* tris, int32_t leaf_ref, 
                                           float& best_t, uint32_t& best_idx, LocalCounters& lc) {
     const uint32_t leaf = uint32_t(~leaf_ref);
     const uint32_t first = leaf >> 2, last = leaf & 3u;  // last = count - 1
-    f32x4 a[4], b[4], c[4];
+    f32x4 a[4], b[4];
+    f32x2 c[4];  // the record's last 8 bytes are padding: not fetched
 #pragma unroll
     for (uint32_t i = 0; i < 4; ++i) {
         const auto* tp = RBRT_AS1(f32x4, tris + first + (i < last ? i : last));
-        a[i] = tp[0], b[i] = tp[1], c[i] = tp[2];
+        a[i] = tp[0], b[i] = tp[1], c[i] = *RBRT_AS1(f32x2, tp + 2);
     }
 #pragma unroll
     for (uint32_t i = 0; i < 4; ++i) {

@@ -438,18 +438,14 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 }
                 if (P.tile_cost && nrec >= P.cost_min_bounces)  // rare: feeds the next frame's tile order
                     atomicAdd(&P.tile_cost[(item % uint32_t(npix)) >> 6], nrec + 1u);
-                if (item >= P.n_items) {  // corrupt path state: never store out of bounds, fail the render loudly
-                    if (atomicAdd(&P.counters->diag[57], 1ull) == 0ull) {
-                        P.counters->diag[58] = item;
-                        P.counters->diag[59] = ((unsigned long long)blockIdx.x << 32) | (slot << 8) | lane;
-                        P.counters->diag[60] = meta;
-                    }
-                    item = 0;
+                if (item < P.n_items) {
+                    float* out = P.sample_buf + size_t(item) * 3u;
+                    out[0] = color.x;
+                    out[1] = color.y;
+                    out[2] = color.z;
+                } else {  // corrupt path state: never store out of bounds; the render call fails loudly (api.cpp)
+                    atomicAdd(&P.counters->diag[57], 1ull);
                 }
-                float* out = P.sample_buf + size_t(item) * 3u;
-                out[0] = color.x;
-                out[1] = color.y;
-                out[2] = color.z;
                 if (STATS) ++n_samples_done;
                 need_new = true;
             }

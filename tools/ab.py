@@ -36,14 +36,14 @@ def main():
                 print(f"[{v}] FAILED rc={p.returncode}: {p.stderr[-400:]}", flush=True)
                 continue
             j = json.loads(p.stdout.strip().splitlines()[-1])
-            res[v].append((j["roofline"]["kernel_ms"], j["value"], j["roofline"]["frac"]))
-            print(f"round {r} [{v}] kernel_ms={j['roofline']['kernel_ms']} value={j['value']} frac={j['roofline']['frac']}",
+            res[v].append((j["roofline"]["kernel_ms"], j["value"], j["roofline"]["frac"], j["ms_per_step"]))
+            print(f"round {r} [{v}] kernel_ms={j['roofline']['kernel_ms']} ms_per_step={j['ms_per_step']} value={j['value']} frac={j['roofline']['frac']}",
                   flush=True)
     print("---- summary (min / median kernel_ms) ----")
     for v, xs in res.items():
         if xs:
             ks = sorted(x[0] for x in xs)
-            print(f"{v:50s} min {ks[0]:.3f}  med {ks[len(ks)//2]:.3f}  value(max) {max(x[1] for x in xs):.1f}")
+            print(f"{v:50s} min {ks[0]:.3f}  med {ks[len(ks)//2]:.3f}  value(max) {max(x[1] for x in xs):.1f}  ms/step(min) {min(x[3] for x in xs):.3f}")
 
 
 if __name__ == "__main__":

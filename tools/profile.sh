@@ -12,7 +12,7 @@ BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-col-stride 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.err" || exit 1
 run_pmc() { # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 2 --warmup 0 --cpu-col-stride 0 \
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 2 --warmup 0 --cpu-col-stride 0 --pipeline 1 \
       > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err" || { echo "pmc pass $name failed"; tail -3 "$OUT/bench_$name.err"; }
 }
 run_pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
