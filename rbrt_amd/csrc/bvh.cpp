@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <limits>
+#include <thread>
 
 namespace rbrt {
 namespace {
@@ -74,11 +76,31 @@ struct ChildInfo {
     float max_e12;
 };
 
+// What a (sub)tree build appends to: binary nodes in DFS pre-order, leaf records in DFS leaf order.
+struct Sink {
+    std::vector<Node2> nodes2;
+    std::vector<BvhTri> tris;
+    uint32_t n_leaves = 0;
+};
+
+// Subtrees below the top of the tree are built by worker threads into sinks of their own and spliced back
+// in DFS order, which reproduces the single-threaded numbering exactly (same arrays for any thread count).
+constexpr int32_t kTaskRefBase = INT32_MIN + 1;  // child refs kTaskRefBase + k stand for task k until the splice
+inline bool is_task_ref(int32_t r) { return r != kNoChild && r < -(int32_t(1) << 30) - 1; }
+
 struct Builder {
     const rbrt_mesh_t& m;
     std::vector<Prim> prims;
     std::vector<Node2> nodes2;
     BvhBuildResult out;
+    struct Task {
+        size_t b, e;
+        int depth;
+        Sink sink;
+        ChildInfo root;
+    };
+    std::vector<Task> tasks;
+    size_t task_grain = 0;  // 0: single-threaded build, no tasks
 
     explicit Builder(const rbrt_mesh_t& mesh) : m(mesh) {}
 
@@ -98,19 +120,29 @@ struct Builder {
         return uint64_t(kLeafMax) << (kMaxInnerDepth - depth + 1);
     }
 
-    ChildInfo make_leaf(size_t b, size_t e, const Box& box, float max_e12) {
-        uint32_t first = uint32_t(out.tris.size());
+    ChildInfo make_leaf(Sink& sk, size_t b, size_t e, const Box& box, float max_e12) {
+        uint32_t first = uint32_t(sk.tris.size());
         uint32_t count = uint32_t(e - b);
         // deterministic order inside a leaf: ascending reference index
         std::sort(prims.begin() + b, prims.begin() + e,
                   [](const Prim& x, const Prim& y) { return x.idx < y.idx; });
-        for (size_t i = b; i < e; ++i) out.tris.push_back(make_tri(prims[i].idx));
-        ++out.n_leaves;
+        for (size_t i = b; i < e; ++i) sk.tris.push_back(make_tri(prims[i].idx));
+        ++sk.n_leaves;
         return ChildInfo{~int32_t((first << 2) | (count - 1)), box, max_e12};
     }
 
-    ChildInfo build_range(size_t b, size_t e, int depth) {
+    // `top`: this call belongs to the single-threaded top of the tree; ranges of at most task_grain
+    // triangles are not built here but queued as tasks (a placeholder ref is returned).
+    ChildInfo build_range(Sink& sk, size_t b, size_t e, int depth, bool top) {
         const size_t count = e - b;
+        if (top && count <= task_grain) {
+            tasks.push_back(Task{b, e, depth, Sink(), ChildInfo()});
+            ChildInfo c;
+            c.ref = kTaskRefBase + int32_t(tasks.size() - 1);
+            c.box.reset();
+            c.max_e12 = 0.0f;
+            return c;  // box and max_e12 are filled in by the splice
+        }
         Box box, cbox;
         box.reset();
         cbox.reset();
@@ -120,7 +152,7 @@ struct Builder {
             cbox.grow(prims[i].c);
             max_e12 = std::max(max_e12, prims[i].e12);
         }
-        if (depth > kMaxInnerDepth || count <= 1) return make_leaf(b, e, box, max_e12);
+        if (depth > kMaxInnerDepth || count <= 1) return make_leaf(sk, b, e, box, max_e12);
 
         // binned SAH over the three axes
         const float parent_area = box.half_area();
@@ -167,7 +199,7 @@ struct Builder {
         float split_cost = std::numeric_limits<float>::infinity();
         if (best_axis >= 0 && parent_area > 0.0f)
             split_cost = cost_traverse() + kCostTri * best_cost / parent_area;
-        if (count <= size_t(kLeafMax) && leaf_cost <= split_cost) return make_leaf(b, e, box, max_e12);
+        if (count <= size_t(kLeafMax) && leaf_cost <= split_cost) return make_leaf(sk, b, e, box, max_e12);
 
         size_t mid = b;
         if (best_axis >= 0) {
@@ -191,16 +223,16 @@ struct Builder {
                                  return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
                              });
         }
-        const uint32_t node = uint32_t(nodes2.size());
-        nodes2.emplace_back();
-        ChildInfo l = build_range(b, mid, depth + 1);
-        ChildInfo r = build_range(mid, e, depth + 1);
-        set_node(node, l, r);
+        const uint32_t node = uint32_t(sk.nodes2.size());
+        sk.nodes2.emplace_back();
+        ChildInfo l = build_range(sk, b, mid, depth + 1, top);
+        ChildInfo r = build_range(sk, mid, e, depth + 1, top);
+        set_node(sk.nodes2, node, l, r);
         return ChildInfo{int32_t(node), box, max_e12};
     }
 
-    void set_node(uint32_t node, const ChildInfo& l, const ChildInfo& r) {
-        Node2& n = nodes2[node];
+    static void set_node(std::vector<Node2>& nodes, uint32_t node, const ChildInfo& l, const ChildInfo& r) {
+        Node2& n = nodes[node];
         for (int k = 0; k < 3; ++k) {
             n.lo0[k] = l.box.lo[k], n.hi0[k] = l.box.hi[k];
             n.lo1[k] = r.box.lo[k], n.hi1[k] = r.box.hi[k];
@@ -209,10 +241,83 @@ struct Builder {
         n.max_e12_0 = l.max_e12, n.max_e12_1 = r.max_e12;
     }
 
+    static int32_t relocate(int32_t ref, uint32_t node_base, uint32_t tri_base) {
+        if (ref >= 0) return int32_t(uint32_t(ref) + node_base);
+        const uint32_t leaf = uint32_t(~ref);
+        return ~int32_t((((leaf >> 2) + tri_base) << 2) | (leaf & 3u));
+    }
+
+    // Appends a finished task's nodes and leaf records to the final arrays; returns its root as the parent sees it.
+    ChildInfo splice_task(Task& t) {
+        const uint32_t node_base = uint32_t(nodes2.size()), tri_base = uint32_t(out.tris.size());
+        for (Node2 n : t.sink.nodes2) {
+            n.child0 = relocate(n.child0, node_base, tri_base);
+            n.child1 = relocate(n.child1, node_base, tri_base);
+            nodes2.push_back(n);
+        }
+        out.tris.insert(out.tris.end(), t.sink.tris.begin(), t.sink.tris.end());
+        out.n_leaves += t.sink.n_leaves;
+        ChildInfo c = t.root;
+        c.ref = relocate(c.ref, node_base, tri_base);
+        t.sink = Sink();  // free early
+        return c;
+    }
+
+    // DFS over the single-threaded top of the tree, in the order the single-threaded build numbers nodes.
+    ChildInfo splice(const Sink& top, int32_t ref, const Box& box, float max_e12) {
+        if (is_task_ref(ref)) return splice_task(tasks[size_t(ref - kTaskRefBase)]);
+        const Node2 src = top.nodes2[size_t(ref)];
+        const uint32_t me = uint32_t(nodes2.size());
+        nodes2.emplace_back();
+        Box b0, b1;
+        for (int k = 0; k < 3; ++k) {
+            b0.lo[k] = src.lo0[k], b0.hi[k] = src.hi0[k];
+            b1.lo[k] = src.lo1[k], b1.hi[k] = src.hi1[k];
+        }
+        const ChildInfo l = splice(top, src.child0, b0, src.max_e12_0);
+        const ChildInfo r = splice(top, src.child1, b1, src.max_e12_1);
+        set_node(nodes2, me, l, r);
+        return ChildInfo{int32_t(me), box, max_e12};
+    }
+
+    ChildInfo build_tree() {
+        unsigned n_threads = std::thread::hardware_concurrency();
+        if (const char* e = std::getenv("RBRT_BVH_THREADS")) n_threads = unsigned(std::max(1, std::atoi(e)));
+        n_threads = std::min(n_threads, 16u);
+        if (n_threads <= 1 || prims.size() < 32768) {
+            Sink sk;
+            sk.nodes2.reserve(prims.size() / 2 + 2);
+            sk.tris.reserve(prims.size() + 2);
+            const ChildInfo root = build_range(sk, 0, prims.size(), 0, false);
+            nodes2 = std::move(sk.nodes2);
+            out.tris = std::move(sk.tris);
+            out.n_leaves = sk.n_leaves;
+            return root;
+        }
+        task_grain = std::max<size_t>(4096, prims.size() / (8u * n_threads));
+        Sink top;
+        const ChildInfo top_root = build_range(top, 0, prims.size(), 0, true);
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
+                Task& t = tasks[k];
+                t.root = build_range(t.sink, t.b, t.e, t.depth, false);  // disjoint prim ranges: no sharing
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+        task_grain = 0;
+        nodes2.reserve(prims.size() / 2 + 2);
+        out.tris.reserve(prims.size() + 2);
+        return splice(top, top_root.ref, top_root.box, top_root.max_e12);
+    }
+
     // A leaf holding one zero-area triangle: |a| = 0 < eps rejects it for every ray
     // (triangle.rs:198-200), so it stands in for "no child".
     ChildInfo make_dummy() {
-        uint32_t first = uint32_t(out.tris.size());
+        uint32_t first = uint32_t(out.tris.size());  // (after the splice: out.tris is final)
         BvhTri t;
         std::memset(&t, 0, sizeof(t));
         t.index = 0xFFFFFFFFu;
@@ -253,18 +358,16 @@ struct Builder {
             prims.push_back(p);
         }
         out.n_indexed = uint32_t(prims.size());
-        nodes2.reserve(prims.size() / 2 + 2);
-        out.tris.reserve(prims.size() + 2);
         if (prims.empty()) {
             nodes2.emplace_back();
             ChildInfo d0 = make_dummy();
-            set_node(0, d0, d0);
+            set_node(nodes2, 0, d0, d0);
         } else {
-            ChildInfo root = build_range(0, prims.size(), 0);
+            ChildInfo root = build_tree();
             if (root.ref < 0) {  // whole mesh fits one leaf
                 nodes2.emplace_back();
                 ChildInfo d = make_dummy();
-                set_node(0, root, d);
+                set_node(nodes2, 0, root, d);
             }
             out.max_e12 = root.max_e12;
         }

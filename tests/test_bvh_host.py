@@ -121,3 +121,15 @@ def test_bvh_culling_keeps_the_brute_force_winner(oracle):
                 if tn <= tf and tf >= eps and tn <= t[r]:  # pruned with the FINAL best t: the hardest case
                     stack.append(int(child[node, k]))
         assert int(tri[r]) in reached, (r, tri[r])
+
+
+def test_threaded_build_equals_single_threaded(oracle, monkeypatch):
+    """Subtrees built by worker threads are spliced back in DFS order: same arrays for any thread count."""
+    md = scenes.standin_mesh(oracle, 70003, **scenes.EXAMPLE_MESH)  # above the 32768-triangle threading threshold
+    monkeypatch.setenv("RBRT_BVH_THREADS", "1")
+    N1, T1, d1, e1 = build(md)
+    for threads in ("2", "5"):
+        monkeypatch.setenv("RBRT_BVH_THREADS", threads)
+        N, T, d, e = build(md)
+        assert d == d1 and e == e1
+        assert np.array_equal(N.view(np.uint32), N1.view(np.uint32)) and np.array_equal(T.view(np.uint32), T1.view(np.uint32))

@@ -19,9 +19,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = ROOT / "profiles"
 out_dir.mkdir(exist_ok=True)
 
-stats = glob.glob(str(SRC / "stats" / "*" / "*kernel_stats.csv"))
+stats = sorted(glob.glob(str(SRC / "stats" / "*" / "*kernel_stats.csv")), key=lambda f: Path(f).stat().st_mtime)
 if stats:
-    shutil.copy(stats[0], out_dir / f"{tag}_kernel_stats.csv")
+    shutil.copy(stats[-1], out_dir / f"{tag}_kernel_stats.csv")
 bench = json.loads((SRC / "bench_stats.json").read_text().strip().splitlines()[-1])
 (out_dir / f"{tag}_bench_under_rocprof.json").write_text(json.dumps(bench, indent=1))
 
