@@ -206,20 +206,21 @@ __device__ __forceinline__ RayCull make_cull(V3 o, V3 d, const float* center, fl
 constexpr uint32_t kMissKey = 0xFFFFFFFFu;
 
 // One child box of a 4-wide node, given its entry planes (nx, ny, nz) and exit planes (fx, fy, fz) for
-// this ray's direction signs and the signed pad (sp_k = pad with the sign of 1/d_k): growing the box
-// moves entry planes against the ray and exit planes with it; one FMA per plane gives the plane's ray
-// parameter. Returns the sort key of the child: kMissKey when the ray misses it, else its entry
-// distance (>= 0, two low mantissa bits replaced by the child slot). An unused slot has NaN planes:
-// every compare fails, it misses. A zero direction component gives inf/NaN parameters on that axis;
-// fmax/fmin ignore a NaN, so the axis can only make the test MORE permissive, which culling tolerates.
-__device__ __forceinline__ uint32_t child_key(float nx, float ny, float nz, float fx, float fy, float fz, V3 sp,
-                                              const RayCull& rc, float eps, float best_t, uint32_t slot) {
-    const float tnx = __builtin_fmaf(nx - sp.x, rc.inv.x, rc.nod.x);
-    const float tny = __builtin_fmaf(ny - sp.y, rc.inv.y, rc.nod.y);
-    const float tnz = __builtin_fmaf(nz - sp.z, rc.inv.z, rc.nod.z);
-    const float tfx = __builtin_fmaf(fx + sp.x, rc.inv.x, rc.nod.x);
-    const float tfy = __builtin_fmaf(fy + sp.y, rc.inv.y, rc.nod.y);
-    const float tfz = __builtin_fmaf(fz + sp.z, rc.inv.z, rc.nod.z);
+// this ray's direction signs. Growing the box by the pad moves entry planes against the ray and exit planes
+// with it; in the ray-parameter domain that is a constant per axis, folded into the FMA's addend by the
+// caller (nodn = nod - pad|1/d|, nodf = nod + pad|1/d|), so one FMA per plane gives the padded plane's
+// parameter. Returns the sort key of the child: kMissKey when the ray misses it, else its entry distance
+// (>= 0, two low mantissa bits replaced by the child slot). An unused slot has NaN planes: every compare
+// fails, it misses. A zero direction component gives inf/NaN parameters on that axis; fmax/fmin ignore a
+// NaN, so the axis can only make the test MORE permissive, which culling tolerates.
+__device__ __forceinline__ uint32_t child_key(float nx, float ny, float nz, float fx, float fy, float fz, V3 inv, V3 nodn,
+                                              V3 nodf, float eps, float best_t, uint32_t slot) {
+    const float tnx = __builtin_fmaf(nx, inv.x, nodn.x);
+    const float tny = __builtin_fmaf(ny, inv.y, nodn.y);
+    const float tnz = __builtin_fmaf(nz, inv.z, nodn.z);
+    const float tfx = __builtin_fmaf(fx, inv.x, nodf.x);
+    const float tfy = __builtin_fmaf(fy, inv.y, nodf.y);
+    const float tfz = __builtin_fmaf(fz, inv.z, nodf.z);
     const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
     const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
     const bool hit = (tn <= tf) && (tf >= eps) && (tn <= best_t);
@@ -246,12 +247,14 @@ __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull&
     // one pad for the node: the largest of its children's error terms (siblings have similar triangles)
     const float pad = __builtin_fmaf(rc.pad_k, __builtin_fmaxf(__builtin_fmaxf(me.x, me.y), __builtin_fmaxf(me.z, me.w)),
                                      rc.pad_base);
-    const V3 sp = mk(__builtin_copysignf(pad, rc.inv.x), __builtin_copysignf(pad, rc.inv.y),
-                     __builtin_copysignf(pad, rc.inv.z));
-    k[0] = child_key(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, sp, rc, eps, best_t, 0u);
-    k[1] = child_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, sp, rc, eps, best_t, 1u);
-    k[2] = child_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, sp, rc, eps, best_t, 2u);
-    k[3] = child_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, sp, rc, eps, best_t, 3u);
+    // the pad in ray-parameter units, per axis (|1/d| may be inf: the plane parameters are then +-inf or NaN,
+    // which only makes the test more permissive)
+    const V3 pt = mk(pad * __builtin_fabsf(rc.inv.x), pad * __builtin_fabsf(rc.inv.y), pad * __builtin_fabsf(rc.inv.z));
+    const V3 nodn = rc.nod - pt, nodf = rc.nod + pt;
+    k[0] = child_key(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, rc.inv, nodn, nodf, eps, best_t, 0u);
+    k[1] = child_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, rc.inv, nodn, nodf, eps, best_t, 1u);
+    k[2] = child_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, rc.inv, nodn, nodf, eps, best_t, 2u);
+    k[3] = child_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, rc.inv, nodn, nodf, eps, best_t, 3u);
     cswap(k[0], k[1]);
     cswap(k[2], k[3]);
     cswap(k[0], k[2]);
