@@ -119,7 +119,7 @@ struct rbrt_hip_scene {
     uint32_t y_low_water = 28;    // RBRT_Y_LOW
     uint32_t leaf_round = 12;     // RBRT_LEAF_ROUND
     uint32_t shade_min = 48;      // RBRT_SHADE_MIN
-    uint32_t shade_rounds = 4;    // RBRT_SHADE_ROUNDS
+    uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
     bool use_wg = false;          // RBRT_KERNEL=wg: one pool per 4-wave workgroup
     uint32_t wg_pool = 448, n_wg = 0;
