@@ -324,3 +324,57 @@ def test_dragon_sized_mesh_cfg4(hip, oracle):
     # and a sub-window of it against the brute-force oracle (108,927 AVX iterations per mesh ray)
     exp, _, _ = oracle.render(cam, sc, abi.default_opts(spp=2, seed=1), window=(500, 532, 300, 316))
     assert np.array_equal(full[300:316, 500:532].view(np.uint32), exp[300:316, 500:532].view(np.uint32))
+
+
+def test_full_size_cfg2_invariants(hip, oracle, monkeypatch):
+    """BASELINE config 2 at full size (1024x768x50, 69,451-triangle stand-in), too big for the brute-force
+    oracle: the image must not depend on the pipeline depth, on the sample-batch size, on the tile
+    sharding, or on the kernel variant; a strided set of columns is compared with the oracle bit for bit."""
+    import hashlib
+
+    import torch
+    W, H, SPP = 1024, 768, 50
+    cam = scenes.camera(oracle, W, H)
+    sc = scenes.example_scene(oracle)
+
+    def sha(t):
+        return hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+
+    img = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    hashes = {}
+    with hip.HipScene(sc) as hs:
+        for depth in (1, 2):
+            hs.set_pipeline(depth)
+            img.fill_(float("nan"))
+            hs.render_device(cam, abi.default_opts(spp=SPP, seed=1), img.data_ptr(), None, None)
+            torch.cuda.synchronize()
+            hashes[f"pipeline {depth}"] = sha(img)
+        ref = img.cpu().numpy().copy()
+        monkeypatch.setenv("RBRT_HIP_WORKSPACE_MB", "100")  # 9.4 MB per sample -> 10 samples per launch -> 5 launches
+        img.fill_(float("nan"))
+        hs.render_device(cam, abi.default_opts(spp=SPP, seed=1), img.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        hashes["5 pipelined batches"] = sha(img)
+        monkeypatch.delenv("RBRT_HIP_WORKSPACE_MB")
+        # two ranks' packed tiles, de-interleaved by the unpack kernel
+        world = 2
+        slot = hip.packed_pixels(W, H, 0, world)
+        slots = torch.full((world * slot * 3,), float("nan"), dtype=torch.float32, device="cuda")
+        for r in range(world):
+            hs.render_device(cam, abi.default_opts(spp=SPP, seed=1, tile_rank=r, tile_world=world),
+                             slots[r * slot * 3:].data_ptr(), None, None)
+        img.fill_(float("nan"))
+        hip.unpack_tiles(0, slots.data_ptr(), W, H, world, img.data_ptr(), None, None, rank_stride_pixels=slot)
+        torch.cuda.synchronize()
+        hashes["2 ranks merged"] = sha(img)
+    monkeypatch.setenv("RBRT_KERNEL", "wg")  # the workgroup-pool variant of the megakernel (read at scene creation)
+    with hip.HipScene(sc) as hs:
+        img.fill_(float("nan"))
+        hs.render_device(cam, abi.default_opts(spp=SPP, seed=1), img.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        hashes["RBRT_KERNEL=wg"] = sha(img)
+    assert len(set(hashes.values())) == 1, hashes
+    assert not np.isnan(ref).any()
+    stride = 64  # 16 columns x 768 rows x 50 spp through the brute-force oracle: a few seconds
+    exp, _, _ = oracle.render(cam, sc, abi.default_opts(spp=SPP, seed=1), want_rgb8=False, col_stride=stride)
+    assert_same_image(ref[:, ::stride], exp[:, ::stride], "config 2, every 64th column")
