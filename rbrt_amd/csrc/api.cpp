@@ -156,6 +156,8 @@ int upload(rbrt_hip_scene* s, const std::vector<T>& host, T** out) {
     return RBRT_OK;
 }
 
+uint32_t div_magic_of(uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : uint32_t(0x100000000ull / d); }  // kernels.hip div_magic
+
 constexpr uint32_t kMaxPipeline = 4;
 
 // Brings s->lanes to s->pipeline entries (streams, events, counters and per-wave scratch of each lane).
@@ -596,6 +598,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     TraceParams P;
     fill_trace_params(s, cam, o, P);
     P.tiles_x = tiles_x, P.tiles_y = tiles_y, P.n_tiles = n_tiles;
+    P.tiles_x_magic = div_magic_of(tiles_x);
     P.tile_rank = o->tile_rank, P.tile_world = world, P.n_local_tiles = n_local;
     {   // tile order: recomputed only when the camera / sharding changes
         std::vector<unsigned char> key(sizeof(rbrt_camera_t) + 2 * sizeof(uint32_t));
@@ -693,6 +696,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         }
         P.sample_base = base;
         P.batch = nb;
+        P.batch_magic = div_magic_of(nb);
         P.n_items = uint64_t(npix) * nb;
         P.sample_buf = L.d_sample_buf;
         P.work_counter = L.d_work_counter;

@@ -175,6 +175,16 @@ __device__ __forceinline__ bool tri_test(V3 v0, V3 ea, V3 eb, V3 o, V3 d, float 
 // product of the FMA form), the slab interval contains t, and `tn <= best_t` (not <) keeps
 // equal-t candidates with a lower index reachable.
 // ---------------------------------------------------------------------------------------------
+// n / d for a launch-constant divisor: m = floor(2^32 / d) (host, div_magic_of) under-estimates the quotient by
+// at most 2, fixed by two conditional steps; ~8 instructions instead of the ~40 of a 32-bit division.
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t d, uint32_t m) {
+    uint32_t q = __umulhi(n, m);
+    uint32_t r = n - q * d;
+    if (r >= d) ++q, r -= d;
+    if (r >= d) ++q;
+    return q;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define RBRT_AS1(T, p) ((const __attribute__((address_space(1))) T*)(p))

@@ -465,11 +465,12 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     if (rk < avail || it < new_hi) {
                         const uint32_t pp = it & 63u;
                         const uint32_t ts = it >> 6;
-                        const uint32_t s = ts % P.batch;
-                        const uint32_t tile_local = P.tile_order[ts / P.batch];  // costly tiles are handed out first
+                        const uint32_t tpos = div_magic(ts, P.batch, P.batch_magic);
+                        const uint32_t s = ts - tpos * P.batch;
+                        const uint32_t tile_local = P.tile_order[tpos];  // costly tiles are handed out first
                         item = s * uint32_t(npix) + tile_local * 64u + pp;       // < 2^32: the host sizes batches so
                         const uint32_t tile = tile_local * P.tile_world + P.tile_rank;
-                        const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+                        const uint32_t ty = div_magic(tile, P.tiles_x, P.tiles_x_magic), tx = tile - ty * P.tiles_x;
                         const uint32_t row = ty * RBRT_TILE + (pp >> 3), col = tx * RBRT_TILE + (pp & 7u);
                         if (row < P.cam.img_height_pix && col < P.cam.img_width_pix) {
                             rng.init(P.seed_key, row * P.cam.img_width_pix + col, P.sample_base + s);
