@@ -117,6 +117,7 @@ struct rbrt_hip_scene {
     uint32_t pool = 128;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
     uint32_t stack_entries = kLdsStack;  // per-lane stack entries kept in LDS (RBRT_LDS_STACK)
     uint32_t y_low_water = 28;    // RBRT_Y_LOW
+    uint32_t y_high_water = 28, y_high_min_parked = 16;  // RBRT_Y_HIGH, RBRT_Y_HIGH_PARKED
     uint32_t leaf_round = 12;     // RBRT_LEAF_ROUND
     uint32_t shade_min = 48;      // RBRT_SHADE_MIN
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
@@ -439,6 +440,14 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             int v = std::atoi(e);
             if (v >= 1 && v <= 64) s->leaf_round = uint32_t(v);
         }
+        if (const char* e = std::getenv("RBRT_Y_HIGH")) {
+            int v = std::atoi(e);
+            if (v >= 1 && v <= 64) s->y_high_water = uint32_t(v);
+        }
+        if (const char* e = std::getenv("RBRT_Y_HIGH_PARKED")) {
+            int v = std::atoi(e);
+            if (v >= 1 && v <= 256) s->y_high_min_parked = uint32_t(v);
+        }
         if (const char* e = std::getenv("RBRT_Y_LOW")) {
             int v = std::atoi(e);
             if (v >= 1 && v <= 64) s->y_low_water = uint32_t(v);
@@ -648,6 +657,8 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     }
     P.stack_entries = s->stack_entries;
     P.y_low_water = s->y_low_water;
+    P.y_high_water = s->y_high_water < s->y_low_water ? s->y_low_water : s->y_high_water;
+    P.y_high_min_parked = s->y_high_min_parked;
     P.leaf_round = s->leaf_round;
     P.shade_min = s->shade_min;
     P.shade_rounds = s->shade_rounds;

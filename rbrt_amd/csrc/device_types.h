@@ -119,6 +119,7 @@ struct TraceParams {
     uint32_t stack_entries;            // per-lane traversal stack entries kept in LDS (<= stack_need)
     uint32_t* gstack;                  // [n_waves][kStackMax][64] overflow of the LDS stacks
     uint32_t y_low_water;              // refill a traversal pass when fewer lanes than this are busy
+    uint32_t y_high_water, y_high_min_parked;  // ... or fewer than y_high_water while at least that many rays are parked
     uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one
     uint32_t shade_min;                // workgroup-pool kernel: let a shading queue fill to this depth while lanes can traverse
     uint32_t shade_rounds;             // shading pass: rounds a sphere-only bounce chain may stay in registers

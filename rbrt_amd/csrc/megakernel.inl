@@ -246,7 +246,9 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         uint32_t n_active = uint32_t(__popcll(__ballot(t_active)));
 
         // ---- idle lanes take parked rays (in batches: only when enough lanes are idle) ----
-        if (cnt[ST_TRAV] != 0 && (n_active < P.y_low_water || n_active + cnt[ST_TRAV] <= 64u)) {
+        // with plenty of parked rays the lanes are topped up sooner (y_high_water) than when few wait
+        const uint32_t y_refill = cnt[ST_TRAV] >= P.y_high_min_parked ? P.y_high_water : P.y_low_water;
+        if (cnt[ST_TRAV] != 0 && (n_active < y_refill || n_active + cnt[ST_TRAV] <= 64u)) {
             uint32_t ny = 0;
 #pragma unroll
             for (uint32_t g = 0; g < kPoolPad; g += 64) {
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             }
             // leave as soon as enough lanes are idle to make a refill / shading pass worthwhile; when no
             // other work exists, as soon as one lane has a result (it creates shading work)
-            const uint32_t keep = (best != 0 || cnt[ST_TRAV] != 0) ? (n_active < P.y_low_water ? n_active : P.y_low_water)
+            const uint32_t y_keep = cnt[ST_TRAV] >= P.y_high_min_parked ? P.y_high_water : P.y_low_water;
+            const uint32_t keep = (best != 0 || cnt[ST_TRAV] != 0) ? (n_active < y_keep ? n_active : y_keep)
                                                                    : n_active;
             do {
                 if (STATS) {
