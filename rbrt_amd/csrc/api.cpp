@@ -100,18 +100,6 @@ struct rbrt_hip_scene {
     float* d_acc = nullptr;
     size_t acc_bytes = 0;
     bool poison_samples = false;      // RBRT_POISON_SAMPLES
-    // host copy of what the tile-cost heuristic needs, and the cached tile order
-    std::vector<rbrt_sphere_t> h_spheres;
-    struct HostMesh {
-        float lo[3], hi[3];
-        int32_t kind;
-    };
-    std::vector<HostMesh> h_meshes;
-    uint32_t* d_tile_order = nullptr;
-    uint32_t* d_tile_cost = nullptr;  // rays of each tile's long paths, summed over the frames so far
-    size_t tile_order_cap = 0;
-    std::vector<unsigned char> tile_order_key;
-    uint32_t cost_frames = 0;         // frames that have fed d_tile_cost under the current key
     uint32_t stack_need = 1;  // deepest BVH: 3 per level + 1
     uint32_t n_waves = 0;  // persistent megakernel grid: as many single-wave workgroups as fit the LDS
     uint32_t pool = 128;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
@@ -212,91 +200,6 @@ int fill_trace_params(const rbrt_hip_scene* s, const rbrt_camera_t* cam, const r
 }
 
 
-// Scheduling heuristic only (never affects the image): order this rank's tiles so that the ones whose
-// paths are expected to be long (they look at glass or metal, or at a mesh) are handed out FIRST. A path
-// is a serial chain of up to 51 bounces (~20 us each when it runs alone), so one long path that starts
-// late keeps the kernel alive for ~1 ms after everything else has finished; started first it overlaps
-// with the bulk of the work. The tiles are then dealt round-robin to the kWorkShards counter shards so
-// that every shard starts with its share of costly tiles.
-std::vector<uint32_t> compute_tile_order(const rbrt_hip_scene* s, const rbrt_camera_t& cam, uint32_t tiles_x,
-                                         uint32_t n_tiles, uint32_t rank, uint32_t world, uint32_t n_local,
-                                         const uint32_t* measured) {
-    struct Scored {
-        uint32_t tile_local;
-        float score;
-        uint32_t measured;
-    };
-    std::vector<Scored> v(n_local);
-    const double px = cam.position[0], py = cam.position[1], pz = cam.position[2];
-    for (uint32_t tl = 0; tl < n_local; ++tl) {
-        const uint32_t tile = tl * world + rank;
-        const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
-        const double col = tx * RBRT_TILE + 0.5 * RBRT_TILE, row = ty * RBRT_TILE + 0.5 * RBRT_TILE;
-        const double col_mm = (col - double(cam.img_width_pix / 2)) * cam.mm_per_pix_hor;
-        const double row_mm = (row - double(cam.img_height_pix / 2)) * cam.mm_per_pix_vert;
-        double d[3], o[3] = {px, py, pz};
-        for (int c = 0; c < 3; ++c)
-            d[c] = (cam.img_center_point[c] + 0.001 * col_mm * cam.right[c] - 0.001 * row_mm * cam.up[c]) - cam.position[c];
-        float score = 0.0f;
-        for (const auto& m : s->h_meshes) {  // the mesh gate with a margin of one tile
-            double tn = -1e300, tf = 1e300;
-            for (int c = 0; c < 3; ++c) {
-                const double inv = 1.0 / d[c];
-                double t0 = (m.lo[c] - o[c]) * inv, t1 = (m.hi[c] - o[c]) * inv;
-                if (t0 > t1) std::swap(t0, t1);
-                if (t0 == t0 && t0 > tn) tn = t0;
-                if (t1 == t1 && t1 < tf) tf = t1;
-            }
-            if (tf >= 0.0 && tn <= tf * 1.05 + 1e-9)
-                score += m.kind == RBRT_MAT_DIELECTRIC ? 64.0f : (m.kind == RBRT_MAT_METAL ? 8.0f : 4.0f);
-        }
-        for (const auto& sp : s->h_spheres) {
-            const double l[3] = {o[0] - sp.center[0], o[1] - sp.center[1], o[2] - sp.center[2]};
-            const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            const double b = 2.0 * (d[0] * l[0] + d[1] * l[1] + d[2] * l[2]);
-            const double r = double(sp.radius) * 1.1;
-            const double c = l[0] * l[0] + l[1] * l[1] + l[2] * l[2] - r * r;
-            if (b * b - 4.0 * a * c >= 0.0 && -b + std::sqrt(b * b - 4.0 * a * c) > 0.0)
-                score += sp.mat.kind == RBRT_MAT_DIELECTRIC ? 16.0f : (sp.mat.kind == RBRT_MAT_METAL ? 6.0f : 1.0f);
-        }
-        v[tl] = Scored{tl, score, measured ? measured[tl] : 0u};
-    }
-    static const bool sort_tiles = [] {
-        const char* e = std::getenv("RBRT_TILE_ORDER");
-        return !(e && e[0] == '0');
-    }();
-    if (!sort_tiles) {
-        std::vector<uint32_t> ident(n_local);
-        for (uint32_t i = 0; i < n_local; ++i) ident[i] = i;
-        return ident;
-    }
-    // measured long-path work of earlier frames first (when there is any), the geometric guess as tie-break
-    const auto costlier = [](const Scored& a, const Scored& b) {
-        return a.measured != b.measured ? a.measured > b.measured : a.score > b.score;
-    };
-    static const bool bands = [] {
-        const char* e = std::getenv("RBRT_TILE_DEAL");
-        return e && e[0] == 'b';
-    }();
-    if (bands) {  // every shard keeps its contiguous band of the image (L2 locality) and orders it costly-first
-        std::vector<uint32_t> order;
-        order.reserve(n_local);
-        for (uint32_t k = 0; k < kWorkShards; ++k) {
-            const auto b = v.begin() + size_t(n_local) * k / kWorkShards, e = v.begin() + size_t(n_local) * (k + 1) / kWorkShards;
-            std::stable_sort(b, e, costlier);
-            for (auto it = b; it != e; ++it) order.push_back(it->tile_local);
-        }
-        return order;
-    }
-    std::stable_sort(v.begin(), v.end(), costlier);
-    std::vector<uint32_t> order;
-    order.reserve(n_local);
-    for (uint32_t k = 0; k < kWorkShards; ++k)
-        for (uint32_t j = k; j < n_local; j += kWorkShards) order.push_back(v[j].tile_local);
-    (void)n_tiles;
-    return order;
-}
-
 }  // namespace
 
 extern "C" {
@@ -363,13 +266,6 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         return rc;
     };
 
-    s->h_spheres.assign(scene->spheres, scene->spheres + scene->n_spheres);
-    for (uint32_t i = 0; i < scene->n_meshes; ++i) {
-        rbrt_hip_scene::HostMesh hm;
-        for (int c = 0; c < 3; ++c) hm.lo[c] = scene->meshes[i].bbox_lo[c], hm.hi[c] = scene->meshes[i].bbox_hi[c];
-        hm.kind = scene->meshes[i].mat.kind;
-        s->h_meshes.push_back(hm);
-    }
     std::vector<DevSphere> spheres(scene->n_spheres);
     std::vector<DevMaterial> mats(scene->n_spheres + scene->n_meshes);
     auto put_mat = [&](size_t k, const rbrt_material_t& m) {
@@ -512,8 +408,6 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     }
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->d_acc) (void)hipFree(s->d_acc);
-    if (s->d_tile_order) (void)hipFree(s->d_tile_order);
-    if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     delete s;
     return RBRT_OK;
@@ -609,52 +503,6 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     P.tiles_x = tiles_x, P.tiles_y = tiles_y, P.n_tiles = n_tiles;
     P.tiles_x_magic = div_magic_of(tiles_x);
     P.tile_rank = o->tile_rank, P.tile_world = world, P.n_local_tiles = n_local;
-    {   // tile order: recomputed only when the camera / sharding changes
-        std::vector<unsigned char> key(sizeof(rbrt_camera_t) + 2 * sizeof(uint32_t));
-        std::memcpy(key.data(), cam, sizeof(rbrt_camera_t));
-        std::memcpy(key.data() + sizeof(rbrt_camera_t), &o->tile_rank, sizeof(uint32_t));
-        std::memcpy(key.data() + sizeof(rbrt_camera_t) + sizeof(uint32_t), &world, sizeof(uint32_t));
-        static const bool feedback = [] {
-            const char* e = std::getenv("RBRT_TILE_FEEDBACK");
-            return !(e && e[0] == '0');
-        }();
-        const bool rekey = key != s->tile_order_key || !s->d_tile_order;
-        // Feedback: the kernel sums the rays of each tile's long paths into d_tile_cost; after 1, 2, 4, ...
-        // 64 frames under the same camera and sharding the order is rebuilt from those sums.
-        const bool refresh = !rekey && feedback && s->cost_frames >= 1 && s->cost_frames <= 64 &&
-                             (s->cost_frames & (s->cost_frames - 1)) == 0;
-        if (rekey || refresh) {
-            if (n_local > s->tile_order_cap) {
-                if (int rc = sync_lanes()) return rc;
-                if (s->d_tile_order) HIP_TRY(hipFree(s->d_tile_order));
-                if (s->d_tile_cost) HIP_TRY(hipFree(s->d_tile_cost));
-                s->d_tile_order = s->d_tile_cost = nullptr;
-                void* p = nullptr;
-                HIP_TRY(hipMalloc(&p, size_t(n_local) * sizeof(uint32_t)));
-                s->d_tile_order = static_cast<uint32_t*>(p);
-                HIP_TRY(hipMalloc(&p, size_t(n_local) * sizeof(uint32_t)));
-                s->d_tile_cost = static_cast<uint32_t*>(p);
-                s->tile_order_cap = n_local;
-            }
-            if (int rc = sync_lanes()) return rc;  // a previous launch may still be using both arrays
-            std::vector<uint32_t> measured;
-            if (refresh) {
-                measured.resize(n_local);
-                HIP_TRY(hipMemcpy(measured.data(), s->d_tile_cost, size_t(n_local) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            } else {
-                HIP_TRY(hipMemset(s->d_tile_cost, 0, size_t(n_local) * sizeof(uint32_t)));
-                s->cost_frames = 0;
-            }
-            const std::vector<uint32_t> order = compute_tile_order(s, *cam, tiles_x, n_tiles, o->tile_rank, world, n_local,
-                                                                   refresh ? measured.data() : nullptr);
-            HIP_TRY(hipMemcpy(s->d_tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            s->tile_order_key = key;
-        }
-        P.tile_cost = feedback && s->cost_frames < 64 ? s->d_tile_cost : nullptr;
-        P.cost_min_bounces = 8;
-        if (P.tile_cost) ++s->cost_frames;
-        P.tile_order = s->d_tile_order;
-    }
     P.stack_entries = s->stack_entries;
     P.y_low_water = s->y_low_water;
     P.y_high_water = s->y_high_water < s->y_low_water ? s->y_low_water : s->y_high_water;

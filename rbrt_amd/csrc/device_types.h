@@ -108,9 +108,6 @@ struct TraceParams {
     uint32_t batch;         // samples in this batch
     uint32_t batch_magic, tiles_x_magic;  // floor(2^32 / d) (d = 1: 2^32 - 1) for div_magic() in the kernels
     uint64_t n_items;       // n_local_tiles * 64 * batch
-    const uint32_t* tile_order;  // [n_local_tiles] local tile ids, estimated-costly first (scheduling only)
-    uint32_t* tile_cost;         // [n_local_tiles] rays of this tile's long paths, or null (scheduling feedback)
-    uint32_t cost_min_bounces;   // a path feeds tile_cost once it has this many bounces
     float* sample_buf;      // [batch][n_local_tiles*64][3]
     DevCounters* counters;
     // persistent megakernel only

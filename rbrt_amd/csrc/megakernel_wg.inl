@@ -356,8 +356,6 @@ __global__ __launch_bounds__(64 * WAVES, RBRT_MK_WAVES_PER_SIMD) void trace_mega
                     }
                 }
                 item = WPOOL(F_ITEM, slot);  // index of this path's sample in the sample buffer
-                if (P.tile_cost && nrec >= P.cost_min_bounces)  // rare: feeds the next frame's tile order
-                    atomicAdd(&P.tile_cost[(item % uint32_t(npix)) >> 6], nrec + 1u);
                 float* out = P.sample_buf + size_t(item) * 3u;
                 out[0] = color.x;
                 out[1] = color.y;
@@ -380,7 +378,7 @@ __global__ __launch_bounds__(64 * WAVES, RBRT_MK_WAVES_PER_SIMD) void trace_mega
                         const uint32_t ts = it >> 6;
                         const uint32_t tpos = div_magic(ts, P.batch, P.batch_magic);
                         const uint32_t s = ts - tpos * P.batch;
-                        const uint32_t tile_local = P.tile_order[tpos];  // costly tiles are handed out first
+                        const uint32_t tile_local = tpos;  // this rank's tiles in row-major order
                         item = s * uint32_t(npix) + tile_local * 64u + pp;       // < 2^32: the host sizes batches so
                         const uint32_t tile = tile_local * P.tile_world + P.tile_rank;
                         const uint32_t ty = div_magic(tile, P.tiles_x, P.tiles_x_magic), tx = tile - ty * P.tiles_x;
