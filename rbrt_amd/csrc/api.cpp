@@ -100,6 +100,11 @@ struct rbrt_hip_scene {
     float* d_acc = nullptr;
     size_t acc_bytes = 0;
     bool poison_samples = false;      // RBRT_POISON_SAMPLES
+    // host copy of the objects' bounds, for the tile-direction choice below
+    struct Bound {
+        float lo[3], hi[3];
+    };
+    std::vector<Bound> h_bounds;
     uint32_t stack_need = 1;  // deepest BVH: 3 per level + 1
     uint32_t n_waves = 0;  // persistent megakernel grid: as many single-wave workgroups as fit the LDS
     uint32_t pool = 128;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
@@ -200,6 +205,41 @@ int fill_trace_params(const rbrt_hip_scene* s, const rbrt_camera_t* cam, const r
 }
 
 
+// Scheduling only (never affects the image). A launch ends with every wave finishing the paths it still
+// holds; that costs least when the last tiles handed out are cheap ones (primary rays that hit nothing end
+// after one ray). Tiles go out in row-major order; this looks at the first and the last eighth of the rank's
+// tiles (the size of one work shard) and says whether the EMPTY end is the first one, in which case the kernel
+// walks the tiles backwards. One primary ray per tile centre against the objects' bounding boxes.
+bool empty_end_is_first(const rbrt_hip_scene* s, const rbrt_camera_t& cam, uint32_t tiles_x, uint32_t rank, uint32_t world,
+                        uint32_t n_local) {
+    const auto tile_hits = [&](uint32_t tl) {
+        const uint32_t tile = tl * world + rank;
+        const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
+        const double col = tx * RBRT_TILE + 0.5 * RBRT_TILE, row = ty * RBRT_TILE + 0.5 * RBRT_TILE;
+        const double col_mm = (col - double(cam.img_width_pix / 2)) * cam.mm_per_pix_hor;
+        const double row_mm = (row - double(cam.img_height_pix / 2)) * cam.mm_per_pix_vert;
+        double d[3];
+        for (int c = 0; c < 3; ++c)
+            d[c] = (cam.img_center_point[c] + 0.001 * col_mm * cam.right[c] - 0.001 * row_mm * cam.up[c]) - cam.position[c];
+        for (const auto& b : s->h_bounds) {
+            double tn = 0.0, tf = 1e300;
+            for (int c = 0; c < 3; ++c) {
+                const double inv = 1.0 / d[c];
+                double t0 = (b.lo[c] - cam.position[c]) * inv, t1 = (b.hi[c] - cam.position[c]) * inv;
+                if (t0 > t1) std::swap(t0, t1);
+                if (t0 == t0 && t0 > tn) tn = t0;
+                if (t1 == t1 && t1 < tf) tf = t1;
+            }
+            if (tn <= tf) return true;
+        }
+        return false;
+    };
+    const uint32_t n_probe = std::max<uint32_t>(1, n_local / kWorkShards);
+    uint32_t first = 0, last = 0;
+    for (uint32_t i = 0; i < n_probe; ++i) first += tile_hits(i) ? 1u : 0u, last += tile_hits(n_local - 1u - i) ? 1u : 0u;
+    return first < last;
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,6 +306,17 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         return rc;
     };
 
+    for (uint32_t i = 0; i < scene->n_spheres; ++i) {
+        rbrt_hip_scene::Bound b;
+        for (int c = 0; c < 3; ++c)
+            b.lo[c] = scene->spheres[i].center[c] - scene->spheres[i].radius, b.hi[c] = scene->spheres[i].center[c] + scene->spheres[i].radius;
+        s->h_bounds.push_back(b);
+    }
+    for (uint32_t i = 0; i < scene->n_meshes; ++i) {
+        rbrt_hip_scene::Bound b;
+        for (int c = 0; c < 3; ++c) b.lo[c] = scene->meshes[i].bbox_lo[c], b.hi[c] = scene->meshes[i].bbox_hi[c];
+        s->h_bounds.push_back(b);
+    }
     std::vector<DevSphere> spheres(scene->n_spheres);
     std::vector<DevMaterial> mats(scene->n_spheres + scene->n_meshes);
     auto put_mat = [&](size_t k, const rbrt_material_t& m) {
@@ -502,6 +553,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     fill_trace_params(s, cam, o, P);
     P.tiles_x = tiles_x, P.tiles_y = tiles_y, P.n_tiles = n_tiles;
     P.tiles_x_magic = div_magic_of(tiles_x);
+    P.tiles_reversed = empty_end_is_first(s, *cam, tiles_x, o->tile_rank, world, n_local) ? 1u : 0u;
     P.tile_rank = o->tile_rank, P.tile_world = world, P.n_local_tiles = n_local;
     P.stack_entries = s->stack_entries;
     P.y_low_water = s->y_low_water;

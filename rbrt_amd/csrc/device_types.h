@@ -106,6 +106,7 @@ struct TraceParams {
     uint32_t tile_rank, tile_world, n_local_tiles;
     uint32_t sample_base;   // first sample index of this batch
     uint32_t batch;         // samples in this batch
+    uint32_t tiles_reversed;  // 1: tiles are handed out last-to-first (scheduling only, see api.cpp empty_end_is_first)
     uint32_t batch_magic, tiles_x_magic;  // floor(2^32 / d) (d = 1: 2^32 - 1) for div_magic() in the kernels
     uint64_t n_items;       // n_local_tiles * 64 * batch
     float* sample_buf;      // [batch][n_local_tiles*64][3]

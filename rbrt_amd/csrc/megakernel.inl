@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         const uint32_t ts = it >> 6;
                         const uint32_t tpos = div_magic(ts, P.batch, P.batch_magic);
                         const uint32_t s = ts - tpos * P.batch;
-                        const uint32_t tile_local = tpos;  // this rank's tiles in row-major order
+                        const uint32_t tile_local = P.tiles_reversed ? P.n_local_tiles - 1u - tpos : tpos;  // row-major, either way
                         item = s * uint32_t(npix) + tile_local * 64u + pp;       // < 2^32: the host sizes batches so
                         const uint32_t tile = tile_local * P.tile_world + P.tile_rank;
                         const uint32_t ty = div_magic(tile, P.tiles_x, P.tiles_x_magic), tx = tile - ty * P.tiles_x;
