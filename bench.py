@@ -47,9 +47,9 @@ def parse_args():
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--spp", type=int, default=50)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=0,
                     help="frame pipeline depth (rbrt_hip_scene_set_pipeline): consecutive steps' trace launches overlap "
-                         "on this many internal streams")
+                         "on this many internal streams; 0 = the library's automatic choice (2, or 3 for short launches)")
     ap.add_argument("--vary-seed", type=int, default=0, help="1: every step renders a new frame (seed + step number)")
     ap.add_argument("--triangles", type=int, default=69451)
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
@@ -225,8 +225,9 @@ def main():
         "config": {"workload": f"example_scene.yaml, {args.triangles}-triangle "
                                f"{'bunny.obj' if real_asset else 'stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
-                   "pipeline": f"{args.pipeline} trace launches in flight (consecutive steps overlap; roofline.kernel_ms is "
-                               f"one launch, first wave to last)" if args.pipeline > 1 else "1 (no overlap between steps)",
+                   "pipeline": (f"{args.pipeline or 'auto: 2 or 3'} trace launches in flight (consecutive steps overlap; "
+                                f"roofline.kernel_ms is one launch, first wave to last)") if args.pipeline != 1
+                   else "1 (no overlap between steps)",
                    "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,
                    **({"EMULATION_rank0_share_of_world": emu} if emu else {}),
                    # (with the pipeline on, the resolve waits on another stream: its event pair measures that wait)

@@ -94,7 +94,7 @@ struct rbrt_hip_scene {
         bool in_use = false;  // ev_resolved has been recorded at least once
     };
     std::vector<Lane> lanes;
-    uint32_t pipeline = 2;   // RBRT_PIPELINE / rbrt_hip_scene_set_pipeline
+    uint32_t pipeline = 0;   // RBRT_PIPELINE / rbrt_hip_scene_set_pipeline; 0 = automatic (depth_for)
     uint32_t scratch_waves = 0;
     uint32_t next_lane = 0;
     float* d_acc = nullptr;
@@ -154,9 +154,17 @@ uint32_t div_magic_of(uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : uint32_t(0x100
 
 constexpr uint32_t kMaxPipeline = 4;
 
-// Brings s->lanes to s->pipeline entries (streams, events, counters and per-wave scratch of each lane).
-int ensure_lanes(rbrt_hip_scene* s) {
-    while (s->lanes.size() < s->pipeline) {
+// Depth of the frame pipeline for launches of `samples` (pixel, sample) items each: what was set, or, in
+// automatic mode, 2 -- and 3 for short launches (a GPU's share of a sharded frame), whose fixed-cost drain is
+// the larger part of them (measured: 1.07 vs 1.18 ms per step for an eighth of config 2, no gain at a quarter).
+uint32_t depth_for(const rbrt_hip_scene* s, uint64_t samples) {
+    if (s->pipeline != 0) return s->pipeline;
+    return samples < 8000000ull ? 3u : 2u;
+}
+
+// Brings s->lanes to `depth` entries (streams, events, counters and per-wave scratch of each lane).
+int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
+    while (s->lanes.size() < depth) {
         rbrt_hip_scene::Lane L;
         void* p = nullptr;
         const size_t counter_bytes = sizeof(unsigned long long) * kWorkShards * kWorkCounterStride;
@@ -438,9 +446,9 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         s->scratch_waves = uint32_t(cus) * 32u;  // both kernel variants index scratch by wave / workgroup
         if (const char* e = std::getenv("RBRT_PIPELINE")) {
             int v = std::atoi(e);
-            if (v >= 1 && v <= int(kMaxPipeline)) s->pipeline = uint32_t(v);
+            if (v >= 0 && v <= int(kMaxPipeline)) s->pipeline = uint32_t(v);
         }
-        if (int rc = ensure_lanes(s)) return bail(rc);
+        if (int rc = ensure_lanes(s, s->pipeline ? s->pipeline : 2u)) return bail(rc);
         if (const char* e = std::getenv("RBRT_POISON_SAMPLES")) s->poison_samples = e[0] == '1';
     }
     *out = s;
@@ -521,7 +529,8 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     if (batch < 1) batch = 1;
     if (batch > o->spp) batch = o->spp;
     const size_t need = batch * per_sample;
-    if (int rc = ensure_lanes(s)) return rc;
+    const uint32_t depth = depth_for(s, uint64_t(npix) * batch);
+    if (int rc = ensure_lanes(s, depth)) return rc;
     const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
         HIP_TRY(hipStreamSynchronize(stream));
         for (auto& L : s->lanes) HIP_TRY(hipStreamSynchronize(L.stream));
@@ -586,8 +595,8 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         const uint32_t base = uint32_t(b * batch);
         const uint32_t nb = uint32_t(std::min<size_t>(batch, o->spp - base));
         // counting launches run alone on lane 0: their counters are reset and read on the caller's stream
-        rbrt_hip_scene::Lane& L = s->lanes[stats ? 0 : s->next_lane++ % s->pipeline];
-        const bool piped = s->pipeline > 1 && !stats;
+        rbrt_hip_scene::Lane& L = s->lanes[stats ? 0 : s->next_lane++ % depth];
+        const bool piped = depth > 1 && !stats;
         hipStream_t ts = piped ? L.stream : stream;  // the trace launch's stream
         if (need > L.sample_buf_bytes) {
             if (L.d_sample_buf) {
@@ -602,7 +611,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         if (piped) {
             // this lane's sample buffer is free once the resolve of its previous launch has run
             if (L.in_use) HIP_TRY(hipStreamWaitEvent(L.stream, L.ev_resolved, 0));
-        } else if (s->pipeline > 1) {
+        } else if (depth > 1) {
             if (int rc = sync_lanes()) return rc;  // a counting launch: nothing else in flight
         }
         P.sample_base = base;
@@ -631,7 +640,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         R.first_batch = b == 0;
         R.last_batch = b + 1 == n_batches;
         HIP_TRY(launch_resolve(R, stream));
-        if (s->pipeline > 1) {  // (also after a counting launch: it used lane 0's buffers on the caller's stream)
+        if (depth > 1) {  // (also after a counting launch: it used lane 0's buffers on the caller's stream)
             HIP_TRY(hipEventRecord(L.ev_resolved, stream));
             L.in_use = true;
         }
@@ -645,12 +654,12 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
 
 int rbrt_hip_scene_set_pipeline(rbrt_hip_scene_t* s, uint32_t depth) {
     if (!s) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: null scene");
-    if (depth < 1 || depth > kMaxPipeline) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: depth must be 1..4");
+    if (depth > kMaxPipeline) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: depth must be 0 (automatic) or 1..4");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     s->pipeline = depth;
     s->next_lane = 0;
-    return ensure_lanes(s);
+    return ensure_lanes(s, depth ? depth : 2u);
 }
 
 int rbrt_hip_scene_stats(rbrt_hip_scene_t* s, rbrt_hip_stats_t* out) {
