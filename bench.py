@@ -176,6 +176,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    enqueue_s = time.perf_counter() - t0  # host time to issue the steps (they run asynchronously)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -228,6 +229,7 @@ def main():
                    "pipeline": (f"{args.pipeline or 'auto: 2 or 3'} trace launches in flight (consecutive steps overlap; "
                                 f"roofline.kernel_ms is one launch, first wave to last)") if args.pipeline != 1
                    else "1 (no overlap between steps)",
+                   "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                    "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,
                    **({"EMULATION_rank0_share_of_world": emu} if emu else {}),
                    # (with the pipeline on, the resolve waits on another stream: its event pair measures that wait)

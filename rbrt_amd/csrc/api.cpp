@@ -96,6 +96,8 @@ struct rbrt_hip_scene {
     std::vector<Lane> lanes;
     uint32_t pipeline = 0;   // RBRT_PIPELINE / rbrt_hip_scene_set_pipeline; 0 = automatic (depth_for)
     uint32_t scratch_waves = 0;
+    uint32_t n_cus = 256;
+    bool waves_fixed = false;  // RBRT_WAVES_PER_CU given: no automatic half-size grids
     uint32_t next_lane = 0;
     float* d_acc = nullptr;
     size_t acc_bytes = 0;
@@ -159,7 +161,18 @@ constexpr uint32_t kMaxPipeline = 4;
 // the larger part of them (measured: 1.07 vs 1.18 ms per step for an eighth of config 2, no gain at a quarter).
 uint32_t depth_for(const rbrt_hip_scene* s, uint64_t samples) {
     if (s->pipeline != 0) return s->pipeline;
-    return samples < 8000000ull ? 3u : 2u;
+    return samples < 8000000ull ? 4u : 2u;
+}
+
+// Waves of one trace launch. A launch that fills the GPU (all resident wave slots) is right for a long launch;
+// short ones (under 24 M samples: a GPU's share of a sharded frame) are issued with HALF the slots, so that two
+// consecutive launches are resident side by side and one's drain always has the other's bulk to share the
+// SIMDs with (measured per step, config 2: a half 2.82 vs 2.88 ms, a quarter 1.69 vs 1.78, an eighth 0.94 vs
+// 1.11). Full-size launches stay whole: 2 % more throughput would cost launches of twice the duration.
+uint32_t grid_for(const rbrt_hip_scene* s, uint64_t samples, uint32_t depth) {
+    if (s->waves_fixed || depth < 2 || samples >= 24000000ull) return s->n_waves;
+    const uint32_t half = s->n_cus * 8u;
+    return half < s->n_waves ? half : s->n_waves;
 }
 
 // Brings s->lanes to `depth` entries (streams, events, counters and per-wave scratch of each lane).
@@ -413,9 +426,10 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         if (per_cu < 1) per_cu = 1;
         if (const char* e = std::getenv("RBRT_WAVES_PER_CU")) {
             int v = std::atoi(e);
-            if (v > 0 && v <= 32) per_cu = v;
+            if (v > 0 && v <= 32) per_cu = v, s->waves_fixed = true;
         }
         s->n_waves = uint32_t(cus * per_cu);
+        s->n_cus = uint32_t(cus);
         if (const char* e = std::getenv("RBRT_KERNEL")) s->use_wg = std::strcmp(e, "wg") == 0;
         if (const char* e = std::getenv("RBRT_WG_POOL")) {
             int v = std::atoi(e);
@@ -622,20 +636,21 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         P.work_counter = L.d_work_counter;
         P.gseq = L.d_gseq;
         P.gstack = L.d_gstack;
-        HIP_TRY(hipMemsetAsync(L.d_work_counter, 0, sizeof(unsigned long long) * kWorkShards * kWorkCounterStride, ts));
+        // (L.d_work_counter is zero: from its allocation, afterwards from the resolve kernel of the lane's last launch)
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
         if (s->use_wg)
             HIP_TRY(launch_trace_megakernel_wg(P, s->n_wg, s->wg_pool, stats, ts));
         else
-            HIP_TRY(launch_trace_megakernel(P, s->n_waves, s->pool, stats, ts));
+            HIP_TRY(launch_trace_megakernel(P, stats ? s->n_waves : grid_for(s, P.n_items, depth), s->pool, stats, ts));
         if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
         if (piped) {
             HIP_TRY(hipEventRecord(L.ev_traced, ts));
             HIP_TRY(hipStreamWaitEvent(stream, L.ev_traced, 0));
         }
         R.sample_buf = L.d_sample_buf;
+        R.work_counter = L.d_work_counter;
         R.batch = nb;
         R.first_batch = b == 0;
         R.last_batch = b + 1 == n_batches;

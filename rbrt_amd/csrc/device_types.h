@@ -134,6 +134,7 @@ struct ResolveParams {
     float* acc;           // [n_local_tiles*64][3] running sum
     float* out_radiance;  // row-major image if tile_world <= 1, else packed tiles; may be null
     uint8_t* out_rgb8;    // same indexing; may be null
+    unsigned long long* work_counter;  // the finished launch's work counters, zeroed here for the lane's next launch
 };
 
 }  // namespace rbrt

@@ -498,6 +498,10 @@ __device__ __forceinline__ uint8_t quantise(float c) {
 __global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) {
     const size_t npix = size_t(R.n_local_tiles) * 64u;
     const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    // the trace launch this resolves has ended: its work counters are reset for the lane's next launch (which
+    // waits for this kernel), saving a memset launch that would have to queue behind the resident megakernels
+    static_assert(kWorkShards * kWorkCounterStride <= kBlock, "one thread per counter word");
+    if (blockIdx.x == 0 && threadIdx.x < kWorkShards * kWorkCounterStride) R.work_counter[threadIdx.x] = 0ull;
     if (i >= npix) return;
     const uint32_t tile_local = uint32_t(i >> 6), p = uint32_t(i & 63u);
     const uint32_t tile = tile_local * R.tile_world + R.tile_rank;
