@@ -130,7 +130,8 @@ def main():
 
     step_no = [0]
 
-    scene.set_pipeline(args.pipeline)
+    if args.pipeline > 0:  # 0: leave the library's choice (automatic, or $RBRT_PIPELINE)
+        scene.set_pipeline(args.pipeline)
 
     def step():
         step_no[0] += 1

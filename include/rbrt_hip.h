@@ -202,8 +202,9 @@ int rbrt_hip_unpack_tiles_strided(int device, void* stream, const float* d_gathe
 /* Counters of the last render on this scene that had RBRT_FLAG_COLLECT_STATS set. */
 int rbrt_hip_scene_stats(rbrt_hip_scene_t* scene, rbrt_hip_stats_t* out);
 
-/* Frame pipeline depth of a scene handle: 1..4, or 0 = automatic (the default, or $RBRT_PIPELINE): 2, and 4
- * for launches of fewer than 8 M samples (short launches also use half-size grids, api.cpp grid_for). With depth d > 1 consecutive
+/* Frame pipeline depth of a scene handle: 1..4, or 0 = automatic (the default, or $RBRT_PIPELINE): 2 for
+ * launches that fill the GPU for long, 3 (and half-size grids, api.cpp grid_for) for launches under 24 M samples.
+ * With depth d > 1 consecutive
  * trace launches -- the sample batches of one render and successive rbrt_hip_render_device calls -- alternate
  * over d internal streams and d sets of work buffers, so that a launch's last, poorly filled waves overlap
  * with the start of the next launch; the per-pixel resolve (and with it every write to the caller's output

@@ -156,21 +156,24 @@ uint32_t div_magic_of(uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : uint32_t(0x100
 
 constexpr uint32_t kMaxPipeline = 4;
 
-// Depth of the frame pipeline for launches of `samples` (pixel, sample) items each: what was set, or, in
-// automatic mode, 2 -- and 3 for short launches (a GPU's share of a sharded frame), whose fixed-cost drain is
-// the larger part of them (measured: 1.07 vs 1.18 ms per step for an eighth of config 2, no gain at a quarter).
+// Launches under 24 M (pixel, sample) items -- a GPU's share of a sharded frame -- are "short": their fixed-cost
+// drain is the larger part of them.
+bool short_launch(uint64_t samples) { return samples < 24000000ull; }
+
+// Depth of the frame pipeline: what was set, or, in automatic mode, 2 for long launches and 3 for short ones.
 uint32_t depth_for(const rbrt_hip_scene* s, uint64_t samples) {
     if (s->pipeline != 0) return s->pipeline;
-    return samples < 8000000ull ? 4u : 2u;
+    return short_launch(samples) ? 3u : 2u;
 }
 
 // Waves of one trace launch. A launch that fills the GPU (all resident wave slots) is right for a long launch;
-// short ones (under 24 M samples: a GPU's share of a sharded frame) are issued with HALF the slots, so that two
-// consecutive launches are resident side by side and one's drain always has the other's bulk to share the
-// SIMDs with (measured per step, config 2: a half 2.82 vs 2.88 ms, a quarter 1.69 vs 1.78, an eighth 0.94 vs
-// 1.11). Full-size launches stay whole: 2 % more throughput would cost launches of twice the duration.
+// short ones are issued with HALF the slots, so that two consecutive launches are resident side by side (one's
+// drain always has the other's bulk to share the SIMDs with) and a third is queued behind them. Measured per
+// step on config 2, full grids 2 deep against half grids 3 deep: a half of the frame 2.88 vs 2.53 ms, a
+// quarter 1.78 vs 1.45, an eighth 1.18 vs 0.91 (half grids 2 or 4 deep: 1.14 / 1.17). A whole frame would gain
+// 2 % (4.94 vs 5.04 ms) at the price of launches of twice the duration; it keeps full grids.
 uint32_t grid_for(const rbrt_hip_scene* s, uint64_t samples, uint32_t depth) {
-    if (s->waves_fixed || depth < 2 || samples >= 24000000ull) return s->n_waves;
+    if (s->waves_fixed || depth < 2 || !short_launch(samples)) return s->n_waves;
     const uint32_t half = s->n_cus * 8u;
     return half < s->n_waves ? half : s->n_waves;
 }
