@@ -343,7 +343,7 @@ def test_full_size_cfg2_invariants(hip, oracle, monkeypatch):
     img = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     hashes = {}
     with hip.HipScene(sc) as hs:
-        for depth in (1, 2):
+        for depth in (1, 2, 3, 0):  # 0 = the library's automatic choice
             hs.set_pipeline(depth)
             img.fill_(float("nan"))
             hs.render_device(cam, abi.default_opts(spp=SPP, seed=1), img.data_ptr(), None, None)
