@@ -19,8 +19,8 @@ constexpr int kBins = 16;
 float cost_traverse() {
     static const float v = [] {
         const char* e = std::getenv("RBRT_BVH_CT");
-        float x = e ? float(std::atof(e)) : 2.0f;
-        return x > 0.0f ? x : 2.0f;
+        float x = e ? float(std::atof(e)) : 4.0f;
+        return x > 0.0f ? x : 4.0f;
     }();
     return v;
 }
