@@ -195,10 +195,21 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
         s->allocs.push_back(p);
         L.d_gstack = static_cast<uint32_t*>(p);
-        HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&L.ev_traced, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&L.ev_resolved, hipEventDisableTiming));
+        // the lane is recorded before its stream and events exist, so that a failure below leaves them to
+        // rbrt_hip_scene_destroy instead of leaking them (a lane without a stream is never selected: the caller
+        // gets the error)
         s->lanes.push_back(L);
+        rbrt_hip_scene::Lane& R = s->lanes.back();
+        hipError_t e = hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_traced, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_resolved, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (R.stream) (void)hipStreamDestroy(R.stream);
+            if (R.ev_traced) (void)hipEventDestroy(R.ev_traced);
+            if (R.ev_resolved) (void)hipEventDestroy(R.ev_resolved);
+            s->lanes.pop_back();
+            return fail(RBRT_ERR_HIP, std::string("pipeline lane: ") + hipGetErrorString(e));
+        }
     }
     return RBRT_OK;
 }
