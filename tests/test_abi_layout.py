@@ -86,3 +86,22 @@ def test_packed_pixels_matches_python_index_math(w, h):
             assert lib.rbrt_hip_packed_pixels(w, h, r, world) == tiles.packed_pixels(w, h, r, world)
             total += tiles.packed_pixels(w, h, r, world)
         assert total == tiles.n_tiles(w, h) * 64
+
+
+def test_argument_errors_come_back_as_codes_without_a_gpu():
+    """Error behaviour at the boundary: negative status codes + rbrt_hip_last_error(), never an abort. These
+    checks run before any device is touched, so they hold on a machine without a GPU too."""
+    lib = abi.load_hip()
+    out = C.c_void_p()
+    assert lib.rbrt_hip_scene_create(None, 0, C.byref(out)) == -1  # RBRT_ERR_INVALID_ARG
+    assert b"null" in lib.rbrt_hip_last_error()
+    lam = abi.material(abi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))
+    too_many = abi.SceneData(spheres=[((float(i), 0.0, 0.0), 0.25, lam) for i in range(256)])
+    assert lib.rbrt_hip_scene_create(too_many.ptr(), 0, C.byref(out)) == -5  # RBRT_ERR_UNSUPPORTED: > 255 objects
+    assert b"255" in lib.rbrt_hip_last_error()
+    bad_mat = abi.SceneData(spheres=[((0.0, 0.0, 0.0), 1.0, abi.Material(7, abi._f3((0, 0, 0)), 0.0))])
+    assert lib.rbrt_hip_scene_create(bad_mat.ptr(), 0, C.byref(out)) == -1
+    opts = abi.default_opts(spp=1)
+    assert lib.rbrt_hip_render_device(None, None, C.byref(opts), None, None, None) == -1
+    assert lib.rbrt_hip_scene_set_pipeline(None, 2) == -1
+    assert lib.rbrt_hip_scene_destroy(None) == 0  # destroying nothing is fine

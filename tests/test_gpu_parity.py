@@ -403,3 +403,26 @@ def test_cli_end_to_end_png(hip, oracle, tmp_path):
     sc = scenes.example_scene(oracle, n_tris)
     _, exp8, _ = oracle.render(cam, sc, abi.default_opts(spp=6, seed=9))
     assert got.shape == exp8.shape and np.array_equal(got, exp8)
+
+
+def test_nan_discriminant_is_reported_like_the_reference_panic(hip, oracle):
+    """sphere.rs:33 panics ("Encountered NAN") when a sphere's discriminant is NaN. Across a C ABI that becomes
+    a status code: the one-shot call returns RBRT_ERR_NAN, the resident-scene call counts the events."""
+    import torch
+    bad = list(scenes.EXAMPLE_SPHERES)
+    c, r, m = bad[1]
+    bad[1] = ((float("nan"), c[1], c[2]), r, m)  # every ray sees a NaN discriminant on this sphere
+    sc = scenes.spheres_scene(bad)
+    cam = scenes.camera(oracle, 64, 48)
+    with pytest.raises(abi.RbrtError) as e:
+        hip.render_scene(cam, 2, sc, seed=1)
+    assert e.value.code == -6  # RBRT_ERR_NAN
+    with hip.HipScene(sc) as hs:
+        img = torch.zeros((48, 64, 3), dtype=torch.float32, device="cuda")
+        hs.render_device(cam, abi.default_opts(spp=2, seed=1, flags=abi.FLAG_COLLECT_STATS), img.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        assert hs.stats()["nan_discriminants"] >= 64 * 48 * 2  # at least one per primary ray
+        # those rays were treated as misses of that sphere: the image is the scene without it
+        exp, _, _ = oracle.render(cam, scenes.spheres_scene([s for i, s in enumerate(scenes.EXAMPLE_SPHERES) if i != 1]),
+                                  abi.default_opts(spp=2, seed=1))
+        assert_same_image(img.cpu().numpy(), exp, "NaN sphere ignored")
