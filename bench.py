@@ -203,6 +203,8 @@ def main():
     alg_bytes = (st["nodes_visited"] * st["node_bytes"] + st["tris_tested"] * TRI_ALG_BYTES +
                  st["mesh_hits"] * NORMAL_ALG_BYTES + local_pixels * PIXEL_ALG_BYTES)
     kernel_ms = trace_ms / max(1, n_launches)
+    launches_per_step = max(1, round(n_launches / max(1, args.steps)))  # > 1 when a frame needs several sample batches
+    alg_bytes = alg_bytes // launches_per_step                          # the counters cover the whole frame
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
     tf = ROOT / "profiles" / "pmc_traffic.json"  # measured with rocprofv3 --pmc in its own run
