@@ -180,6 +180,7 @@ uint32_t grid_for(const rbrt_hip_scene* s, uint64_t samples, uint32_t depth) {
 
 // Brings s->lanes to `depth` entries (streams, events, counters and per-wave scratch of each lane).
 int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
+    const size_t had = s->lanes.size();
     while (s->lanes.size() < depth) {
         rbrt_hip_scene::Lane L;
         void* p = nullptr;
@@ -211,6 +212,8 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
             return fail(RBRT_ERR_HIP, std::string("pipeline lane: ") + hipGetErrorString(e));
         }
     }
+    // the memsets above ran on the null stream, which the lanes' non-blocking streams do not wait for
+    if (s->lanes.size() != had) HIP_TRY(hipDeviceSynchronize());
     return RBRT_OK;
 }
 
