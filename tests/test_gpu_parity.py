@@ -426,3 +426,21 @@ def test_nan_discriminant_is_reported_like_the_reference_panic(hip, oracle):
         exp, _, _ = oracle.render(cam, scenes.spheres_scene([s for i, s in enumerate(scenes.EXAMPLE_SPHERES) if i != 1]),
                                   abi.default_opts(spp=2, seed=1))
         assert_same_image(img.cpu().numpy(), exp, "NaN sphere ignored")
+
+
+def test_one_scene_many_cameras_and_sizes(hip, oracle):
+    """One resident scene, frames of different sizes and spp queued back to back (sample buffers of the pipeline
+    lanes grow and are reused, launches of different grids overlap): every frame is the oracle's."""
+    import torch
+    sc = scenes.example_scene(oracle, 2004)
+    jobs = [(64, 48, 3, 1), (200, 120, 5, 2), (64, 48, 3, 3), (33, 17, 9, 4), (200, 120, 2, 5), (8, 8, 1, 6)]
+    with hip.HipScene(sc) as hs:
+        outs = []
+        for w, h, spp, seed in jobs:
+            img = torch.full((h, w, 3), float("nan"), dtype=torch.float32, device="cuda")
+            hs.render_device(scenes.camera(oracle, w, h), abi.default_opts(spp=spp, seed=seed), img.data_ptr(), None, None)
+            outs.append(img)
+        torch.cuda.synchronize()
+        for (w, h, spp, seed), img in zip(jobs, outs):
+            exp, _, _ = oracle.render(scenes.camera(oracle, w, h), sc, abi.default_opts(spp=spp, seed=seed))
+            assert_same_image(img.cpu().numpy(), exp, f"{w}x{h}x{spp} seed {seed}")
