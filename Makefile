@@ -17,7 +17,7 @@ BINDIR := rbrt_amd/bin
 
 all: $(LIBDIR)/librbrt_hip.so host oracle
 
-$(LIBDIR)/librbrt_hip.so: $(CSRC)/kernels.hip $(CSRC)/megakernel.inl $(CSRC)/megakernel_wg.inl $(CSRC)/api.cpp $(CSRC)/bvh.cpp $(CSRC)/bvh.h \
+$(LIBDIR)/librbrt_hip.so: $(CSRC)/kernels.hip $(CSRC)/megakernel.inl $(CSRC)/api.cpp $(CSRC)/bvh.cpp $(CSRC)/bvh.h \
                           $(CSRC)/device_types.h include/rbrt_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/api.cpp $(CSRC)/bvh.cpp

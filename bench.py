@@ -15,7 +15,14 @@ The scene is resident in HBM before the timed region (upload + BVH build are set
 region is K x [render kernels + gather + unpack], bracketed by barrier + synchronize, MAX over ranks.
 
 Rank 0 prints ONE JSON line with, besides the contract's fields:
-  roofline     — the trace kernel's algorithmic bytes / its HIP-event duration vs 8 TB/s HBM
+  roofline     — the trace kernel's ALGORITHMIC bytes / the duration of an ISOLATED launch (a short second leg with
+                 the frame pipeline off, so that a launch's HIP-event span is the cost of its own work and
+                 kernel_ms <= that leg's ms per step) vs 8 TB/s HBM; beside it the two figures that describe the
+                 kernel as it really runs: measured_hbm (rocprofv3 PMC traffic, from profiles/) and valu_issue
+                 (the VALU-issue bound from SQ_INSTS_VALU: the tree lives in L1/L2, the kernel is issue-bound)
+  single_frame — one blocking frame including the device-to-host copy of the radiance (what a caller of the
+                 reference's blocking render_scene would see); `value` is steady-state throughput with consecutive
+                 frames overlapping in the library's frame pipeline
   cpu_baseline — the CPU oracle (a C++ restatement of the reference's AVX path; the Rust reference
                  cannot be built here) timed on this host on a bounded sample of the same workload
 """
@@ -54,7 +61,12 @@ def parse_args():
     ap.add_argument("--triangles", type=int, default=69451)
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
     ap.add_argument("--cpu-col-stride", type=int, default=8,
-                    help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline)")
+                    help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline; 1 = the whole "
+                         "frame, ~2 min on 16 cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = every core this process may use)")
+    ap.add_argument("--isolated-steps", type=int, default=8,
+                    help="steps of the second, unpipelined leg that times isolated trace launches for the roofline (N = 1 only; 0 = skip)")
+    ap.add_argument("--single-frames", type=int, default=5, help="blocking frames incl. D2H timed for single_frame (N = 1 only; 0 = skip)")
     ap.add_argument("--check", action="store_true", help="also compare the sampled columns with the GPU image")
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="WORLD",
                     help="single process: time only rank 0's share of a WORLD-GPU run (its tiles, no gather); a "
@@ -186,6 +198,40 @@ def main():
         elapsed = float(t.item())
     trace_ms, resolve_ms, n_launches = scene.kernel_ms()
     scene.set_timing(False)
+    scene.check()  # a NaN sphere discriminant (sphere.rs:33 panics) or corrupt path state fails the run loudly
+
+    # ---- second leg (N = 1): isolated launches. With the pipeline on, a launch's event span includes time it shares
+    # with its neighbours (it is a latency, and can exceed ms_per_step); the roofline's denominator is the
+    # duration of a launch that has the GPU to itself, measured here with HIP events on the launch's own stream.
+    iso = None
+    if world == 1 and not emu and args.isolated_steps > 0 and args.pipeline != 1:
+        scene.set_pipeline(1)
+        step()
+        fence()
+        scene.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.isolated_steps):
+            step()
+        fence()
+        iso_elapsed = time.perf_counter() - t0
+        iso_trace_ms, iso_resolve_ms, iso_n = scene.kernel_ms()
+        scene.set_timing(False)
+        scene.set_pipeline(args.pipeline)
+        iso = {"steps": args.isolated_steps, "ms_per_step": iso_elapsed / args.isolated_steps * 1e3,
+               "kernel_ms": iso_trace_ms / max(1, iso_n), "resolve_ms": iso_resolve_ms / max(1, iso_n), "launches": iso_n}
+    # ---- third leg (N = 1): one blocking frame at a time, radiance copied to host memory (pinned) ----------------
+    single = None
+    if world == 1 and not emu and args.single_frames > 0:
+        host_img = torch.empty((H, W, 3), dtype=torch.float32).pin_memory()
+        fence()
+        ts = []
+        for _ in range(args.single_frames):
+            t0 = time.perf_counter()
+            step()
+            host_img.copy_(image, non_blocking=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        single = {"frames": args.single_frames, "ms": sum(ts) / len(ts) * 1e3, "ms_min": min(ts) * 1e3}
 
     if rank != 0:
         if world > 1:
@@ -202,24 +248,50 @@ def main():
     local_pixels = (rbrt_amd.packed_pixels(W, H, rank, world) if world > 1 else W * H)
     alg_bytes = (st["nodes_visited"] * st["node_bytes"] + st["tris_tested"] * TRI_ALG_BYTES +
                  st["mesh_hits"] * NORMAL_ALG_BYTES + local_pixels * PIXEL_ALG_BYTES)
-    kernel_ms = trace_ms / max(1, n_launches)
+    pipelined_kernel_ms = trace_ms / max(1, n_launches)
     launches_per_step = max(1, round(n_launches / max(1, args.steps)))  # > 1 when a frame needs several sample batches
     alg_bytes = alg_bytes // launches_per_step                          # the counters cover the whole frame
+    if iso is not None:
+        kernel_ms, kernel_ms_from = iso["kernel_ms"], "isolated launches (second leg, pipeline 1)"
+    else:
+        kernel_ms = pipelined_kernel_ms
+        kernel_ms_from = ("the timed region (pipeline 1: launches do not overlap)" if args.pipeline == 1 else
+                          "the timed region, launches OVERLAP: a latency, not the cost of the work")
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None
-    tf = ROOT / "profiles" / "pmc_traffic.json"  # measured with rocprofv3 --pmc in its own run
-    if tf.exists() and world == 1:
-        try:
-            rec = json.loads(tf.read_text())
-            if rec.get("workload") == f"{W}x{H}x{spp}" and rec.get("triangles") == args.triangles:
-                traffic = rec.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": n_launches,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "numerator": "ALGORITHMIC bytes (SURVEY 8(d)): 128 B x BVH nodes visited + 36 B x triangles tested + 12 B x "
+                             "mesh hits + 12 B x pixels; mostly L1/L2 hits, not DRAM traffic",
+                "kernel": "trace_megakernel", "kernel_ms": round(kernel_ms, 4), "kernel_ms_from": kernel_ms_from,
+                "kernel_ms_pipelined": round(pipelined_kernel_ms, 4), "launches_timed": n_launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "counters": {k: st[k] for k in ("rays", "mesh_gate_pass", "nodes_visited", "tris_tested", "mesh_hits")}}
+    if iso is not None:
+        roofline["isolated_leg"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in iso.items()}
+    # The two figures that describe the kernel as it really runs come from rocprofv3 PMC passes (their own runs of
+    # this same command, tools/profile.sh; committed under profiles/): a bench run cannot read counters itself.
+    prof = ROOT / "profiles" / "r02_pmc_summary.json"
+    if prof.exists() and world == 1:
+        try:
+            rec = json.loads(prof.read_text())
+            if rec.get("workload") == f"{W}x{H}x{spp}" and rec.get("triangles") == args.triangles:
+                roofline["traffic"] = rec.get("hbm_bytes_per_launch")
+                roofline["traffic_source"] = "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                if rec.get("hbm_bytes_per_launch") and kernel_ms > 0:
+                    gbs = rec["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+                    roofline["measured_hbm"] = {"bytes_per_launch": rec["hbm_bytes_per_launch"], "GBps": round(gbs, 1),
+                                                "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                if rec.get("sq_insts_valu") and kernel_ms > 0:
+                    # one wave64 VALU instruction issues in 4 cycles of its SIMD (MI355X_MICROARCH.md, 'vector-instruction
+                    # ISSUE cost'); 256 CUs x 4 SIMDs; 2.4 GHz
+                    bound_ms = rec["sq_insts_valu"] * 4.0 / 1024.0 / 2.4e9 * 1e3
+                    roofline["valu_issue"] = {"sq_insts_valu": rec["sq_insts_valu"], "cycles_per_inst": 4, "simds": 1024,
+                                              "clock_ghz": 2.4, "bound_ms": round(bound_ms, 3),
+                                              "frac": round(bound_ms / kernel_ms, 4),
+                                              "valu_lane_utilisation": rec.get("valu_lane_utilisation"),
+                                              "source": "profiles/r02_pmc_summary.json"}
+        except Exception:
+            pass
 
     out = {
         "metric": "Mray-samples/sec (WxHxspp/s) on bunny scene; achieved HBM GB/s vs peak",
@@ -229,9 +301,8 @@ def main():
         "config": {"workload": f"example_scene.yaml, {args.triangles}-triangle "
                                f"{'bunny.obj' if real_asset else 'stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
-                   "pipeline": (f"{args.pipeline or 'auto: 2 or 3'} trace launches in flight (consecutive steps overlap; "
-                                f"roofline.kernel_ms is one launch, first wave to last)") if args.pipeline != 1
-                   else "1 (no overlap between steps)",
+                   "pipeline": (f"{args.pipeline or 'auto: 2 or 3'} trace launches in flight (consecutive steps overlap)")
+                   if args.pipeline != 1 else "1 (no overlap between steps)",
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                    "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,
                    **({"EMULATION_rank0_share_of_world": emu} if emu else {}),
@@ -239,11 +310,15 @@ def main():
                    "resolve_kernel_ms": round(resolve_ms / max(1, n_launches), 4) if args.pipeline == 1 else None},
         "roofline": roofline,
     }
+    if single is not None:
+        out["single_frame"] = {"ms": round(single["ms"], 4), "ms_min": round(single["ms_min"], 4), "frames": single["frames"],
+                               "value": round(samples_per_step / (single["ms"] * 1e-3) / 1e6, 2), "unit": "Mray-samples/s",
+                               "what": "one blocking frame: render + synchronise + copy of the fp32 radiance to pinned host memory"}
 
     # ---- CPU baseline (rank 0, N = 1 only): bounded sample of the same workload ---------------------
     if world == 1 and args.cpu_col_stride > 0:
         from oracle import pyoracle  # the checker, used here only as the timed CPU baseline
-        n_threads = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
+        n_threads = args.cpu_threads or len(os.sched_getaffinity(0))  # every core this process may use
         cols = len(range(0, W, args.cpu_col_stride))
         t0 = time.perf_counter()
         rad, _, cpu_rays = pyoracle.render(cam, host_scene, abi.default_opts(spp=spp, seed=args.seed),
@@ -252,8 +327,8 @@ def main():
         cpu_samples = cols * H * spp
         out["cpu_baseline"] = {
             "value": round(cpu_samples / cpu_s / 1e6, 4), "unit": "Mray-samples/s", "cores": n_threads,
-            "kind": "port",
-            "sample": f"every {args.cpu_col_stride}th column ({cols} of {W}) x {H} rows x {spp} spp of the same "
+            "host_logical_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{'every column' if args.cpu_col_stride == 1 else f'every {args.cpu_col_stride}th column'} ({cols} of {W}) x {H} rows x {spp} spp of the same "
                       f"scene and seed, {cpu_s:.1f} s; C++ restatement of the reference AVX path (brute force over "
                       f"all triangles), not the Rust binary",
         }

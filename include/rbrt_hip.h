@@ -178,6 +178,10 @@ size_t rbrt_hip_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_ran
 
 /* Renders into DEVICE memory on `stream` (a hipStream_t, may be NULL = default stream) and
  * returns without synchronising.
+ * Threading rule: a scene handle is used by ONE host thread at a time and all its render_device calls go to the
+ * SAME stream (the handle's accumulator, its pipeline lanes and their events are ordered through that stream);
+ * use one handle per stream / thread otherwise (the reference's render_scene is not re-entrant either: it takes
+ * Scene by value, lib.rs:75-79).
  *   d_radiance: if tile_world <= 1: float[H][W][3] row-major.
  *               else: this rank's tiles packed, float[n_local_tiles][64][3] (tile-local pixel
  *               p = (y%8)*8 + (x%8)); feed the gathered buffers to rbrt_hip_unpack_tiles.
@@ -185,6 +189,17 @@ size_t rbrt_hip_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_ran
 int rbrt_hip_render_device(rbrt_hip_scene_t* scene, const rbrt_camera_t* cam,
                            const rbrt_render_opts_t* opts, void* stream, float* d_radiance,
                            uint8_t* d_rgb8);
+
+/* Progressive / checkpointed rendering (no counterpart in the reference, whose sample loop lib.rs:95-101 runs to the
+ * end or not at all; a 4096 x 4096 x 4096 spp render is 68.7 G paths). Renders samples [sample_begin, sample_end) of
+ * the opts->spp samples of every pixel and adds them, in sample order, to the running sums in d_accum (device,
+ * fp32, indexed like d_radiance; read unless sample_begin == 0). The call with sample_end == opts->spp also
+ * writes the mean to d_radiance and its quantisation to d_rgb8 (either may be NULL). Calls must cover [0, spp) in
+ * ascending, non-overlapping ranges; the final image is then bit-identical to one rbrt_hip_render_device call,
+ * because the per-pixel additions happen in the same order. A checkpoint is d_accum plus sample_end. */
+int rbrt_hip_render_pass(rbrt_hip_scene_t* scene, const rbrt_camera_t* cam, const rbrt_render_opts_t* opts,
+                         void* stream, uint32_t sample_begin, uint32_t sample_end, float* d_accum,
+                         float* d_radiance, uint8_t* d_rgb8);
 
 /* De-interleave gathered per-rank packed tile buffers (concatenated rank 0..world-1, each
  * rbrt_hip_packed_pixels(...)*3 floats, device memory) into a row-major float[H][W][3] device
@@ -198,6 +213,19 @@ int rbrt_hip_unpack_tiles(int device, void* stream, const float* d_gathered, uin
 int rbrt_hip_unpack_tiles_strided(int device, void* stream, const float* d_gathered, uint32_t width,
                                   uint32_t height, uint32_t tile_world, size_t rank_stride_pixels,
                                   float* d_radiance, uint8_t* d_rgb8);
+
+/* Error state of the resident path. rbrt_hip_render_device returns before the kernels have run, so what they
+ * detect cannot come back through its return value: a NaN sphere discriminant (the reference panics with
+ * "Encountered NAN", sphere.rs:33; here those rays miss that sphere and are counted) or a corrupt path slot
+ * (internal error). This call synchronises the device, returns RBRT_ERR_NAN / RBRT_ERR_HIP if either happened in
+ * any render on this scene since the previous check, and clears the flags. The one-shot rbrt_hip_render does the
+ * same check itself. Call it where the reference's render_scene would have returned (lib.rs:124). */
+int rbrt_hip_scene_check(rbrt_hip_scene_t* scene);
+
+/* How the last rbrt_hip_render_device call on this scene split its samples: samples per batch (one trace launch
+ * each, sized to the workspace cap $RBRT_HIP_WORKSPACE_MB and to the kernel's 32-bit work-item numbers) and the
+ * number of batches. Diagnostic. */
+int rbrt_hip_scene_last_batching(rbrt_hip_scene_t* scene, uint32_t* samples_per_batch, uint32_t* n_batches);
 
 /* Counters of the last render on this scene that had RBRT_FLAG_COLLECT_STATS set. */
 int rbrt_hip_scene_stats(rbrt_hip_scene_t* scene, rbrt_hip_stats_t* out);
@@ -221,6 +249,12 @@ int rbrt_hip_scene_set_pipeline(rbrt_hip_scene_t* scene, uint32_t depth);
 int rbrt_hip_trace_rays(rbrt_hip_scene_t* scene, const float* rays, size_t n, float min_dist,
                         float max_dist, float* out_t, int32_t* out_obj, int32_t* out_tri,
                         float* out_dist);
+
+/* Test hook for BoundingBox::hit (aabbox.rs:28-58): n rays against the box [lo, hi], decided by the division-free
+ * form the megakernel uses (out_fast[n]) and by the verbatim form with six IEEE divisions (out_exact[n]); the two
+ * must agree for every input. Host arrays. */
+int rbrt_hip_selftest_gate(const float lo[3], const float hi[3], const float* rays, size_t n, uint8_t* out_fast,
+                           uint8_t* out_exact);
 
 /* Diagnostic: pass statistics of the persistent megakernel from the last render with
  * RBRT_FLAG_COLLECT_STATS: out[0..5] passes per kind (empty, traverse, terminate, lambertian, metal,

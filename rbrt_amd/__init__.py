@@ -73,6 +73,13 @@ class HipScene:
         abi.check(self._lib.rbrt_hip_render_device(self._h, C.byref(cam), C.byref(opts), C.c_void_p(stream or 0),
                                                    C.c_void_p(d_radiance or 0), C.c_void_p(d_rgb8 or 0)))
 
+    def render_pass(self, cam: abi.Camera, opts: abi.RenderOpts, sample_begin: int, sample_end: int, d_accum: int,
+                    d_radiance: int | None = None, d_rgb8: int | None = None, stream: int | None = None):
+        """Samples [sample_begin, sample_end) of opts.spp, accumulated into d_accum (rbrt_hip_render_pass)."""
+        abi.check(self._lib.rbrt_hip_render_pass(self._h, C.byref(cam), C.byref(opts), C.c_void_p(stream or 0), sample_begin,
+                                                 sample_end, C.c_void_p(d_accum), C.c_void_p(d_radiance or 0),
+                                                 C.c_void_p(d_rgb8 or 0)))
+
     def set_pipeline(self, depth: int):
         """Overlap consecutive trace launches over `depth` internal streams (rbrt_hip_scene_set_pipeline)."""
         abi.check(self._lib.rbrt_hip_scene_set_pipeline(self._h, int(depth)))
@@ -85,6 +92,17 @@ class HipScene:
         t, r, n = C.c_float(), C.c_float(), C.c_uint32()
         abi.check(self._lib.rbrt_hip_scene_kernel_ms(self._h, C.byref(t), C.byref(r), C.byref(n)))
         return t.value, r.value, n.value
+
+    def check(self):
+        """Synchronise and raise RbrtError if a kernel flagged a NaN sphere discriminant (sphere.rs:33) or corrupt
+        path state since the last check (rbrt_hip_scene_check)."""
+        abi.check(self._lib.rbrt_hip_scene_check(self._h))
+
+    def last_batches(self):
+        """(samples per batch, number of batches) of the last render_device call."""
+        b, n = C.c_uint32(), C.c_uint32()
+        abi.check(self._lib.rbrt_hip_scene_last_batching(self._h, C.byref(b), C.byref(n)))
+        return b.value, n.value
 
     def stats(self) -> dict:
         st = abi.Stats()

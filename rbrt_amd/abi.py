@@ -119,12 +119,17 @@ HIP_SYMBOLS = {
     "rbrt_hip_packed_pixels": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rbrt_hip_render_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
+    "rbrt_hip_render_pass": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_uint32, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "rbrt_hip_unpack_tiles": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p]),
     "rbrt_hip_unpack_tiles_strided": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                                 C.c_size_t, C.c_void_p, C.c_void_p]),
     "rbrt_hip_scene_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "rbrt_hip_scene_check": (C.c_int, [C.c_void_p]),
+    "rbrt_hip_scene_last_batching": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rbrt_hip_trace_rays": (C.c_int, [C.c_void_p, f32p, C.c_size_t, C.c_float, C.c_float, f32p, i32p, i32p, f32p]),
+    "rbrt_hip_selftest_gate": (C.c_int, [f32p, f32p, f32p, C.c_size_t, u8p, u8p]),
     "rbrt_hip_bvh_build_host": (C.c_int, [C.POINTER(Mesh), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
                                           f32p]),

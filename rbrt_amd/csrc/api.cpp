@@ -18,9 +18,6 @@ namespace rbrt {
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats,
                                    hipStream_t stream);
 size_t megakernel_gseq_bytes(uint32_t n_waves);
-size_t megakernel_wg_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
-int megakernel_wg_waves();
-hipError_t launch_trace_megakernel_wg(const TraceParams& P, uint32_t n_wg, uint32_t pool, bool stats, hipStream_t stream);
 size_t megakernel_gstack_bytes(uint32_t n_waves);
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
@@ -28,6 +25,7 @@ hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height,
                          size_t rank_stride_pixels, float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
 hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, float* out_t, int32_t* out_obj,
                              int32_t* out_tri, float* out_dist, hipStream_t stream);
+hipError_t launch_gate_selftest(const float* d_box, const float* d_rays, size_t n, uint8_t* d_fast, uint8_t* d_exact);
 uint64_t host_splitmix64(uint64_t x);
 }  // namespace rbrt
 
@@ -75,6 +73,7 @@ struct rbrt_hip_scene {
     DevSphere* d_spheres = nullptr;
     DevMaterial* d_materials = nullptr;
     DevMesh* d_meshes = nullptr;
+    BvhTri* d_tris = nullptr;  // all meshes' triangle records
     DevCounters* d_counters = nullptr;
     // workspace, grown on demand
     // Frame pipeline: consecutive trace launches (the batches of one render, or successive renders) alternate
@@ -114,17 +113,17 @@ struct rbrt_hip_scene {
     uint32_t y_low_water = 28;    // RBRT_Y_LOW
     uint32_t y_high_water = 28, y_high_min_parked = 16;  // RBRT_Y_HIGH, RBRT_Y_HIGH_PARKED
     uint32_t leaf_round = 12;     // RBRT_LEAF_ROUND
-    uint32_t shade_min = 48;      // RBRT_SHADE_MIN
+    uint32_t leaf_tris = 64;      // RBRT_LEAF_TRIS
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
-    bool use_wg = false;          // RBRT_KERNEL=wg: one pool per 4-wave workgroup
-    uint32_t wg_pool = 448, n_wg = 0;
     // stats / timing
     rbrt_hip_stats_t stats{};
     bool stats_pending = false;
     bool timing = false;
     std::vector<hipEvent_t> events;  // [t0, t1, r1] per batch
     size_t events_used = 0;
+    bool timing_overflow = false;  // more than kMaxTimedLaunches launches since set_timing: the rest go untimed
+    uint32_t last_batch = 0, last_n_batches = 0;  // sample batching of the last render (rbrt_hip_scene_last_batching)
     uint64_t total_nodes = 0, total_tris = 0;
 };
 
@@ -155,6 +154,7 @@ int upload(rbrt_hip_scene* s, const std::vector<T>& host, T** out) {
 uint32_t div_magic_of(uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : uint32_t(0x100000000ull / d); }  // kernels.hip div_magic
 
 constexpr uint32_t kMaxPipeline = 4;
+constexpr size_t kMaxTimedLaunches = 4096;  // timing events are recycled per set_timing, never more than this many launches
 
 // Launches under 24 M (pixel, sample) items -- a GPU's share of a sharded frame -- are "short": their fixed-cost
 // drain is the larger part of them.
@@ -238,6 +238,7 @@ int fill_trace_params(const rbrt_hip_scene* s, const rbrt_camera_t* cam, const r
     P.spheres = s->d_spheres;
     P.materials = s->d_materials;
     P.meshes = s->d_meshes;
+    P.tris = s->d_tris;
     P.counters = s->d_counters;
     return RBRT_OK;
 }
@@ -328,7 +329,10 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         const rbrt_mesh_t& m = scene->meshes[i];
         if (int rc = check_material(m.mat)) return rc;
-        if (m.n_total >= (1u << 28)) return fail(RBRT_ERR_UNSUPPORTED, "mesh has 2^28 or more triangles");
+        // The BVH is at most kMaxBvhDepth + 1 inner levels deep with <= kLeafMax triangles per leaf (2-bit count
+        // field): 4 << 21 = 8,388,608 triangles is what always fits, whatever their arrangement (bvh.cpp capacity()).
+        if (m.n_total > (uint32_t(kLeafMax) << (kMaxBvhDepth + 1)))
+            return fail(RBRT_ERR_UNSUPPORTED, "mesh has more than 8,388,608 triangles (BVH depth budget)");
         if (m.n_total && (!m.v0x || !m.v0y || !m.v0z || !m.e1x || !m.e1y || !m.e1z || !m.e2x || !m.e2y ||
                           !m.e2z || !m.nx || !m.ny || !m.nz || !m.is_padding))
             return fail(RBRT_ERR_INVALID_ARG, "mesh array pointer is null");
@@ -368,20 +372,30 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         put_mat(i, scene->spheres[i].mat);
     }
     std::vector<DevMesh> meshes(scene->n_meshes);
+    std::vector<BvhTri> all_tris;  // the triangle records of every mesh, concatenated: leaf links become absolute
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         const rbrt_mesh_t& m = scene->meshes[i];
         put_mat(scene->n_spheres + i, m.mat);
         BvhBuildResult bvh = build_bvh(m);
+        const uint32_t tri_base = uint32_t(all_tris.size());
+        if (uint64_t(tri_base) + bvh.tris.size() >= (1ull << 26))
+            return bail(fail(RBRT_ERR_UNSUPPORTED, "more than 2^26 triangle records in one scene"));
+        if (tri_base != 0)
+            for (BvhNode4& nd : bvh.nodes)
+                for (int c = 0; c < 4; ++c)
+                    if (nd.child[c] < 0 && nd.child[c] != kNoChild) {
+                        const uint32_t leaf = uint32_t(~nd.child[c]);
+                        nd.child[c] = ~int32_t((((leaf >> 2) + tri_base) << 2) | (leaf & 3u));
+                    }
+        all_tris.insert(all_tris.end(), bvh.tris.begin(), bvh.tris.end());
         std::vector<Normal4> normals(m.n_total);
         for (uint32_t k = 0; k < m.n_total; ++k) normals[k] = Normal4{m.nx[k], m.ny[k], m.nz[k], 0.0f};
         DevMesh& dm = meshes[i];
         BvhNode4* d_nodes = nullptr;
-        BvhTri* d_tris = nullptr;
         Normal4* d_normals = nullptr;
         if (int rc = upload(s, bvh.nodes, &d_nodes)) return bail(rc);
-        if (int rc = upload(s, bvh.tris, &d_tris)) return bail(rc);
         if (int rc = upload(s, normals, &d_normals)) return bail(rc);
-        dm.nodes = d_nodes, dm.tris = d_tris, dm.normals = d_normals;
+        dm.nodes = d_nodes, dm.tris = nullptr, dm.normals = d_normals;  // tris: set below, once the scene's array exists
         float diag2 = 0.0f;
         for (int c = 0; c < 3; ++c) {
             dm.bbox_lo[c] = m.bbox_lo[c];
@@ -400,6 +414,8 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         s->total_nodes += bvh.nodes.size();
         s->total_tris += bvh.tris.size();
     }
+    if (int rc = upload(s, all_tris, &s->d_tris)) return bail(rc);
+    for (DevMesh& dm : meshes) dm.tris = s->d_tris;
     if (int rc = upload(s, spheres, &s->d_spheres)) return bail(rc);
     if (int rc = upload(s, mats, &s->d_materials)) return bail(rc);
     if (int rc = upload(s, meshes, &s->d_meshes)) return bail(rc);
@@ -447,14 +463,9 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         }
         s->n_waves = uint32_t(cus * per_cu);
         s->n_cus = uint32_t(cus);
-        if (const char* e = std::getenv("RBRT_KERNEL")) s->use_wg = std::strcmp(e, "wg") == 0;
-        if (const char* e = std::getenv("RBRT_WG_POOL")) {
+        if (const char* e = std::getenv("RBRT_LEAF_TRIS")) {
             int v = std::atoi(e);
-            if (v == 384 || v == 448 || v == 512 || v == 640) s->wg_pool = uint32_t(v);
-        }
-        if (const char* e = std::getenv("RBRT_SHADE_MIN")) {
-            int v = std::atoi(e);
-            if (v >= 0 && v <= 64) s->shade_min = uint32_t(v);
+            if (v >= 1 && v <= 256) s->leaf_tris = uint32_t(v);
         }
         if (const char* e = std::getenv("RBRT_SHADE_ROUNDS")) {
             int v = std::atoi(e);
@@ -464,22 +475,13 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             int v = std::atoi(e);
             if (v >= 1 && v <= 64) s->shade_cont_min = uint32_t(v);
         }
-        {
-            int wg_per_cu = int((160u * 1024u) / megakernel_wg_lds_bytes(s->wg_pool, s->stack_entries, s->n_spheres, s->n_meshes));
-            if (wg_per_cu > 16 / megakernel_wg_waves()) wg_per_cu = 16 / megakernel_wg_waves();
-            if (wg_per_cu < 1) wg_per_cu = 1;
-            if (const char* e = std::getenv("RBRT_WG_PER_CU")) {
-                int v = std::atoi(e);
-                if (v > 0 && v <= 8) wg_per_cu = v;
-            }
-            s->n_wg = uint32_t(cus * wg_per_cu);
-        }
-        s->scratch_waves = uint32_t(cus) * 32u;  // both kernel variants index scratch by wave / workgroup
+        s->scratch_waves = uint32_t(cus) * 32u;  // per-wave scratch is indexed by workgroup (= wave)
         if (const char* e = std::getenv("RBRT_PIPELINE")) {
             int v = std::atoi(e);
             if (v >= 0 && v <= int(kMaxPipeline)) s->pipeline = uint32_t(v);
         }
-        if (int rc = ensure_lanes(s, s->pipeline ? s->pipeline : 2u)) return bail(rc);
+        // all lanes up front: rbrt_hip_render_device then never allocates lanes (which synchronises the device)
+        if (int rc = ensure_lanes(s, kMaxPipeline)) return bail(rc);
         if (const char* e = std::getenv("RBRT_POISON_SAMPLES")) s->poison_samples = e[0] == '1';
     }
     *out = s;
@@ -506,6 +508,7 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
 int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* s, int enable) {
     if (!s) return fail(RBRT_ERR_INVALID_ARG, "null scene");
     s->timing = enable != 0;
+    s->timing_overflow = false;
     s->events_used = 0;
     return RBRT_OK;
 }
@@ -531,10 +534,14 @@ int rbrt_hip_scene_kernel_ms(rbrt_hip_scene_t* s, float* trace_ms, float* resolv
     return RBRT_OK;
 }
 
-int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const rbrt_render_opts_t* o,
-                           void* stream_v, float* d_radiance, uint8_t* d_rgb8) {
+// Samples [s_begin, s_end) of a render of o->spp samples per pixel. `acc` holds (and receives) the per-pixel running
+// sums in sample order -- lib.rs:95-100's `color +=` -- packed like the radiance output; it is read unless
+// s_begin == 0 and written unless s_end == o->spp, in which case the mean (lib.rs:101) and the quantisation go out.
+static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const rbrt_render_opts_t* o, void* stream_v,
+                   uint32_t s_begin, uint32_t s_end, float* acc, float* d_radiance, uint8_t* d_rgb8) {
     if (!s || !cam || !o) return fail(RBRT_ERR_INVALID_ARG, "render: null argument");
     if (o->spp == 0) return fail(RBRT_ERR_INVALID_ARG, "spp must be >= 1");
+    if (s_begin >= s_end || s_end > o->spp) return fail(RBRT_ERR_INVALID_ARG, "sample range must satisfy begin < end <= spp");
     if (o->max_depth > uint32_t(kMaxPathDepth))
         return fail(RBRT_ERR_UNSUPPORTED, "max_depth above the kernel limit of 64");
     if (cam->img_width_pix == 0 || cam->img_height_pix == 0)
@@ -558,7 +565,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     size_t batch = workspace_cap_bytes() / per_sample;
     if (batch * npix > 0xFFF00000ull) batch = 0xFFF00000ull / npix;  // work items are 32-bit in the kernel
     if (batch < 1) batch = 1;
-    if (batch > o->spp) batch = o->spp;
+    if (batch > s_end - s_begin) batch = s_end - s_begin;
     const size_t need = batch * per_sample;
     const uint32_t depth = depth_for(s, uint64_t(npix) * batch);
     if (int rc = ensure_lanes(s, depth)) return rc;
@@ -567,7 +574,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         for (auto& L : s->lanes) HIP_TRY(hipStreamSynchronize(L.stream));
         return RBRT_OK;
     };
-    if (per_sample > s->acc_bytes) {
+    if (!acc && per_sample > s->acc_bytes) {
         if (s->d_acc) {
             if (int rc = sync_lanes()) return rc;
             HIP_TRY(hipFree(s->d_acc));
@@ -600,7 +607,7 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     P.y_high_water = s->y_high_water < s->y_low_water ? s->y_low_water : s->y_high_water;
     P.y_high_min_parked = s->y_high_min_parked;
     P.leaf_round = s->leaf_round;
-    P.shade_min = s->shade_min;
+    P.leaf_tris = s->leaf_tris;
     P.shade_rounds = s->shade_rounds;
     P.shade_cont_min = s->shade_cont_min;
 
@@ -609,12 +616,15 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     R.width = W, R.height = H, R.tiles_x = tiles_x, R.n_tiles = n_tiles;
     R.tile_rank = o->tile_rank, R.tile_world = world, R.n_local_tiles = n_local;
     R.inv_spp = 1.0f / float(o->spp);  // lib.rs:101
-    R.acc = s->d_acc;
+    R.acc = acc ? acc : s->d_acc;
     R.out_radiance = d_radiance;
     R.out_rgb8 = d_rgb8;
 
-    const size_t n_batches = (size_t(o->spp) + batch - 1) / batch;
-    if (s->timing) {
+    const size_t n_batches = (size_t(s_end - s_begin) + batch - 1) / batch;
+    s->last_batch = uint32_t(batch), s->last_n_batches = uint32_t(n_batches);
+    if (s->timing && s->events_used + 3 * n_batches > kMaxTimedLaunches * 3) s->timing_overflow = true;
+    const bool timing = s->timing && !s->timing_overflow;
+    if (timing) {
         while (s->events.size() < s->events_used + 3 * n_batches) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
@@ -623,8 +633,8 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
     }
     const size_t ev0 = s->events_used;
     for (size_t b = 0; b < n_batches; ++b) {
-        const uint32_t base = uint32_t(b * batch);
-        const uint32_t nb = uint32_t(std::min<size_t>(batch, o->spp - base));
+        const uint32_t base = s_begin + uint32_t(b * batch);
+        const uint32_t nb = uint32_t(std::min<size_t>(batch, s_end - base));
         // counting launches run alone on lane 0: their counters are reset and read on the caller's stream
         rbrt_hip_scene::Lane& L = s->lanes[stats ? 0 : s->next_lane++ % depth];
         const bool piped = depth > 1 && !stats;
@@ -656,12 +666,9 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         // (L.d_work_counter is zero: from its allocation, afterwards from the resolve kernel of the lane's last launch)
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
-        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
-        if (s->use_wg)
-            HIP_TRY(launch_trace_megakernel_wg(P, s->n_wg, s->wg_pool, stats, ts));
-        else
-            HIP_TRY(launch_trace_megakernel(P, stats ? s->n_waves : grid_for(s, P.n_items, depth), s->pool, stats, ts));
-        if (s->timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
+        if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
+        HIP_TRY(launch_trace_megakernel(P, stats ? s->n_waves : grid_for(s, P.n_items, depth), s->pool, stats, ts));
+        if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
         if (piped) {
             HIP_TRY(hipEventRecord(L.ev_traced, ts));
             HIP_TRY(hipStreamWaitEvent(stream, L.ev_traced, 0));
@@ -669,19 +676,30 @@ int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const 
         R.sample_buf = L.d_sample_buf;
         R.work_counter = L.d_work_counter;
         R.batch = nb;
-        R.first_batch = b == 0;
-        R.last_batch = b + 1 == n_batches;
+        R.first_batch = base == 0;
+        R.last_batch = base + nb == o->spp;
         HIP_TRY(launch_resolve(R, stream));
         if (depth > 1) {  // (also after a counting launch: it used lane 0's buffers on the caller's stream)
             HIP_TRY(hipEventRecord(L.ev_resolved, stream));
             L.in_use = true;
         }
-        if (s->timing) {
+        if (timing) {
             HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 2], stream));
             s->events_used = ev0 + 3 * (b + 1);
         }
     }
     return RBRT_OK;
+}
+
+int rbrt_hip_render_device(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const rbrt_render_opts_t* o,
+                           void* stream, float* d_radiance, uint8_t* d_rgb8) {
+    return render_samples(s, cam, o, stream, 0, o ? o->spp : 0, nullptr, d_radiance, d_rgb8);
+}
+
+int rbrt_hip_render_pass(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const rbrt_render_opts_t* o, void* stream,
+                         uint32_t sample_begin, uint32_t sample_end, float* d_accum, float* d_radiance, uint8_t* d_rgb8) {
+    if (!d_accum) return fail(RBRT_ERR_INVALID_ARG, "render_pass: d_accum is null");
+    return render_samples(s, cam, o, stream, sample_begin, sample_end, d_accum, d_radiance, d_rgb8);
 }
 
 int rbrt_hip_scene_set_pipeline(rbrt_hip_scene_t* s, uint32_t depth) {
@@ -712,6 +730,32 @@ int rbrt_hip_scene_stats(rbrt_hip_scene_t* s, rbrt_hip_stats_t* out) {
     *out = s->stats;
     if (c.diag[57])
         return fail(RBRT_ERR_HIP, "the trace kernel detected corrupt internal state (a path slot without a valid sample index)");
+    return RBRT_OK;
+}
+
+// Synchronises, then reports and clears what the kernels flagged since the last check: a NaN sphere discriminant
+// (the reference panics there, sphere.rs:33) or a path slot without a valid sample index (internal corruption).
+int rbrt_hip_scene_check(rbrt_hip_scene_t* s) {
+    if (!s) return fail(RBRT_ERR_INVALID_ARG, "check: null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long nan = 0, corrupt = 0;
+    HIP_TRY(hipMemcpy(&nan, &s->d_counters->nan_discriminants, sizeof(nan), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&corrupt, &s->d_counters->diag[57], sizeof(corrupt), hipMemcpyDeviceToHost));
+    if (nan) HIP_TRY(hipMemset(&s->d_counters->nan_discriminants, 0, sizeof(nan)));
+    if (corrupt) HIP_TRY(hipMemset(&s->d_counters->diag[57], 0, sizeof(corrupt)));
+    if (corrupt)
+        return fail(RBRT_ERR_HIP, "the trace kernel detected corrupt internal state (a path slot without a valid sample index)");
+    if (nan)
+        return fail(RBRT_ERR_NAN, "a sphere discriminant was NaN " + std::to_string(nan) +
+                                      " times (the reference panics: sphere.rs:33); those rays were treated as misses");
+    return RBRT_OK;
+}
+
+int rbrt_hip_scene_last_batching(rbrt_hip_scene_t* s, uint32_t* samples_per_batch, uint32_t* n_batches) {
+    if (!s) return fail(RBRT_ERR_INVALID_ARG, "last_batching: null scene");
+    if (samples_per_batch) *samples_per_batch = s->last_batch;
+    if (n_batches) *n_batches = s->last_n_batches;
     return RBRT_OK;
 }
 
@@ -839,6 +883,32 @@ int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n
     return RBRT_OK;
 }
 void rbrt_hip_free_host(void* p) { std::free(p); }
+
+// Test hook: BoundingBox::hit (aabbox.rs:28-58) on n rays against one box, by the division-free form the megakernel
+// uses (out_fast) and by the verbatim IEEE form (out_exact). Host arrays.
+int rbrt_hip_selftest_gate(const float lo[3], const float hi[3], const float* rays, size_t n, uint8_t* out_fast,
+                           uint8_t* out_exact) {
+    if (!lo || !hi || (!rays && n) || !out_fast || !out_exact) return fail(RBRT_ERR_INVALID_ARG, "selftest_gate: null argument");
+    if (n == 0) return RBRT_OK;
+    if (int rc = ensure_device(0)) return rc;
+    float *d_box = nullptr, *d_rays = nullptr;
+    uint8_t *d_f = nullptr, *d_e = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_box), (void)hipFree(d_rays), (void)hipFree(d_f), (void)hipFree(d_e); };
+    const float box[6] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_box), sizeof(box));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rays), n * 6 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_f), n);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_e), n);
+    if (e == hipSuccess) e = hipMemcpy(d_box, box, sizeof(box), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, n * 6 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_gate_selftest(d_box, d_rays, n, d_f, d_e);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out_fast, d_f, n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_exact, d_e, n, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(RBRT_ERR_HIP, std::string("selftest_gate: ") + hipGetErrorString(e));
+    return RBRT_OK;
+}
 
 int rbrt_hip_trace_rays(rbrt_hip_scene_t* s, const float* rays, size_t n, float min_dist, float max_dist,
                         float* out_t, int32_t* out_obj, int32_t* out_tri, float* out_dist) {

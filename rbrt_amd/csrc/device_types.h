@@ -66,7 +66,7 @@ struct DevMaterial {
 
 struct DevMesh {
     const BvhNode4* nodes;
-    const BvhTri* tris;
+    const BvhTri* tris;      // the SCENE's triangle array (all meshes; this mesh's leaves point into its own part)
     const Normal4* normals;  // [reference index] -> (nx, ny, nz, 0)
     float bbox_lo[3];
     float bbox_hi[3];
@@ -101,6 +101,7 @@ struct TraceParams {
     const DevSphere* spheres;
     const DevMaterial* materials;  // [object id]: spheres first, then meshes
     const DevMesh* meshes;
+    const BvhTri* tris;  // the triangle records of ALL meshes, one array; leaf links hold absolute positions in it
     // work decomposition
     uint32_t tiles_x, tiles_y, n_tiles;
     uint32_t tile_rank, tile_world, n_local_tiles;
@@ -118,8 +119,8 @@ struct TraceParams {
     uint32_t* gstack;                  // [n_waves][kStackMax][64] overflow of the LDS stacks
     uint32_t y_low_water;              // refill a traversal pass when fewer lanes than this are busy
     uint32_t y_high_water, y_high_min_parked;  // ... or fewer than y_high_water while at least that many rays are parked
-    uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one
-    uint32_t shade_min;                // workgroup-pool kernel: let a shading queue fill to this depth while lanes can traverse
+    uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one ...
+    uint32_t leaf_tris;                // ... or once the pending leaves hold this many triangles (a leaf round deals them out to all lanes)
     uint32_t shade_rounds;             // shading pass: rounds a sphere-only bounce chain may stay in registers
     uint32_t shade_cont_min;           // ... as long as at least this many lanes continue (ignored once the work has run out)
 };

@@ -142,6 +142,34 @@ __device__ __forceinline__ bool bbox_gate(const float* lo, const float* hi, V3 o
     return true;
 }
 
+// The same DECISION as bbox_gate for every input, without the six IEEE divisions on the common path: the quotients
+// are formed as (bound - o) * v_rcp_f32(d) (1 ulp reciprocal), each within 2 * 2^-23 relative of the correctly
+// rounded quotient bbox_gate computes (the subtraction is the same instruction in both). min / max are monotone, so
+// t_min and t_max are within E = 4 * 2^-23 * (largest of the six magnitudes) of bbox_gate's values, and both of its
+// tests -- t_max < 0, t_min > t_max -- come out the same whenever |t_max| > E and |t_min - t_max| > 2E. Otherwise
+// (a ray grazing an edge of the box within a few ulp, a zero / tiny / huge direction component, non-finite
+// quotients) the lane falls back to the IEEE form; the wave takes that branch only when one of its lanes needs it.
+__device__ __forceinline__ bool bbox_gate_fast(const float* lo, const float* hi, V3 o, V3 d) {
+    const float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
+    const float lx = (lo[0] - o.x) * rx, ux = (hi[0] - o.x) * rx;
+    const float ly = (lo[1] - o.y) * ry, uy = (hi[1] - o.y) * ry;
+    const float lz = (lo[2] - o.z) * rz, uz = (hi[2] - o.z) * rz;
+    const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx, ux), __builtin_fminf(ly, uy)), __builtin_fminf(lz, uz));
+    const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx, ux), __builtin_fmaxf(ly, uy)), __builtin_fmaxf(lz, uz));
+    const float m = __builtin_fmaxf(
+        __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(lx), __builtin_fabsf(ux)), __builtin_fmaxf(__builtin_fabsf(ly), __builtin_fabsf(uy))),
+        __builtin_fmaxf(__builtin_fabsf(lz), __builtin_fabsf(uz)));
+    const float E = m * (4.0f / 8388608.0f);
+    const float dmin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    // every comparison below is false for a NaN operand: anything unusual lands in the exact branch
+    const bool sure = (__builtin_fabsf(t_max) > E) && (__builtin_fabsf(t_min - t_max) > 2.0f * E) && (m < 1e30f) && (m > 1e-30f) &&
+                      (dmin > 1e-30f) && (dmax < 1e30f) && (d.x == d.x) && (d.y == d.y) && (d.z == d.z);
+    bool res = !(t_max < 0.0f) && !(t_min > t_max);
+    if (!sure) res = bbox_gate(lo, hi, o, d);
+    return res;
+}
+
 // One lane of triangle.rs:189-255. Every compare is an ordered compare (false on NaN) and the
 // accept expression has the reference's shape: !(c1 | c2 | c3) & c4.
 __device__ __forceinline__ bool tri_test(V3 v0, V3 ea, V3 eb, V3 o, V3 d, float eps, float eps_frac,
@@ -481,7 +509,6 @@ __device__ __forceinline__ bool scatter(const DevMaterial& m, V3 in_d, V3 p, V3 
 }
 
 #include "megakernel.inl"
-#include "megakernel_wg.inl"
 
 // lib.rs:116-122: (sqrt(c) * 256) as u8 — Rust's float->int cast saturates and maps NaN to 0.
 __device__ __forceinline__ uint8_t quantise(float c) {
@@ -603,6 +630,16 @@ __global__ __launch_bounds__(kRaysBlock) void trace_rays_kernel(const TraceParam
     if (out_dist) out_dist[i] = hit ? h.dist : nanv;
 }
 
+// Test hook (rbrt_hip_selftest_gate): both forms of the mesh gate on arbitrary rays against one box.
+__global__ __launch_bounds__(kBlock) void gate_selftest_kernel(const float* __restrict__ box, const float* __restrict__ rays, size_t n,
+                                                               uint8_t* out_fast, uint8_t* out_exact) {
+    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = mk(rays + 6 * i), d = mk(rays + 6 * i + 3);
+    out_fast[i] = bbox_gate_fast(box, box + 3, o, d) ? 1 : 0;
+    out_exact[i] = bbox_gate(box, box + 3, o, d) ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Launch wrappers (called from api.cpp, which is plain C++)
 // ---------------------------------------------------------------------------------------------
@@ -612,7 +649,7 @@ size_t megakernel_gstack_bytes(uint32_t n_waves) { return size_t(n_waves) * kSta
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
     const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw;
     const size_t pool_pad = (size_t(pool) + 63u) & ~size_t(63);  // status + list: one byte per (padded) slot each
-    return (size_t(kFields) * pool + pool_pad / 2u + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
+    return (size_t(kFields) * pool + kCellDw + kTqDw + pool_pad / 2u + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
 }
 
 // n_waves single-wave workgroups; each loops until the global work counter (zeroed by the caller on
@@ -644,41 +681,6 @@ hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint3
     return hipGetLastError();
 }
 
-constexpr int kWgWaves = 4;
-size_t megakernel_wg_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
-    const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw;
-    const size_t qent = (size_t(kNumStatus) * pool + 1u) / 2u;
-    return (size_t(kFields) * pool + 16u + qent + size_t(kWgWaves) * stack_entries * 64u + scene) * sizeof(uint32_t);
-}
-int megakernel_wg_waves() { return kWgWaves; }
-
-// n_wg workgroups of kWgWaves waves, each workgroup with one shared pool of `pool` path slots.
-hipError_t launch_trace_megakernel_wg(const TraceParams& P, uint32_t n_wg, uint32_t pool, bool stats, hipStream_t stream) {
-    if (P.n_items == 0 || n_wg == 0) return hipSuccess;
-    const size_t lds = megakernel_wg_lds_bytes(pool, P.stack_entries, P.n_spheres, P.n_meshes);
-#define RBRT_LAUNCH_WG(POOLN)                                                                                        \
-    do {                                                                                                             \
-        if (stats)                                                                                                   \
-            hipLaunchKernelGGL((trace_megakernel_wg<kWgWaves, POOLN, true>), dim3(n_wg), dim3(64 * kWgWaves), lds,   \
-                               stream, P);                                                                           \
-        else                                                                                                         \
-            hipLaunchKernelGGL((trace_megakernel_wg<kWgWaves, POOLN, false>), dim3(n_wg), dim3(64 * kWgWaves), lds,  \
-                               stream, P);                                                                           \
-    } while (0)
-    if (pool == 384)
-        RBRT_LAUNCH_WG(384);
-    else if (pool == 448)
-        RBRT_LAUNCH_WG(448);
-    else if (pool == 512)
-        RBRT_LAUNCH_WG(512);
-    else if (pool == 640)
-        RBRT_LAUNCH_WG(640);
-    else
-        return hipErrorInvalidValue;
-#undef RBRT_LAUNCH_WG
-    return hipGetLastError();
-}
-
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream) {
     const size_t npix = size_t(R.n_local_tiles) * 64u;
     if (npix == 0) return hipSuccess;
@@ -702,6 +704,13 @@ hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, 
     hipLaunchKernelGGL(trace_rays_kernel, dim3(uint32_t((n + kRaysBlock - 1) / kRaysBlock)), dim3(kRaysBlock),
                        size_t(kStackMax) * kRaysBlock * sizeof(uint32_t), stream, P, rays, n, out_t, out_obj,
                        out_tri, out_dist);
+    return hipGetLastError();
+}
+
+hipError_t launch_gate_selftest(const float* d_box, const float* d_rays, size_t n, uint8_t* d_fast, uint8_t* d_exact) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gate_selftest_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, d_box, d_rays, n,
+                       d_fast, d_exact);
     return hipGetLastError();
 }
 

@@ -18,17 +18,26 @@
 // Which lane works on which path never affects the result: a path owns its RNG stream and its
 // sample slot, and resolve_kernel adds the samples of a pixel in sample order.
 
+#ifndef RBRT_FAST_GATE
+#define RBRT_FAST_GATE 1  // mesh bbox gate through bbox_gate_fast (same decisions, no IEEE divisions on the common path)
+#endif
 #ifndef RBRT_MK_WAVES_PER_SIMD
 #define RBRT_MK_WAVES_PER_SIMD 4  // register budget: 512 / 4 = 128 VGPRs per lane
 #endif
 
-enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_S0, F_S1, F_ITEM, F_META, F_DIST, F_T, F_TRI, F_WORD, kFields };
+// (the distance of the closest hit so far is not stored: it is a pure function of the ray and F_T -- the same
+// `length(o - (o + t*d))` expression that produced it -- and is recomputed where scene.rs:27,37 compares it)
+enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_S0, F_S1, F_ITEM, F_META, F_T, F_TRI, F_WORD, kFields };
+constexpr uint32_t kCellDw = 128u, kTqDw = 64u;  // LDS behind the pool: 64 x u64 result cells, 64 x u32 triangle-test queue
 enum : uint32_t { ST_EMPTY = 0u, ST_TRAV = 1u, ST_TERM = 2u, ST_LAMB = 3u, ST_METAL = 4u, ST_DIEL = 5u, kNumStatus = 6u,
                   ST_BUSY = 6u /* being traversed by a lane right now */ };
 constexpr int kSeqWords = kMaxPathDepth / 4;
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+__device__ __forceinline__ float lane_get(float v, int lane_byte_index) {  // v of another lane (every lane takes part)
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_byte_index, __float_as_int(v)));
 }
 // meta word: depth left [0,7) | records [7,14) | object id + 1 [14,22) | mesh index [22,30)
 __device__ __forceinline__ uint32_t pack_meta(uint32_t depth, uint32_t nrec, int32_t obj, uint32_t mesh) {
@@ -60,7 +69,7 @@ __device__ __forceinline__ uint32_t next_gated_mesh(const SceneLds& sc, uint32_t
     uint32_t m = m0;
     for (; m < n_meshes; ++m) {
         const float* md = reinterpret_cast<const float*>(sc.mesh + m * kMeshDw);
-        if (bbox_gate(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d)) {
+        if (RBRT_FAST_GATE ? bbox_gate_fast(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d) : bbox_gate(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d)) {
             if (STATS) ++lc.gate;
             break;
         }
@@ -132,15 +141,21 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t kPoolPad = (uint32_t(POOLN) + 63u) & ~63u;  // census loops run in groups of 64 slots
     uint32_t* const pool = lds;
-    uint8_t* const status = reinterpret_cast<uint8_t*>(pool + kFields * POOLN);  // [kPoolPad] one byte per slot
+    static_assert((kFields * POOLN) % 2 == 0, "the u64 cells must be 8-byte aligned");
+    // Leaf rounds (below): cell[l] collects the best (t, triangle index) found for lane l's ray by whichever lanes
+    // tested its triangles; tq is the queue of (triangle, owner lane) pairs of the chunk being tested.
+    unsigned long long* const cell = reinterpret_cast<unsigned long long*>(pool + kFields * POOLN);  // [64]
+    uint32_t* const tq = pool + kFields * POOLN + kCellDw;                                            // [64]
+    uint8_t* const status = reinterpret_cast<uint8_t*>(tq + kTqDw);              // [kPoolPad] one byte per slot
     uint8_t* const list = status + kPoolPad;                                     // [kPoolPad] slot ids (< 256)
     const uint32_t lane = threadIdx.x;
-    uint32_t* const stack_base = pool + kFields * POOLN + kPoolPad / 2u;         // 2 * kPoolPad bytes of byte arrays
+    uint32_t* const stack_base = tq + kTqDw + kPoolPad / 2u;                     // 2 * kPoolPad bytes of byte arrays
     uint32_t* const stack = stack_base + lane;
     uint32_t* const gseq = P.gseq + size_t(blockIdx.x) * kPoolMax * kSeqWords;
 #define POOL(f, s) pool[(f) * POOLN + (s)]
 
     for (uint32_t s = lane; s < kPoolPad; s += 64) status[s] = s < uint32_t(POOLN) ? ST_EMPTY : ST_BUSY;  // pad slots never match
+    cell[lane] = ~0ull;
     // scene tables behind the stacks
     const uint32_t n_obj = P.n_spheres + P.n_meshes;
     uint32_t* const sc_base = stack_base + P.stack_entries * 64u;
@@ -185,7 +200,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     float t_best = 0.0f;
     uint32_t t_best_idx = 0, t_mesh = 0;
     const BvhNode4* t_nodes = nullptr;
-    const BvhTri* t_tris = nullptr;
     uint32_t t_sp = 0;
     int32_t t_cur = 0;          // node to visit next: >= 0 inner, < 0 leaf, kNoChild = none (stack ran empty)
     int32_t t_pend = kNoChild;  // a leaf reached earlier whose triangles have not been tested yet
@@ -209,9 +223,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (__any(t_has_result)) {
             if (t_has_result) {
                 const uint32_t slot = t_slot;
-                float closest = __uint_as_float(POOL(F_DIST, slot));
                 const uint32_t meta = POOL(F_META, slot);
                 int32_t obj = int32_t((meta >> 14) & 255u) - 1;
+                float closest = 3.40282347e+38f;  // f32::MAX (scene.rs:21)
+                if (obj >= 0) {                   // dist_from_ray_orig of the closest hit so far, recomputed as it was computed
+                    const V3 pc = t_o + __uint_as_float(POOL(F_T, slot)) * t_d;
+                    closest = length(t_o - pc);
+                }
                 if (t_best > eps && t_best < 100000.0f) {  // triangle.rs:405
                     const V3 p = t_o + t_best * t_d;
                     const float dist = length(t_o - p);
@@ -220,7 +238,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         if (dist < closest) {
                             closest = dist;
                             obj = int32_t(P.n_spheres + t_mesh);
-                            POOL(F_DIST, slot) = __float_as_uint(dist);
                             POOL(F_T, slot) = __float_as_uint(t_best);
                             POOL(F_TRI, slot) = t_best_idx;
                         }
@@ -273,7 +290,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     t_mesh = (POOL(F_META, slot) >> 22) & 255u;
                     const uint32_t* md = sc.mesh + t_mesh * kMeshDw;
                     t_nodes = lds_ptr<BvhNode4>(md + MD_NODES);
-                    t_tris = lds_ptr<BvhTri>(md + MD_TRIS);
                     t_rc = make_cull(t_o, t_d, reinterpret_cast<const float*>(md) + MD_CENTER,
                                      __uint_as_float(md[MD_RADIUS]), P.eps_frac);
                     t_best = 1000000.0f;  // triangle.rs:398
@@ -321,29 +337,70 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     dg_lane_steps += uint32_t(__popcll(__ballot(t_active)));
                 }
                 // Leaves are deferred: a lane that reaches a leaf remembers it (one pending leaf per lane) and
-                // keeps walking; triangles are tested in rounds, when enough lanes hold a leaf or no lane can
-                // walk on. Testing later only delays the shrinking of t_best, it cannot change the result.
+                // keeps walking; triangles are tested in LEAF ROUNDS. Testing later only delays the shrinking of
+                // t_best, it cannot change the result.
                 if (t_active && t_cur < 0 && t_cur != kNoChild && t_pend == kNoChild) {
                     t_pend = t_cur;
                     t_cur = t_sp != 0 ? pop() : kNoChild;
                 }
                 const bool can_walk = t_active && t_cur >= 0;
-                // A lane is stalled when it holds a pending leaf and has reached another one (or the end of
-                // its walk): it idles through every node round until the next leaf round. A leaf round is
-                // run when enough lanes are stalled, when most lanes hold a leaf anyway, or when nobody can walk.
-                const uint32_t n_pend = uint32_t(__popcll(__ballot(t_active && t_pend != kNoChild)));
+                // A lane is stalled when it holds a pending leaf and has reached another one (or the end of its
+                // walk). A leaf round runs when the pending leaves hold a full wave of triangles, when enough
+                // lanes are stalled, or when nobody can walk.
+                const bool pend = t_active && t_pend != kNoChild;
+                const uint32_t pleaf = pend ? uint32_t(~t_pend) : 0u;  // (first << 2) | (count - 1)
+                const uint64_t mp = __ballot(pend), m0 = __ballot(pend && (pleaf & 1u)), m1 = __ballot(pend && (pleaf & 2u));
+                const uint32_t n_pend_tris = uint32_t(__popcll(mp)) + uint32_t(__popcll(m0)) + 2u * uint32_t(__popcll(m1));
                 const uint32_t n_stalled = uint32_t(__popcll(__ballot(t_active && !can_walk)));
                 if (STATS && __any(can_walk)) {
                     ++dg_walk_rounds;
                     dg_walk_lanes += uint32_t(__popcll(__ballot(can_walk)));
                 }
-                if (n_pend != 0 && (n_stalled >= P.leaf_round || n_pend >= 48u || !__any(can_walk))) {
+                if (n_pend_tris >= P.leaf_tris || (n_pend_tris != 0 && (n_stalled >= P.leaf_round || !__any(can_walk)))) {
+                    // ---- leaf round: the pending triangles are dealt out to ALL lanes, one triangle each ----
+                    // (a leaf holds 1..4 triangles and only some lanes hold a leaf: testing them where they are
+                    // pending ran at a third of the lanes.) Position p of the concatenated triangle list belongs to
+                    // the owner lane whose [prefix, prefix + count) contains it; lane j of a chunk tests position
+                    // B + j for its owner's ray (fetched with ds_bpermute) and merges the result into the owner's
+                    // cell with one LDS 64-bit atomic min on (t bits, reference index): t > eps > 0, so the integer
+                    // order of the key IS the lexicographic (t, index) order of triangle.rs:400's strict `<` scan.
+                    const uint32_t prefix = lane_rank(mp) + lane_rank(m0) + 2u * lane_rank(m1);
+                    const uint32_t n_mine = pend ? (pleaf & 3u) + 1u : 0u, first = pleaf >> 2;
                     if (STATS) {
                         ++dg_leaf_rounds;
-                        dg_leaf_lanes += n_pend;
+                        dg_leaf_lanes += n_pend_tris;
                     }
-                    if (t_active && t_pend != kNoChild) {
-                        leaf_test<STATS>(t_tris, t_pend, t_o, t_d, eps, P.eps_frac, t_best, t_best_idx, lc);
+                    for (uint32_t B = 0; B < n_pend_tris; B += 64u) {
+#pragma unroll
+                        for (uint32_t i = 0; i < uint32_t(kLeafMax); ++i) {
+                            const uint32_t pos = prefix + i - B;
+                            if (i < n_mine && pos < 64u) tq[pos] = ((first + i) << 6) | lane;
+                        }
+                        __syncthreads();
+                        const bool valid = B + lane < n_pend_tris;
+                        const uint32_t e = valid ? tq[lane] : lane;
+                        const uint32_t owner = e & 63u;
+                        const int ob = int(owner << 2);  // ds_bpermute takes a byte index
+                        const V3 ro = mk(lane_get(t_o.x, ob), lane_get(t_o.y, ob), lane_get(t_o.z, ob));
+                        const V3 rd = mk(lane_get(t_d.x, ob), lane_get(t_d.y, ob), lane_get(t_d.z, ob));
+                        const auto* tp = RBRT_AS1(f32x4, P.tris + (valid ? e >> 6 : 0u));
+                        const f32x4 ta = tp[0], tb = tp[1];
+                        const f32x2 tc = *RBRT_AS1(f32x2, tp + 2);  // the record's last 8 bytes are padding: not fetched
+                        float tt;
+                        const bool hit = tri_test(mk(ta.x, ta.y, ta.z), mk(ta.w, tb.x, tb.y), mk(tb.z, tb.w, tc.x), ro, rd, eps,
+                                                  P.eps_frac, tt);
+                        if (STATS && valid) ++lc.tris;
+                        if (valid && hit)
+                            atomicMin(&cell[owner], ((unsigned long long)__float_as_uint(tt) << 32) | __float_as_uint(tc.y));
+                        __syncthreads();
+                    }
+                    if (pend) {
+                        const unsigned long long k = cell[lane];
+                        cell[lane] = ~0ull;
+                        if (k < (((unsigned long long)__float_as_uint(t_best) << 32) | t_best_idx)) {
+                            t_best = __uint_as_float(uint32_t(k >> 32));
+                            t_best_idx = uint32_t(k);
+                        }
                         t_pend = kNoChild;
                     }
                 }
@@ -623,7 +680,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 POOL(F_S1, slot) = rng.s1;
                 POOL(F_ITEM, slot) = item;
                 POOL(F_WORD, slot) = word;
-                POOL(F_DIST, slot) = __float_as_uint(closest);
                 POOL(F_T, slot) = __float_as_uint(s_ht);
                 POOL(F_TRI, slot) = 0u;
                 POOL(F_META, slot) = pack_meta(depth, nrec, s_obj, gated < P.n_meshes ? gated : 0u);

@@ -133,3 +133,31 @@ def test_threaded_build_equals_single_threaded(oracle, monkeypatch):
         N, T, d, e = build(md)
         assert d == d1 and e == e1
         assert np.array_equal(N.view(np.uint32), N1.view(np.uint32)) and np.array_equal(T.view(np.uint32), T1.view(np.uint32))
+
+
+def test_depth_budget_adversarial_and_oversize(oracle):
+    """The 2-bit leaf count field holds at most 4 triangles. (1) 3000 coincident triangles (no spatial split exists:
+    the builder must fall back to median splits and still end with <= 4 per leaf inside the depth budget);
+    (2) a mesh above the 8,388,608 triangles the depth budget always accommodates is refused up front."""
+    tri = np.float32([[0, 0, -5], [1, 0, -5], [0, 1, -5]])
+    md = oracle.mesh_prep(np.tile(tri, (3000, 1, 1)))
+    N, T, depth, _ = build(md)
+    child = N[:, 24:28].view(np.int32)
+    leaves = child[(child < 0) & (child != NO_CHILD)]
+    counts = ((~leaves) & 3) + 1
+    firsts = (~leaves) >> 2
+    assert counts.max() <= 4 and depth <= 20
+    assert (firsts + counts).max() <= len(T)
+    assert counts.sum() == len(T)  # every record in exactly one leaf
+    big = np.zeros(8, np.float32)  # the size check comes before any array is read
+    m = abi.Mesh()
+    m.n_total = (4 << 21) + 8
+    m.n_real = m.n_total
+    for k in abi.MeshData.FIELDS:
+        setattr(m, k, abi.fptr(big))
+    m.is_padding = np.zeros(8, np.uint8).ctypes.data_as(abi.u8p)
+    m.mat = abi.material(abi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))
+    sc = abi.Scene(0, None, 1, C.pointer(m))
+    h = C.c_void_p()
+    assert abi.load_hip().rbrt_hip_scene_create(C.byref(sc), 0, C.byref(h)) == abi.RBRT_ERR_UNSUPPORTED
+    assert b"8,388,608" in abi.load_hip().rbrt_hip_last_error()

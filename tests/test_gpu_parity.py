@@ -329,7 +329,7 @@ def test_dragon_sized_mesh_cfg4(hip, oracle):
 def test_full_size_cfg2_invariants(hip, oracle, monkeypatch):
     """BASELINE config 2 at full size (1024x768x50, 69,451-triangle stand-in), too big for the brute-force
     oracle: the image must not depend on the pipeline depth, on the sample-batch size, on the tile
-    sharding, or on the kernel variant; a strided set of columns is compared with the oracle bit for bit."""
+    sharding; a strided set of columns is compared with the oracle bit for bit."""
     import hashlib
 
     import torch
@@ -367,12 +367,6 @@ def test_full_size_cfg2_invariants(hip, oracle, monkeypatch):
         hip.unpack_tiles(0, slots.data_ptr(), W, H, world, img.data_ptr(), None, None, rank_stride_pixels=slot)
         torch.cuda.synchronize()
         hashes["2 ranks merged"] = sha(img)
-    monkeypatch.setenv("RBRT_KERNEL", "wg")  # the workgroup-pool variant of the megakernel (read at scene creation)
-    with hip.HipScene(sc) as hs:
-        img.fill_(float("nan"))
-        hs.render_device(cam, abi.default_opts(spp=SPP, seed=1), img.data_ptr(), None, None)
-        torch.cuda.synchronize()
-        hashes["RBRT_KERNEL=wg"] = sha(img)
     assert len(set(hashes.values())) == 1, hashes
     assert not np.isnan(ref).any()
     stride = 64  # 16 columns x 768 rows x 50 spp through the brute-force oracle: a few seconds
@@ -444,3 +438,88 @@ def test_one_scene_many_cameras_and_sizes(hip, oracle):
         for (w, h, spp, seed), img in zip(jobs, outs):
             exp, _, _ = oracle.render(scenes.camera(oracle, w, h), sc, abi.default_opts(spp=spp, seed=seed))
             assert_same_image(img.cpu().numpy(), exp, f"{w}x{h}x{spp} seed {seed}")
+
+
+def test_division_free_mesh_gate_decides_like_the_ieee_form(hip, oracle):
+    """The megakernel's mesh gate forms its six slab quotients with v_rcp_f32 and falls back to the verbatim IEEE
+    form (aabbox.rs:28-58) only near a decision boundary. Both forms, and the oracle, on random rays, on rays aimed at
+    the box's faces, edges and corners to within a few ulp, and on zero / tiny / huge / non-finite components."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    lo, hi = np.float32([0.7825403, 0.57846975, -15.222859]), np.float32([7.573573, 7.4303217, -9.879498])  # config 2's mesh box
+    n = 400_000
+    o = (rng.normal(size=(n, 3)) * 12).astype(np.float32)
+    # targets ON the box surface: a random face point, snapped to edges / corners for a third of the rays
+    t = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    for k in range(3):
+        snap = rng.random(n) < 0.55
+        t[snap, k] = np.where(rng.random(snap.sum()) < 0.5, lo[k], hi[k])
+    d = (t - o).astype(np.float32)
+    d *= rng.choice(np.float32([1e-3, 0.3, 1.0, 1.0, 7.0, 1e4]), (n, 1))
+    ulps = rng.integers(-3, 4, (n, 3))
+    d = (d.view(np.int32) + ulps.astype(np.int32)).view(np.float32)  # nudge by a few ulp either way
+    rays = np.concatenate([o, d], 1)
+    # axis-parallel and degenerate directions, origins on / inside / outside the box
+    specials = np.float32([0.0, -0.0, 1e-38, -1e-38, 1e-31, 1e31, np.inf, -np.inf, np.nan, 1.0, -1.0])
+    extra = []
+    for a in specials:
+        for b in specials:
+            for org in ([0, 0, 0], [4, 4, -12], lo, hi, [lo[0], 4, -12], [4, hi[1], 30], [np.nan, 0, 0], [np.inf, 0, 0]):
+                extra.append([*org, a, b, -1.0])
+                extra.append([*org, -0.5, a, b])
+                extra.append([*org, b, 0.25, a])
+    rays = np.concatenate([rays, np.float32(extra)]).astype(np.float32)
+    n = len(rays)
+    fast, exact = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    abi.check(abi.load_hip().rbrt_hip_selftest_gate(abi.fptr(lo), abi.fptr(hi), abi.fptr(rays), n,
+                                                     fast.ctypes.data_as(abi.u8p), exact.ctypes.data_as(abi.u8p)))
+    assert np.array_equal(fast, exact), np.flatnonzero(fast != exact)[:10]
+    L = oracle.lib()
+    sub = np.concatenate([rng.choice(n - len(extra), 20000, replace=False), np.arange(n - len(extra), n)])
+    for i in sub:
+        assert bool(L.rbrt_oracle_kat_bbox_hit(oracle._p(lo), oracle._p(hi), oracle._p(rays[i]))) == bool(exact[i]), rays[i]
+    assert 0.2 < exact.mean() < 0.9
+
+
+def test_render_pass_checkpoint_and_resume(hip, oracle):
+    """rbrt_hip_render_pass: samples in ranges, running sums in a caller-owned buffer. A checkpoint (sums copied to the
+    host after 7 of 20 samples) resumed on a NEW scene handle gives the image of one uninterrupted call, bit for bit."""
+    import torch
+    cam = scenes.camera(oracle, 160, 120)
+    sc = scenes.example_scene(oracle, 2003)
+    spp, seed = 20, 6
+    exp, exp8, _ = oracle.render(cam, sc, abi.default_opts(spp=spp, seed=seed))
+    opts = abi.default_opts(spp=spp, seed=seed)
+    acc = torch.full((120, 160, 3), float("nan"), dtype=torch.float32, device="cuda")
+    with hip.HipScene(sc) as hs:
+        hs.render_pass(cam, opts, 0, 3, acc.data_ptr())
+        hs.render_pass(cam, opts, 3, 7, acc.data_ptr())
+        torch.cuda.synchronize()
+        hs.check()
+        checkpoint = acc.cpu().numpy().copy()  # what the host writes to disk, with sample_end = 7
+    assert not np.isnan(checkpoint).any()
+    acc2 = torch.from_numpy(checkpoint).cuda()
+    out = torch.full((120, 160, 3), float("nan"), dtype=torch.float32, device="cuda")
+    out8 = torch.zeros((120, 160, 3), dtype=torch.uint8, device="cuda")
+    with hip.HipScene(sc) as hs:
+        hs.render_pass(cam, opts, 7, 8, acc2.data_ptr())
+        hs.render_pass(cam, opts, 8, spp, acc2.data_ptr(), out.data_ptr(), out8.data_ptr())
+        torch.cuda.synchronize()
+        hs.check()
+        with pytest.raises(abi.RbrtError):
+            hs.render_pass(cam, opts, 5, 5, acc2.data_ptr())
+        with pytest.raises(abi.RbrtError):
+            hs.render_pass(cam, opts, 5, spp + 1, acc2.data_ptr())
+    assert_same_image(out.cpu().numpy(), exp, "resumed render")
+    assert np.array_equal(out8.cpu().numpy(), exp8)
+    # tile-sharded passes: packed accumulators per rank
+    n = hip.packed_pixels(160, 120, 1, 2)
+    accp = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    outp = torch.full((n, 3), float("nan"), dtype=torch.float32, device="cuda")
+    o2 = abi.default_opts(spp=spp, seed=seed, tile_rank=1, tile_world=2)
+    with hip.HipScene(sc) as hs:
+        hs.render_pass(cam, o2, 0, 11, accp.data_ptr())
+        hs.render_pass(cam, o2, 11, spp, accp.data_ptr(), outp.data_ptr())
+        torch.cuda.synchronize()
+    from rbrt_amd import tiles
+    assert np.array_equal(outp.cpu().numpy().view(np.uint32), tiles.pack(exp, 1, 2).view(np.uint32))

@@ -1,18 +1,22 @@
 #!/bin/bash
 # Profiles the default bench.py workload on the GPU box (run through gpurun from the repo root):
-#   1. rocprofv3 --kernel-trace --stats         -> per-kernel durations
+#   1. rocprofv3 --kernel-trace --stats of the ISOLATED run (--pipeline 1: launches do not overlap, so the CSV's
+#      average duration of trace_megakernel is the roofline's denominator) and of the default (pipelined) command
 #   2. separate --pmc passes (counters only, as gpurun requires): SQ activity, then the memory-side
 #      traffic counters (FETCH_SIZE and WRITE_SIZE need a pass each: MI355X_MICROARCH.md "rocprofv3 PMC slots")
-# Output under gpurun_out/profile/; tools/summarize_profile.py turns it into profiles/*.json|csv.
+# Output under gpurun_out/profile/; tools/summarize_profile.py <tag> turns it into profiles/<tag>_*.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profile
 rm -rf "$OUT" && mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-col-stride 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.err" || exit 1
+COMMON="--cpu-col-stride 0 --single-frames 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_isolated" -- python3 bench.py --steps 10 --warmup 2 --pipeline 1 $COMMON \
+    > "$OUT/bench_stats_isolated.json" 2> "$OUT/bench_stats_isolated.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_default" -- python3 bench.py --steps 10 --warmup 2 --isolated-steps 0 $COMMON \
+    > "$OUT/bench_stats_default.json" 2> "$OUT/bench_stats_default.err" || exit 1
 run_pmc() { # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 2 --warmup 0 --cpu-col-stride 0 --pipeline 1 \
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 2 --warmup 0 --pipeline 1 $COMMON \
       > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err" || { echo "pmc pass $name failed"; tail -3 "$OUT/bench_$name.err"; }
 }
 run_pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY

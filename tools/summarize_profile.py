@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Condenses gpurun_out/profile/ (made by tools/profile.sh on the GPU box) into the committed summaries:
 
-    profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats per-kernel table
+    profiles/<tag>_{isolated,default}_kernel_stats.csv   rocprofv3 --kernel-trace --stats per-kernel tables
     profiles/<tag>_pmc.json              counters per dispatch of the trace kernel + derived ratios
-    profiles/pmc_traffic.json            HBM-side bytes per launch, read by bench.py for roofline.traffic
+    profiles/<tag>_pmc_summary.json      HBM-side bytes per launch, VALU instruction count, lane utilisation:
+                                         read by bench.py for roofline.traffic / measured_hbm / valu_issue
 """
 import collections
 import csv
@@ -19,11 +20,16 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = ROOT / "profiles"
 out_dir.mkdir(exist_ok=True)
 
-stats = sorted(glob.glob(str(SRC / "stats" / "*" / "*kernel_stats.csv")), key=lambda f: Path(f).stat().st_mtime)
-if stats:
-    shutil.copy(stats[-1], out_dir / f"{tag}_kernel_stats.csv")
-bench = json.loads((SRC / "bench_stats.json").read_text().strip().splitlines()[-1])
-(out_dir / f"{tag}_bench_under_rocprof.json").write_text(json.dumps(bench, indent=1))
+bench = None
+for leg in ("isolated", "default"):
+    stats = sorted(glob.glob(str(SRC / f"stats_{leg}" / "*" / "*kernel_stats.csv")), key=lambda f: Path(f).stat().st_mtime)
+    if stats:
+        shutil.copy(stats[-1], out_dir / f"{tag}_{leg}_kernel_stats.csv")
+    jf = SRC / f"bench_stats_{leg}.json"
+    if jf.exists() and jf.read_text().strip():
+        b = json.loads(jf.read_text().strip().splitlines()[-1])
+        (out_dir / f"{tag}_{leg}_bench_under_rocprof.json").write_text(json.dumps(b, indent=1))
+        bench = bench or b
 
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = collections.defaultdict(set)
@@ -70,6 +76,13 @@ for k, d in res.items():
         if "TCC_EA0_RDREQ_sum" in c:
             rec["tcc_ea0_rdreq"] = c["TCC_EA0_RDREQ_sum"]
             rec["tcc_ea0_rdreq_32B"] = c.get("TCC_EA0_RDREQ_32B_sum")
-        (out_dir / "pmc_traffic.json").write_text(json.dumps(rec, indent=1))
-        print("traffic", json.dumps(rec))
+        if "SQ_INSTS_VALU" in c:
+            rec["sq_insts_valu"] = c["SQ_INSTS_VALU"]
+            rec["sq_insts_salu"] = c.get("SQ_INSTS_SALU")
+            rec["sq_lds_bank_conflict"] = c.get("SQ_LDS_BANK_CONFLICT")
+            rec["valu_lane_utilisation"] = d["derived"].get("valu_lane_utilisation")
+            rec["l2_hit_rate"] = d["derived"].get("l2_hit_rate")
+            rec["l1_hit_rate"] = d["derived"].get("l1_hit_rate")
+        (out_dir / f"{tag}_pmc_summary.json").write_text(json.dumps(rec, indent=1))
+        print("summary", json.dumps(rec))
 print(json.dumps({k: v["derived"] for k, v in res.items()}, indent=1))
