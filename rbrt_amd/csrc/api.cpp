@@ -112,8 +112,8 @@ struct rbrt_hip_scene {
     uint32_t stack_entries = kLdsStack;  // per-lane stack entries kept in LDS (RBRT_LDS_STACK)
     uint32_t y_low_water = 28;    // RBRT_Y_LOW
     uint32_t y_high_water = 28, y_high_min_parked = 16;  // RBRT_Y_HIGH, RBRT_Y_HIGH_PARKED
-    uint32_t leaf_round = 12;     // RBRT_LEAF_ROUND
-    uint32_t leaf_tris = 64;      // RBRT_LEAF_TRIS
+    uint32_t leaf_round = 6;      // RBRT_LEAF_ROUND
+    uint32_t leaf_tris = 32;      // RBRT_LEAF_TRIS
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
     // stats / timing
@@ -329,9 +329,9 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         const rbrt_mesh_t& m = scene->meshes[i];
         if (int rc = check_material(m.mat)) return rc;
-        // The BVH is at most kMaxBvhDepth + 1 inner levels deep with <= kLeafMax triangles per leaf (2-bit count
-        // field): 4 << 21 = 8,388,608 triangles is what always fits, whatever their arrangement (bvh.cpp capacity()).
-        if (m.n_total > (uint32_t(kLeafMax) << (kMaxBvhDepth + 1)))
+        // The BVH is at most kMaxBvhDepth + 1 inner levels deep with <= kLeafMax triangles per leaf: 4 << 21 =
+        // 8,388,608 triangles is what always fits, whatever their arrangement (bvh.cpp capacity()).
+        if (m.n_total > (4u << (kMaxBvhDepth + 1)))
             return fail(RBRT_ERR_UNSUPPORTED, "mesh has more than 8,388,608 triangles (BVH depth budget)");
         if (m.n_total && (!m.v0x || !m.v0y || !m.v0z || !m.e1x || !m.e1y || !m.e1z || !m.e2x || !m.e2y ||
                           !m.e2z || !m.nx || !m.ny || !m.nz || !m.is_padding))
@@ -378,14 +378,14 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         put_mat(scene->n_spheres + i, m.mat);
         BvhBuildResult bvh = build_bvh(m);
         const uint32_t tri_base = uint32_t(all_tris.size());
-        if (uint64_t(tri_base) + bvh.tris.size() >= (1ull << 26))
-            return bail(fail(RBRT_ERR_UNSUPPORTED, "more than 2^26 triangle records in one scene"));
+        if (uint64_t(tri_base) + bvh.tris.size() >= (1ull << 25))
+            return bail(fail(RBRT_ERR_UNSUPPORTED, "more than 2^25 triangle records in one scene"));
         if (tri_base != 0)
             for (BvhNode4& nd : bvh.nodes)
                 for (int c = 0; c < 4; ++c)
                     if (nd.child[c] < 0 && nd.child[c] != kNoChild) {
                         const uint32_t leaf = uint32_t(~nd.child[c]);
-                        nd.child[c] = ~int32_t((((leaf >> 2) + tri_base) << 2) | (leaf & 3u));
+                        nd.child[c] = ~int32_t((((leaf >> kLeafBits) + tri_base) << kLeafBits) | (leaf & uint32_t(kLeafMax - 1)));
                     }
         all_tris.insert(all_tris.end(), bvh.tris.begin(), bvh.tris.end());
         std::vector<Normal4> normals(m.n_total);

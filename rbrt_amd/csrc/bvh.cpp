@@ -128,7 +128,7 @@ struct Builder {
                   [](const Prim& x, const Prim& y) { return x.idx < y.idx; });
         for (size_t i = b; i < e; ++i) sk.tris.push_back(make_tri(prims[i].idx));
         ++sk.n_leaves;
-        return ChildInfo{~int32_t((first << 2) | (count - 1)), box, max_e12};
+        return ChildInfo{~int32_t((first << kLeafBits) | (count - 1)), box, max_e12};
     }
 
     // `top`: this call belongs to the single-threaded top of the tree; ranges of at most task_grain
@@ -244,7 +244,7 @@ struct Builder {
     static int32_t relocate(int32_t ref, uint32_t node_base, uint32_t tri_base) {
         if (ref >= 0) return int32_t(uint32_t(ref) + node_base);
         const uint32_t leaf = uint32_t(~ref);
-        return ~int32_t((((leaf >> 2) + tri_base) << 2) | (leaf & 3u));
+        return ~int32_t((((leaf >> kLeafBits) + tri_base) << kLeafBits) | (leaf & uint32_t(kLeafMax - 1)));
     }
 
     // Appends a finished task's nodes and leaf records to the final arrays; returns its root as the parent sees it.
@@ -324,7 +324,7 @@ struct Builder {
         out.tris.push_back(t);
         Box b;
         for (int k = 0; k < 3; ++k) b.lo[k] = b.hi[k] = 0.0f;
-        return ChildInfo{~int32_t((first << 2) | 0), b, 0.0f};
+        return ChildInfo{~int32_t((first << kLeafBits) | 0), b, 0.0f};
     }
 
     void run() {

@@ -12,7 +12,11 @@ constexpr int kMaxBvhDepth = 20;     // deepest 4-wide node (root = 0) the build
 constexpr int kStackMax = 3 * (kMaxBvhDepth + 1) + 1;  // a visit defers at most 3 children per level
 constexpr int kMaxPathDepth = 64;    // opts.max_depth limit (reference: 50, lib.rs:99)
 constexpr int kMaxObjects = 255;     // spheres + meshes (object id is stored in one byte per bounce)
-constexpr int kLeafMax = 4;          // triangles per leaf (2-bit count field)
+#ifndef RBRT_LEAF_BITS
+#define RBRT_LEAF_BITS 2
+#endif
+constexpr int kLeafBits = RBRT_LEAF_BITS;  // width of the count field of a leaf link
+constexpr int kLeafMax = 1 << kLeafBits;   // triangles per leaf
 constexpr int kPoolMax = 256;        // largest path pool per wave the persistent megakernel is built for
 constexpr uint32_t kWorkShards = 8;         // work-item counters (one per XCD)
 constexpr uint32_t kWorkCounterStride = 16;  // in u64: each counter on its own 128-B line
@@ -23,7 +27,7 @@ constexpr int kLdsStack = 8;         // per-lane traversal stack entries kept in
 // One 4-wide BVH node = 128 B = one cache line, fetched as 8 x dwordx4 by ONE lane: the four child boxes
 // as SoA (so the four slab tests are the same code on four registers), four child links and, per
 // child, max |e1|*|e2| of its subtree (the error-bound term of the culling pad).
-// child >= 0 : index of an inner node; child < 0 : leaf, ~child = (first_tri << 2) | (count - 1);
+// child >= 0 : index of an inner node; child < 0 : leaf, ~child = (first_tri << kLeafBits) | (count - 1);
 // kNoChild marks an unused slot, whose box is NaN so that every slab compare fails.
 constexpr int32_t kNoChild = INT32_MIN;
 struct alignas(128) BvhNode4 {

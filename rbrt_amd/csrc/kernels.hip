@@ -272,7 +272,8 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {
 }
 
 // Fetch one 128-B node (8 x dwordx4 by this lane) and test its four children; k[] comes back sorted by
-// entry distance (misses last), links = the four child links.
+// entry distance (misses last) -- or, with SORTED = false, in slot order --, links = the four child links.
+template <bool SORTED = true>
 __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull& rc, float eps, float best_t,
                                             uint32_t k[4], f32x4& links) {
     const char* nb = reinterpret_cast<const char*>(node);
@@ -293,11 +294,13 @@ __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull&
     k[1] = child_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, rc.inv, nodn, nodf, eps, best_t, 1u);
     k[2] = child_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, rc.inv, nodn, nodf, eps, best_t, 2u);
     k[3] = child_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, rc.inv, nodn, nodf, eps, best_t, 3u);
-    cswap(k[0], k[1]);
-    cswap(k[2], k[3]);
-    cswap(k[0], k[2]);
-    cswap(k[1], k[3]);
-    cswap(k[1], k[2]);
+    if (SORTED) {
+        cswap(k[0], k[1]);
+        cswap(k[2], k[3]);
+        cswap(k[0], k[2]);
+        cswap(k[1], k[3]);
+        cswap(k[1], k[2]);
+    }
 }
 __device__ __forceinline__ int32_t link_of(const f32x4& links, uint32_t key) {
     const uint32_t s = key & 3u;
@@ -305,34 +308,25 @@ __device__ __forceinline__ int32_t link_of(const f32x4& links, uint32_t key) {
     return __float_as_int(v);
 }
 
-// All triangles of one leaf (<= kLeafMax = 4), triangle.rs:189-255 + the arg-min rule of triangle.rs:400.
-// The (up to) 12 x 16-B loads are issued together so the leaf costs one memory round trip, not four;
-// slots past `count` re-read the last triangle and are masked out.
+// All triangles of one leaf (<= kLeafMax), triangle.rs:189-255 + the arg-min rule of triangle.rs:400 (the simple
+// one-thread-per-ray path; the megakernel deals the triangles of pending leaves out to all lanes instead).
 template <bool STATS>
 __device__ __forceinline__ void leaf_test(const BvhTri* tris, int32_t leaf_ref, V3 o, V3 d, float eps, float eps_frac,
                                           float& best_t, uint32_t& best_idx, LocalCounters& lc) {
     const uint32_t leaf = uint32_t(~leaf_ref);
-    const uint32_t first = leaf >> 2, last = leaf & 3u;  // last = count - 1
-    f32x4 a[4], b[4];
-    f32x2 c[4];  // the record's last 8 bytes are padding: not fetched
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-        const auto* tp = RBRT_AS1(f32x4, tris + first + (i < last ? i : last));
-        a[i] = tp[0], b[i] = tp[1], c[i] = *RBRT_AS1(f32x2, tp + 2);
-    }
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-        if (i <= last) {
-            if (STATS) ++lc.tris;
-            float t;
-            const bool hit = tri_test(mk(a[i].x, a[i].y, a[i].z), mk(a[i].w, b[i].x, b[i].y), mk(b[i].z, b[i].w, c[i].x),
-                                      o, d, eps, eps_frac, t);
-            const uint32_t idx = __float_as_uint(c[i].y);
-            // strict < keeps the first (lowest) index among equal t
-            if (hit && (t < best_t || (t == best_t && idx < best_idx))) {
-                best_t = t;
-                best_idx = idx;
-            }
+    const uint32_t first = leaf >> kLeafBits, last = leaf & uint32_t(kLeafMax - 1);  // last = count - 1
+    for (uint32_t i = 0; i <= last; ++i) {
+        const auto* tp = RBRT_AS1(f32x4, tris + first + i);
+        const f32x4 a = tp[0], b = tp[1];
+        const f32x2 c = *RBRT_AS1(f32x2, tp + 2);  // the record's last 8 bytes are padding: not fetched
+        if (STATS) ++lc.tris;
+        float t;
+        const bool hit = tri_test(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, eps, eps_frac, t);
+        const uint32_t idx = __float_as_uint(c.y);
+        // strict < keeps the first (lowest) index among equal t
+        if (hit && (t < best_t || (t == best_t && idx < best_idx))) {
+            best_t = t;
+            best_idx = idx;
         }
     }
 }
@@ -647,7 +641,7 @@ size_t megakernel_gseq_bytes(uint32_t n_waves) { return size_t(n_waves) * kPoolM
 size_t megakernel_gstack_bytes(uint32_t n_waves) { return size_t(n_waves) * kStackMax * 64u * sizeof(uint32_t); }
 
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
-    const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw;
+    const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw + kGenDw;
     const size_t pool_pad = (size_t(pool) + 63u) & ~size_t(63);  // status + list: one byte per (padded) slot each
     return (size_t(kFields) * pool + kCellDw + kTqDw + pool_pad / 2u + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
 }

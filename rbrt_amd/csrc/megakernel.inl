@@ -18,8 +18,16 @@
 // Which lane works on which path never affects the result: a path owns its RNG stream and its
 // sample slot, and resolve_kernel adds the samples of a pixel in sample order.
 
+#ifdef RBRT_MARKERS  // analysis build only (tools/static_cost.py): region markers in the instruction stream
+#define RBRT_MARK(name) asm volatile("; @@" name ::: "memory")
+#else
+#define RBRT_MARK(name)
+#endif
 #ifndef RBRT_FAST_GATE
 #define RBRT_FAST_GATE 1  // mesh bbox gate through bbox_gate_fast (same decisions, no IEEE divisions on the common path)
+#endif
+#ifndef RBRT_PUSH_ORDER
+#define RBRT_PUSH_ORDER 0  // 0: children pushed far-to-near (sorted); 1: nearest next, the rest in slot order
 #endif
 #ifndef RBRT_MK_WAVES_PER_SIMD
 #define RBRT_MK_WAVES_PER_SIMD 4  // register budget: 512 / 4 = 128 VGPRs per lane
@@ -33,6 +41,11 @@ enum : uint32_t { ST_EMPTY = 0u, ST_TRAV = 1u, ST_TERM = 2u, ST_LAMB = 3u, ST_ME
                   ST_BUSY = 6u /* being traversed by a lane right now */ };
 constexpr int kSeqWords = kMaxPathDepth / 4;
 
+// Wave-wide vote. HIP's __ballot / __any take an int: the predicate is first materialised with v_cndmask and then
+// compared again (two VALU instructions per vote, and this kernel votes several times per traversal step); the
+// builtin consumes the compare's SGPR mask directly.
+__device__ __forceinline__ uint64_t wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wany(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
@@ -52,6 +65,9 @@ enum { MD_NODES = 0, MD_TRIS = 2, MD_NORMALS = 4, MD_BBOX_LO = 6, MD_BBOX_HI = 9
 static_assert(offsetof(DevMesh, tris) == 8 && offsetof(DevMesh, normals) == 16 && offsetof(DevMesh, bbox_lo) == 24 &&
                   offsetof(DevMesh, bbox_hi) == 36 && offsetof(DevMesh, center) == 48 && offsetof(DevMesh, radius) == 60,
               "LDS scene table layout");
+// path-generation parameters in LDS (behind the scene tables), as dword indices
+enum { G_POS = 0, G_RIGHT = 3, G_UP = 6, G_CENTER = 9, G_MMH = 12, G_MMV, G_W, G_H, G_BATCH, G_BATCH_MAGIC, G_TILES_X,
+       G_TILES_X_MAGIC, G_TILE_WORLD, G_TILE_RANK, G_N_LOCAL, G_REVERSED, G_SAMPLE_BASE, G_MAX_DEPTH, G_SEED_LO, G_SEED_HI, kGenDw };
 struct SceneLds {
     const float* sph;      // [n_spheres][4]: centre xyz, radius
     const uint32_t* mat;   // [n_spheres + n_meshes][5]: albedo xyz, param, kind
@@ -169,7 +185,27 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         for (uint32_t i = lane; i < n_obj * kMatDw; i += 64) dst[i] = gm[i];
         dst += n_obj * kMatDw;
         for (uint32_t i = lane; i < P.n_meshes * kMeshDw; i += 64) dst[i] = gh[i];
+        // what path generation reads (camera, work decomposition): kept in LDS rather than in ~30 SGPRs that the
+        // rest of the kernel would have to spill around (the spill code is VALU: v_readlane / v_writelane)
+        dst += P.n_meshes * kMeshDw;
+        if (lane == 0) {
+            float* gf = reinterpret_cast<float*>(dst);
+            for (int c = 0; c < 3; ++c) {
+                gf[G_POS + c] = P.cam.position[c], gf[G_RIGHT + c] = P.cam.right[c];
+                gf[G_UP + c] = P.cam.up[c], gf[G_CENTER + c] = P.cam.img_center_point[c];
+            }
+            gf[G_MMH] = P.cam.mm_per_pix_hor, gf[G_MMV] = P.cam.mm_per_pix_vert;
+            dst[G_W] = P.cam.img_width_pix, dst[G_H] = P.cam.img_height_pix;
+            dst[G_BATCH] = P.batch, dst[G_BATCH_MAGIC] = P.batch_magic;
+            dst[G_TILES_X] = P.tiles_x, dst[G_TILES_X_MAGIC] = P.tiles_x_magic;
+            dst[G_TILE_WORLD] = P.tile_world, dst[G_TILE_RANK] = P.tile_rank;
+            dst[G_N_LOCAL] = P.n_local_tiles, dst[G_REVERSED] = P.tiles_reversed;
+            dst[G_SAMPLE_BASE] = P.sample_base, dst[G_MAX_DEPTH] = P.max_depth;
+            dst[G_SEED_LO] = uint32_t(P.seed_key), dst[G_SEED_HI] = uint32_t(P.seed_key >> 32);
+        }
     }
+    const uint32_t* const gp = sc_base + P.n_spheres * kSphDw + n_obj * kMatDw + P.n_meshes * kMeshDw;
+    const float* const gpf = reinterpret_cast<const float*>(gp);
     const SceneLds sc = {reinterpret_cast<const float*>(sc_base), sc_base + P.n_spheres * kSphDw,
                          sc_base + P.n_spheres * kSphDw + n_obj * kMatDw};
     // work items are reserved from the global counter in chunks, the next chunk asynchronously
@@ -192,8 +228,11 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     const float eps = P.min_dist;
 
     // ---- per-lane traversal state; lives in registers across shading passes ----
-    bool t_active = false;      // this lane is in the middle of a traversal
-    bool t_has_result = false;  // this lane finished a traversal that is not finalised yet
+    // (flags are integers in VGPRs and every vote below is a direct compare of one register: a vote on a composed
+    // bool costs two extra VALU instructions, v_cndmask + v_cmp, and the traversal step votes five times.
+    // Invariant: a lane that is not traversing has t_cur == t_pend == kNoChild.)
+    uint32_t t_active = 0;      // 1: this lane is in the middle of a traversal
+    uint32_t t_has_result = 0;  // 1: this lane finished a traversal that is not finalised yet
     uint32_t t_slot = 0;
     V3 t_o = mk(0.0f, 0.0f, 0.0f), t_d = t_o;
     RayCull t_rc = {t_o, t_o, 0u, 16u, 32u, 0.0f, 0.0f};
@@ -201,26 +240,32 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     uint32_t t_best_idx = 0, t_mesh = 0;
     const BvhNode4* t_nodes = nullptr;
     uint32_t t_sp = 0;
-    int32_t t_cur = 0;          // node to visit next: >= 0 inner, < 0 leaf, kNoChild = none (stack ran empty)
+    int32_t t_cur = kNoChild;   // node to visit next: >= 0 inner, < 0 leaf, kNoChild = none (stack ran empty)
     int32_t t_pend = kNoChild;  // a leaf reached earlier whose triangles have not been tested yet
     // The first P.stack_entries stack slots of a lane live in LDS, deeper ones in this wave's global scratch.
     uint32_t* const gstack = P.gstack + size_t(blockIdx.x) * kStackMax * 64u + lane;
     const uint32_t n_lds_stack = P.stack_entries;
+    // (volatile LDS accesses: otherwise the two arms are merged into one access through a selected generic
+    // pointer, i.e. a flat_store / flat_load plus a dozen address instructions on the hottest path of the kernel)
+    typedef volatile __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* const stack_lds = (lds_u32*)stack;
     auto push = [&](int32_t v) {
-        if (t_sp < n_lds_stack)
-            stack[t_sp * 64u] = uint32_t(v);
+        if (__builtin_expect(t_sp < n_lds_stack, 1))
+            stack_lds[t_sp * 64u] = uint32_t(v);
         else
             gstack[(t_sp - n_lds_stack) * 64u] = uint32_t(v);
         ++t_sp;
     };
     auto pop = [&]() -> int32_t {
         --t_sp;
-        return int32_t(t_sp < n_lds_stack ? stack[t_sp * 64u] : gstack[(t_sp - n_lds_stack) * 64u]);
+        if (__builtin_expect(t_sp < n_lds_stack, 1)) return int32_t(stack_lds[t_sp * 64u]);
+        return int32_t(gstack[(t_sp - n_lds_stack) * 64u]);
     };
 
     for (;;) {
+        RBRT_MARK("finalise");
         // ---- finalise finished traversals in a batch (mesh.rs:245-266, scene.rs:33-41) ----
-        if (__any(t_has_result)) {
+        if (wany(t_has_result != 0u)) {
             if (t_has_result) {
                 const uint32_t slot = t_slot;
                 const uint32_t meta = POOL(F_META, slot);
@@ -247,21 +292,23 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 const uint32_t depth = meta & 127u;
                 POOL(F_META, slot) = pack_meta(depth, (meta >> 7) & 127u, obj, m2 < P.n_meshes ? m2 : 0u);
                 status[slot] = m2 < P.n_meshes ? ST_TRAV : classify(sc, obj, depth);
-                t_has_result = false;
+                t_has_result = 0;
             }
         }
         __syncthreads();
+        RBRT_MARK("census");
         // ---- census: how many slots wait for each kind of work ---------------------------------
         uint32_t cnt[kNumStatus] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (uint32_t g = 0; g < kPoolPad; g += 64) {
             const uint32_t st = status[g + lane];
 #pragma unroll
-            for (uint32_t k = 0; k < kNumStatus; ++k) cnt[k] += uint32_t(__popcll(__ballot(st == k)));
+            for (uint32_t k = 0; k < kNumStatus; ++k) cnt[k] += uint32_t(__popcll(wballot(st == k)));
         }
         if (STATS) ++dg_census, dg_dr_rounds += more_work ? 0u : 1u;
-        uint32_t n_active = uint32_t(__popcll(__ballot(t_active)));
+        uint32_t n_active = uint32_t(__popcll(wballot(t_active != 0u)));
 
+        RBRT_MARK("refill");
         // ---- idle lanes take parked rays (in batches: only when enough lanes are idle) ----
         // with plenty of parked rays the lanes are topped up sooner (y_high_water) than when few wait
         const uint32_t y_refill = cnt[ST_TRAV] >= P.y_high_min_parked ? P.y_high_water : P.y_low_water;
@@ -270,13 +317,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 #pragma unroll
             for (uint32_t g = 0; g < kPoolPad; g += 64) {
                 const bool m = status[g + lane] == ST_TRAV;
-                const uint64_t mask = __ballot(m);
+                const uint64_t mask = wballot(m);
                 if (m) list[ny + lane_rank(mask)] = uint8_t(g + lane);
                 ny += uint32_t(__popcll(mask));
             }
             __syncthreads();
             if (STATS) ++dg_refills;
-            const uint64_t idle = __ballot(!t_active);
+            const uint64_t idle = wballot(t_active == 0u);
             if (!t_active) {
                 const uint32_t k = lane_rank(idle);
                 if (k < ny) {
@@ -297,7 +344,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     t_sp = 0;
                     t_cur = 0;
                     t_pend = kNoChild;
-                    t_active = true;
+                    t_active = 1;
                     if (STATS) ++dg_lanes[ST_TRAV];
                 }
             }
@@ -306,6 +353,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             n_active += taken;
         }
 
+        RBRT_MARK("choose");
         // ---- pick the shading kind with the most waiting slots ----
         // A TERM pass also starts new paths in empty slots while work is left.
         const uint32_t n_gen_slots = more_work ? cnt[ST_EMPTY] : 0u;
@@ -330,33 +378,42 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             const uint32_t y_keep = cnt[ST_TRAV] >= P.y_high_min_parked ? P.y_high_water : P.y_low_water;
             const uint32_t keep = (best != 0 || cnt[ST_TRAV] != 0) ? (n_active < y_keep ? n_active : y_keep)
                                                                    : n_active;
+        RBRT_MARK("burst_top");
             do {
                 if (STATS) {
                     ++dg_steps;
-                    if (!more_work) ++dg_dr_steps, dg_dr_lane_steps += uint32_t(__popcll(__ballot(t_active)));
-                    dg_lane_steps += uint32_t(__popcll(__ballot(t_active)));
+                    if (!more_work) ++dg_dr_steps, dg_dr_lane_steps += uint32_t(__popcll(wballot(t_active != 0u)));
+                    dg_lane_steps += uint32_t(__popcll(wballot(t_active != 0u)));
                 }
                 // Leaves are deferred: a lane that reaches a leaf remembers it (one pending leaf per lane) and
                 // keeps walking; triangles are tested in LEAF ROUNDS. Testing later only delays the shrinking of
                 // t_best, it cannot change the result.
-                if (t_active && t_cur < 0 && t_cur != kNoChild && t_pend == kNoChild) {
+                if (t_cur < 0 && t_cur != kNoChild && t_pend == kNoChild) {
                     t_pend = t_cur;
                     t_cur = t_sp != 0 ? pop() : kNoChild;
                 }
-                const bool can_walk = t_active && t_cur >= 0;
+                const bool can_walk = t_cur >= 0;
+                const uint64_t walk_mask = wballot(t_cur >= 0), active_mask = wballot(t_active != 0u);
                 // A lane is stalled when it holds a pending leaf and has reached another one (or the end of its
                 // walk). A leaf round runs when the pending leaves hold a full wave of triangles, when enough
                 // lanes are stalled, or when nobody can walk.
-                const bool pend = t_active && t_pend != kNoChild;
-                const uint32_t pleaf = pend ? uint32_t(~t_pend) : 0u;  // (first << 2) | (count - 1)
-                const uint64_t mp = __ballot(pend), m0 = __ballot(pend && (pleaf & 1u)), m1 = __ballot(pend && (pleaf & 2u));
-                const uint32_t n_pend_tris = uint32_t(__popcll(mp)) + uint32_t(__popcll(m0)) + 2u * uint32_t(__popcll(m1));
-                const uint32_t n_stalled = uint32_t(__popcll(__ballot(t_active && !can_walk)));
-                if (STATS && __any(can_walk)) {
-                    ++dg_walk_rounds;
-                    dg_walk_lanes += uint32_t(__popcll(__ballot(can_walk)));
+                const bool pend = t_pend != kNoChild;
+                const uint32_t pleaf = pend ? uint32_t(~t_pend) : 0u;  // (first << kLeafBits) | (count - 1)
+                const uint64_t mp = wballot(t_pend != kNoChild);
+                uint64_t mb[kLeafBits];  // per bit of (count - 1): the lanes that have it set
+                uint32_t n_pend_tris = uint32_t(__popcll(mp));
+#pragma unroll
+                for (int b = 0; b < kLeafBits; ++b) {
+                    mb[b] = wballot(((pleaf >> b) & 1u) != 0u);  // (pleaf is 0 in lanes without a pending leaf)
+                    n_pend_tris += uint32_t(__popcll(mb[b])) << b;
                 }
-                if (n_pend_tris >= P.leaf_tris || (n_pend_tris != 0 && (n_stalled >= P.leaf_round || !__any(can_walk)))) {
+                const uint32_t n_stalled = uint32_t(__popcll(active_mask & ~walk_mask));
+                if (STATS && walk_mask != 0ull) {
+                    ++dg_walk_rounds;
+                    dg_walk_lanes += uint32_t(__popcll(walk_mask));
+                }
+                if (n_pend_tris >= P.leaf_tris || (n_pend_tris != 0 && (n_stalled >= P.leaf_round || walk_mask == 0ull))) {
+        RBRT_MARK("leaf_round");
                     // ---- leaf round: the pending triangles are dealt out to ALL lanes, one triangle each ----
                     // (a leaf holds 1..4 triangles and only some lanes hold a leaf: testing them where they are
                     // pending ran at a third of the lanes.) Position p of the concatenated triangle list belongs to
@@ -364,12 +421,15 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     // B + j for its owner's ray (fetched with ds_bpermute) and merges the result into the owner's
                     // cell with one LDS 64-bit atomic min on (t bits, reference index): t > eps > 0, so the integer
                     // order of the key IS the lexicographic (t, index) order of triangle.rs:400's strict `<` scan.
-                    const uint32_t prefix = lane_rank(mp) + lane_rank(m0) + 2u * lane_rank(m1);
-                    const uint32_t n_mine = pend ? (pleaf & 3u) + 1u : 0u, first = pleaf >> 2;
+                    uint32_t prefix = lane_rank(mp);
+#pragma unroll
+                    for (int b = 0; b < kLeafBits; ++b) prefix += lane_rank(mb[b]) << b;
+                    const uint32_t n_mine = pend ? (pleaf & uint32_t(kLeafMax - 1)) + 1u : 0u, first = pleaf >> kLeafBits;
                     if (STATS) {
                         ++dg_leaf_rounds;
                         dg_leaf_lanes += n_pend_tris;
                     }
+        RBRT_MARK("leaf_chunk");
                     for (uint32_t B = 0; B < n_pend_tris; B += 64u) {
 #pragma unroll
                         for (uint32_t i = 0; i < uint32_t(kLeafMax); ++i) {
@@ -404,11 +464,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         t_pend = kNoChild;
                     }
                 }
+        RBRT_MARK("walk");
                 if (can_walk) {
                     uint32_t k[4];
                     f32x4 links;
-                    node4_visit(t_nodes + t_cur, t_rc, eps, t_best, k, links);
+                    node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links);
                     if (STATS) ++lc.nodes;
+#if RBRT_PUSH_ORDER == 0
                     if (k[0] != kMissKey) {  // farthest first, so that the nearest is popped first
                         if (k[3] != kMissKey) push(link_of(links, k[3]));
                         if (k[2] != kMissKey) push(link_of(links, k[2]));
@@ -417,16 +479,32 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     } else {
                         t_cur = t_sp != 0 ? pop() : kNoChild;
                     }
+#else
+                    // the nearest child next, the other hit children onto the stack in slot order (no sort, no
+                    // per-entry link selection); keys are distinct (the slot is in their low bits)
+                    const uint32_t kmin = min(min(k[0], k[1]), min(k[2], k[3]));
+                    if (kmin != kMissKey) {
+                        if (k[0] != kMissKey && k[0] != kmin) push(__float_as_int(links.x));
+                        if (k[1] != kMissKey && k[1] != kmin) push(__float_as_int(links.y));
+                        if (k[2] != kMissKey && k[2] != kmin) push(__float_as_int(links.z));
+                        if (k[3] != kMissKey && k[3] != kmin) push(__float_as_int(links.w));
+                        t_cur = link_of(links, kmin);
+                    } else {
+                        t_cur = t_sp != 0 ? pop() : kNoChild;
+                    }
+#endif
                 }
                 if (t_active && t_cur == kNoChild && t_pend == kNoChild) {
-                    t_active = false;
-                    t_has_result = true;
+                    t_active = 0;
+                    t_has_result = 1;
                 }
-            } while (uint32_t(__popcll(__ballot(t_active))) >= keep);
+        RBRT_MARK("burst_end");
+            } while (uint32_t(__popcll(wballot(t_active != 0u))) >= keep);
             if (STATS) dg_t_trav += __builtin_amdgcn_s_memtime() - dg_tk;
             continue;
         }
 
+        RBRT_MARK("pass_lists");
         // ============================ shading pass of one kind ===============================
         if (STATS) {
             ++dg_pass[kind];
@@ -437,7 +515,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 #pragma unroll
         for (uint32_t g = 0; g < kPoolPad; g += 64) {
             const bool m = status[g + lane] == kind;
-            const uint64_t mask = __ballot(m);
+            const uint64_t mask = wballot(m);
             if (m) list[c0 + lane_rank(mask)] = uint8_t(g + lane);
             c0 += uint32_t(__popcll(mask));
         }
@@ -446,7 +524,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 #pragma unroll
             for (uint32_t g = 0; g < kPoolPad; g += 64) {
                 const bool m = status[g + lane] == ST_EMPTY;
-                const uint64_t mask = __ballot(m);
+                const uint64_t mask = wballot(m);
                 if (m) list[c0 + c1 + lane_rank(mask)] = uint8_t(g + lane);  // c0 + c1 <= POOLN
                 c1 += uint32_t(__popcll(mask));
             }
@@ -463,6 +541,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         uint32_t item = 0, depth = 0, nrec = 0, word = 0;
         bool have_ray = false;
 
+        RBRT_MARK("term");
         if (kind == ST_TERM) {
             bool need_new = is_gen;
             if (is_main) {
@@ -507,8 +586,9 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 if (STATS) ++n_samples_done;
                 need_new = true;
             }
+        RBRT_MARK("gen");
             // ---- new paths (cam.rs:64-82); work items come from the sharded global counters ----
-            const uint64_t want = __ballot(need_new && more_work);
+            const uint64_t want = wballot(need_new && more_work);
             if (want) {
                 const uint32_t n_want = uint32_t(__popcll(want));
                 const uint32_t avail = work.res_end - work.res_next;
@@ -523,27 +603,30 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     if (rk < avail || it < new_hi) {
                         const uint32_t pp = it & 63u;
                         const uint32_t ts = it >> 6;
-                        const uint32_t tpos = div_magic(ts, P.batch, P.batch_magic);
-                        const uint32_t s = ts - tpos * P.batch;
-                        const uint32_t tile_local = P.tiles_reversed ? P.n_local_tiles - 1u - tpos : tpos;  // row-major, either way
+                        const uint32_t batch = gp[G_BATCH];
+                        const uint32_t tpos = div_magic(ts, batch, gp[G_BATCH_MAGIC]);
+                        const uint32_t s = ts - tpos * batch;
+                        const uint32_t tile_local = gp[G_REVERSED] ? gp[G_N_LOCAL] - 1u - tpos : tpos;  // row-major, either way
                         item = s * uint32_t(npix) + tile_local * 64u + pp;       // < 2^32: the host sizes batches so
-                        const uint32_t tile = tile_local * P.tile_world + P.tile_rank;
-                        const uint32_t ty = div_magic(tile, P.tiles_x, P.tiles_x_magic), tx = tile - ty * P.tiles_x;
+                        const uint32_t tile = tile_local * gp[G_TILE_WORLD] + gp[G_TILE_RANK];
+                        const uint32_t tiles_x = gp[G_TILES_X];
+                        const uint32_t ty = div_magic(tile, tiles_x, gp[G_TILES_X_MAGIC]), tx = tile - ty * tiles_x;
                         const uint32_t row = ty * RBRT_TILE + (pp >> 3), col = tx * RBRT_TILE + (pp & 7u);
-                        if (row < P.cam.img_height_pix && col < P.cam.img_width_pix) {
-                            rng.init(P.seed_key, row * P.cam.img_width_pix + col, P.sample_base + s);
-                            const float col_off = float(col) - float(P.cam.img_width_pix / 2);
-                            const float row_off = float(row) - float(P.cam.img_height_pix / 2);
+                        const uint32_t img_w = gp[G_W], img_h = gp[G_H];
+                        if (row < img_h && col < img_w) {
+                            rng.init((uint64_t(gp[G_SEED_HI]) << 32) | gp[G_SEED_LO], row * img_w + col, gp[G_SAMPLE_BASE] + s);
+                            const float col_off = float(col) - float(img_w / 2);
+                            const float row_off = float(row) - float(img_h / 2);
                             const float u0 = rng.next_f32();
-                            const float col_mm = ((col_off + u0) - 0.5f) * P.cam.mm_per_pix_hor;
+                            const float col_mm = ((col_off + u0) - 0.5f) * gpf[G_MMH];
                             const float u1 = rng.next_f32();
-                            const float row_mm = ((row_off + u1) - 0.5f) * P.cam.mm_per_pix_vert;
-                            const V3 pos = mk(P.cam.position);
-                            const V3 target = (mk(P.cam.img_center_point) + (0.001f * col_mm) * mk(P.cam.right)) -
-                                              (0.001f * row_mm) * mk(P.cam.up);
+                            const float row_mm = ((row_off + u1) - 0.5f) * gpf[G_MMV];
+                            const V3 pos = mk(gpf + G_POS);
+                            const V3 target = (mk(gpf + G_CENTER) + (0.001f * col_mm) * mk(gpf + G_RIGHT)) -
+                                              (0.001f * row_mm) * mk(gpf + G_UP);
                             o = pos;
                             d = normalize(target - pos);
-                            depth = P.max_depth;
+                            depth = gp[G_MAX_DEPTH];
                             nrec = 0;
                             word = 0;
                             have_ray = true;
@@ -560,6 +643,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 if (more_work && work.res_end - work.res_next < 64u) work.prefetch(P, lane);
             }
         }
+        RBRT_MARK("scatter_load");
         // ---- RayScattering::scatter, then the closest sphere + mesh gate for the new ray ----
         // In the first round every lane shades the pass's kind (wave-uniform branches). A lane whose new
         // ray passes no mesh gate already knows its next hit; when that needs shading again it may stay
@@ -587,6 +671,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             s_ht = __uint_as_float(POOL(F_T, slot));
             s_tri = POOL(F_TRI, slot);
         }
+        RBRT_MARK("round_top");
         for (uint32_t round = 1;; ++round) {
             if (scat) {
                 const V3 p = o + s_ht * d;  // same expression as inside the intersection routines
@@ -607,6 +692,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 }
                 V3 nd;
                 bool ok;
+                RBRT_MARK("scatter_kind");
                 if (lk == ST_LAMB) {  // lambertian.rs:11-24
                     const V3 target = (p + normalize(n)) + random_point_in_unit_sphere(rng);
                     nd = normalize(target - p);
@@ -645,6 +731,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             // closest sphere + mesh gate for the new ray (scene.rs:19-43 up to the meshes)
             uint32_t gated = 0, next = ST_TERM;
             float closest = 3.40282347e+38f;
+        RBRT_MARK("spheres_gate");
             if (have_ray) {
                 if (STATS) ++lc.rays;
                 s_obj = -1;
@@ -660,13 +747,15 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         }
                     }
                 }
+                RBRT_MARK("gate");
                 gated = next_gated_mesh<STATS>(sc, P.n_meshes, 0, o, d, lc);
                 next = gated < P.n_meshes ? uint32_t(ST_TRAV) : classify(sc, s_obj, depth);
             }
             // stay in registers? only sphere hits that need shading, while enough lanes do (or the wave
             // has no other work left), and for a bounded number of rounds
+            RBRT_MARK("park");
             const bool cand = have_ray && next >= ST_LAMB;
-            const uint32_t n_cand = uint32_t(__popcll(__ballot(cand)));
+            const uint32_t n_cand = uint32_t(__popcll(wballot(cand)));
             const bool go = n_cand != 0 && round < kMaxShadeRounds &&
                             (more_work ? (round < P.shade_rounds && n_cand >= P.shade_cont_min) : true);
             if (have_ray && !(cand && go)) {

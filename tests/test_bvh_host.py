@@ -9,6 +9,8 @@ import scenes
 from rbrt_amd import abi
 
 NO_CHILD = -2 ** 31
+LEAF_BITS = 2  # device_types.h kLeafBits (RBRT_LEAF_BITS)
+LEAF_MAX = 1 << LEAF_BITS
 
 
 def build(md):
@@ -64,7 +66,7 @@ def test_bvh4_invariants(oracle, n_tris):
             if c >= 0:
                 lo, hi, e = check(c, d + 1)
             else:
-                first, cnt = (~c) >> 2, ((~c) & 3) + 1
+                first, cnt = (~c) >> LEAF_BITS, ((~c) & (LEAF_MAX - 1)) + 1
                 lo, hi = tlo[first:first + cnt].min(0), thi[first:first + cnt].max(0)
                 e = e12[first:first + cnt].max()
                 assert (np.diff(idx[first:first + cnt].astype(np.int64)) > 0).all()  # ascending index inside a leaf
@@ -106,7 +108,7 @@ def test_bvh_culling_keeps_the_brute_force_winner(oracle):
         while stack:
             node = stack.pop()
             if node < 0:
-                first, cnt = (~node) >> 2, ((~node) & 3) + 1
+                first, cnt = (~node) >> LEAF_BITS, ((~node) & (LEAF_MAX - 1)) + 1
                 reached.update(idx[first:first + cnt].tolist())
                 continue
             for k in range(4):
@@ -144,9 +146,9 @@ def test_depth_budget_adversarial_and_oversize(oracle):
     N, T, depth, _ = build(md)
     child = N[:, 24:28].view(np.int32)
     leaves = child[(child < 0) & (child != NO_CHILD)]
-    counts = ((~leaves) & 3) + 1
-    firsts = (~leaves) >> 2
-    assert counts.max() <= 4 and depth <= 20
+    counts = ((~leaves) & (LEAF_MAX - 1)) + 1
+    firsts = (~leaves) >> LEAF_BITS
+    assert counts.max() <= LEAF_MAX and depth <= 20
     assert (firsts + counts).max() <= len(T)
     assert counts.sum() == len(T)  # every record in exactly one leaf
     big = np.zeros(8, np.float32)  # the size check comes before any array is read

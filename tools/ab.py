@@ -30,15 +30,16 @@ def main():
                     k, val = kv.split("=", 1)
                     env[k] = val
             cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", str(args.steps), "--warmup", "2",
-                   "--cpu-col-stride", "0"] + args.extra.split()
+                   "--cpu-col-stride", "0", "--single-frames", "0", "--isolated-steps", "6"] + args.extra.split()
             p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             if p.returncode != 0:
                 print(f"[{v}] FAILED rc={p.returncode}: {p.stderr[-400:]}", flush=True)
                 continue
             j = json.loads(p.stdout.strip().splitlines()[-1])
             res[v].append((j["roofline"]["kernel_ms"], j["value"], j["roofline"]["frac"], j["ms_per_step"]))
-            print(f"round {r} [{v}] kernel_ms={j['roofline']['kernel_ms']} ms_per_step={j['ms_per_step']} value={j['value']} frac={j['roofline']['frac']}",
-                  flush=True)
+            c = j["roofline"]["counters"]
+            print(f"round {r} [{v}] isolated_kernel_ms={j['roofline']['kernel_ms']} ms_per_step={j['ms_per_step']} value={j['value']} "
+                  f"nodes={c['nodes_visited'] / 1e6:.1f}M tris={c['tris_tested'] / 1e6:.1f}M sha={j['config']['image_sha256_16']}", flush=True)
     print("---- summary (min / median kernel_ms) ----")
     for v, xs in res.items():
         if xs:
