@@ -114,6 +114,7 @@ struct rbrt_hip_scene {
     uint32_t y_high_water = 28, y_high_min_parked = 16;  // RBRT_Y_HIGH, RBRT_Y_HIGH_PARKED
     uint32_t leaf_round = 6;      // RBRT_LEAF_ROUND
     uint32_t leaf_tris = 32;      // RBRT_LEAF_TRIS
+    uint32_t drain_mode = 1;      // RBRT_DRAIN_MODE
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
     // stats / timing
@@ -153,7 +154,8 @@ int upload(rbrt_hip_scene* s, const std::vector<T>& host, T** out) {
 
 uint32_t div_magic_of(uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : uint32_t(0x100000000ull / d); }  // kernels.hip div_magic
 
-constexpr uint32_t kMaxPipeline = 4;
+constexpr uint32_t kMaxPipeline = 8;
+constexpr uint32_t kLanesAtCreate = 4;  // lanes made by scene_create (deeper pipelines: rbrt_hip_scene_set_pipeline makes the rest)
 constexpr size_t kMaxTimedLaunches = 4096;  // timing events are recycled per set_timing, never more than this many launches
 
 // Launches under 24 M (pixel, sample) items -- a GPU's share of a sharded frame -- are "short": their fixed-cost
@@ -467,6 +469,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             int v = std::atoi(e);
             if (v >= 1 && v <= 256) s->leaf_tris = uint32_t(v);
         }
+        if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 3u;
         if (const char* e = std::getenv("RBRT_SHADE_ROUNDS")) {
             int v = std::atoi(e);
             if (v >= 1 && v <= int(kMaxShadeRounds)) s->shade_rounds = uint32_t(v);
@@ -475,13 +478,13 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             int v = std::atoi(e);
             if (v >= 1 && v <= 64) s->shade_cont_min = uint32_t(v);
         }
-        s->scratch_waves = uint32_t(cus) * 32u;  // per-wave scratch is indexed by workgroup (= wave)
+        s->scratch_waves = s->n_waves;  // per-wave scratch is indexed by workgroup (= wave); no grid is larger than n_waves
         if (const char* e = std::getenv("RBRT_PIPELINE")) {
             int v = std::atoi(e);
             if (v >= 0 && v <= int(kMaxPipeline)) s->pipeline = uint32_t(v);
         }
         // all lanes up front: rbrt_hip_render_device then never allocates lanes (which synchronises the device)
-        if (int rc = ensure_lanes(s, kMaxPipeline)) return bail(rc);
+        if (int rc = ensure_lanes(s, std::max(kLanesAtCreate, s->pipeline))) return bail(rc);
         if (const char* e = std::getenv("RBRT_POISON_SAMPLES")) s->poison_samples = e[0] == '1';
     }
     *out = s;
@@ -608,6 +611,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.y_high_min_parked = s->y_high_min_parked;
     P.leaf_round = s->leaf_round;
     P.leaf_tris = s->leaf_tris;
+    P.drain_mode = s->drain_mode;
     P.shade_rounds = s->shade_rounds;
     P.shade_cont_min = s->shade_cont_min;
 
@@ -704,7 +708,7 @@ int rbrt_hip_render_pass(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const rb
 
 int rbrt_hip_scene_set_pipeline(rbrt_hip_scene_t* s, uint32_t depth) {
     if (!s) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: null scene");
-    if (depth > kMaxPipeline) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: depth must be 0 (automatic) or 1..4");
+    if (depth > kMaxPipeline) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: depth must be 0 (automatic) or 1..8");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     s->pipeline = depth;

@@ -125,6 +125,7 @@ struct TraceParams {
     uint32_t y_high_water, y_high_min_parked;  // ... or fewer than y_high_water while at least that many rays are parked
     uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one ...
     uint32_t leaf_tris;                // ... or once the pending leaves hold this many triangles (a leaf round deals them out to all lanes)
+    uint32_t drain_mode;               // scheduling once the work items have run out (bits: megakernel.inl "drain")
     uint32_t shade_rounds;             // shading pass: rounds a sphere-only bounce chain may stay in registers
     uint32_t shade_cont_min;           // ... as long as at least this many lanes continue (ignored once the work has run out)
 };

@@ -365,7 +365,11 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 
         // Traverse while the lanes are well filled; shade when they are not (that is what parks new
         // rays) or when shading work has piled up to a full wave.
-        const bool traverse = n_active != 0 && (best == 0 || (n_active >= P.y_low_water && best < 64u));
+        // (once the work items have run out -- the drain -- there is nothing to keep lanes filled FOR: what counts
+        // is how few, and how full, the remaining rounds are. drain_mode bit 1: all traversals first.)
+        const bool drain = !more_work;
+        const bool traverse = n_active != 0 && (best == 0 || (n_active >= P.y_low_water && best < 64u) ||
+                                                (drain && (P.drain_mode & 2u)));
         if (traverse) {
             if (STATS) {
                 ++dg_pass[ST_TRAV];
@@ -376,8 +380,10 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             // leave as soon as enough lanes are idle to make a refill / shading pass worthwhile; when no
             // other work exists, as soon as one lane has a result (it creates shading work)
             const uint32_t y_keep = cnt[ST_TRAV] >= P.y_high_min_parked ? P.y_high_water : P.y_low_water;
-            const uint32_t keep = (best != 0 || cnt[ST_TRAV] != 0) ? (n_active < y_keep ? n_active : y_keep)
-                                                                   : n_active;
+            // (drain_mode bit 0: in the drain a burst runs until every lane has finished)
+            const uint32_t keep = (drain && (P.drain_mode & 1u)) ? 1u
+                                  : (best != 0 || cnt[ST_TRAV] != 0) ? (n_active < y_keep ? n_active : y_keep)
+                                                                     : n_active;
         RBRT_MARK("burst_top");
             do {
                 if (STATS) {
