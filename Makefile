@@ -18,9 +18,10 @@ BINDIR := rbrt_amd/bin
 all: $(LIBDIR)/librbrt_hip.so host oracle
 
 $(LIBDIR)/librbrt_hip.so: $(CSRC)/kernels.hip $(CSRC)/megakernel.inl $(CSRC)/api.cpp $(CSRC)/bvh.cpp $(CSRC)/bvh.h \
+                          $(CSRC)/bvh_device.hip $(CSRC)/bvh_device.h \
                           $(CSRC)/device_types.h include/rbrt_hip.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/api.cpp $(CSRC)/bvh.cpp
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/bvh_device.hip $(CSRC)/api.cpp $(CSRC)/bvh.cpp
 
 host:
 	@if [ -f rbrt_amd/host/Makefile ]; then $(MAKE) -C rbrt_amd/host; fi

@@ -268,6 +268,12 @@ int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* scene, uint64_t* out, size_t
 int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
                             size_t* n_tris, uint32_t* max_depth, float* max_e12);
 void rbrt_hip_free_host(void* p);
+/* Diagnostic: the GPU-side BVH builder alone (rbrt_amd/csrc/bvh_device.hip; rbrt_hip_scene_create uses it for meshes of
+ * 131,072 entries or more, $RBRT_BVH_BUILDER = host | device overrides). Same outputs as rbrt_hip_bvh_build_host;
+ * *built = 0 when the builder declined the mesh (fewer than 8 entries, <= 4 indexed triangles, or a tree beyond the
+ * traversal's depth budget), in which case scene_create falls back to the host builder. */
+int rbrt_hip_bvh_build_device(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
+                              size_t* n_tris, uint32_t* max_depth, float* max_e12, int* built);
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 

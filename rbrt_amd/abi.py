@@ -134,6 +134,9 @@ HIP_SYMBOLS = {
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
                                           f32p]),
     "rbrt_hip_free_host": (None, [C.c_void_p]),
+    "rbrt_hip_bvh_build_device": (C.c_int, [C.POINTER(Mesh), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
+                                            f32p, C.POINTER(C.c_int)]),
     "rbrt_hip_scene_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]),
     "rbrt_render_opts_default": (None, [C.POINTER(RenderOpts)]),
     "rbrt_hip_device_count": (C.c_int, []),

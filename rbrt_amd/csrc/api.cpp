@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "bvh.h"
+#include "bvh_device.h"
 #include "device_types.h"
 
 namespace rbrt {
@@ -126,6 +127,7 @@ struct rbrt_hip_scene {
     bool timing_overflow = false;  // more than kMaxTimedLaunches launches since set_timing: the rest go untimed
     uint32_t last_batch = 0, last_n_batches = 0;  // sample batching of the last render (rbrt_hip_scene_last_batching)
     uint64_t total_nodes = 0, total_tris = 0;
+    uint32_t n_device_built = 0;  // meshes whose BVH the GPU built
 };
 
 namespace {
@@ -150,6 +152,35 @@ int upload(rbrt_hip_scene* s, const std::vector<T>& host, T** out) {
     if (!host.empty()) HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<T*>(d);
     return RBRT_OK;
+}
+
+// Uploads a mesh's SoA arrays and builds its BVH on the GPU (bvh_device.hip): triangle records to d_tris_out (leaf
+// links absolute, d_tris_out[0] being record tri_base of the scene's array), normals to d_normals (may be null).
+// r->ok says whether a tree was built; on error nothing is left allocated.
+hipError_t device_build_mesh(const rbrt_mesh_t& m, BvhTri* d_tris_out, uint32_t tri_base, Normal4* d_normals, DeviceBvhResult* r) {
+    const float* src[12] = {m.v0x, m.v0y, m.v0z, m.e1x, m.e1y, m.e1z, m.e2x, m.e2y, m.e2z, m.nx, m.ny, m.nz};
+    float* d_soa = nullptr;
+    uint8_t* d_pad = nullptr;
+    const size_t stride = (size_t(m.n_total) + 63u) & ~size_t(63);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_soa), stride * 12u * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_pad), m.n_total);
+    for (int k = 0; k < 12 && e == hipSuccess; ++k)
+        e = hipMemcpy(d_soa + stride * k, src[k], size_t(m.n_total) * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_pad, m.is_padding, m.n_total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const DeviceMeshSoa soa = {d_soa, d_soa + stride, d_soa + 2 * stride, d_soa + 3 * stride, d_soa + 4 * stride,
+                                   d_soa + 5 * stride, d_soa + 6 * stride, d_soa + 7 * stride, d_soa + 8 * stride, d_pad};
+        e = build_bvh_device(soa, m.n_total, d_tris_out, tri_base, r, nullptr);
+    }
+    if (e == hipSuccess && r->ok && d_normals)
+        e = device_normals(d_soa + 9 * stride, d_soa + 10 * stride, d_soa + 11 * stride, m.n_total, d_normals, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_soa), (void)hipFree(d_pad);
+    if (e != hipSuccess && r->d_nodes) {
+        (void)hipFree(r->d_nodes);
+        r->d_nodes = nullptr, r->ok = false;
+    }
+    return e;
 }
 
 uint32_t div_magic_of(uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : uint32_t(0x100000000ull / d); }  // kernels.hip div_magic
@@ -349,6 +380,13 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         rbrt_hip_scene_destroy(s);
         return rc;
     };
+#define HIP_TRY_BAIL(expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return bail(fail(_e == hipErrorOutOfMemory ? RBRT_ERR_OOM : RBRT_ERR_HIP,                   \
+                             std::string(#expr) + ": " + hipGetErrorString(_e)));                       \
+    } while (0)
 
     for (uint32_t i = 0; i < scene->n_spheres; ++i) {
         rbrt_hip_scene::Bound b;
@@ -374,30 +412,88 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         put_mat(i, scene->spheres[i].mat);
     }
     std::vector<DevMesh> meshes(scene->n_meshes);
-    std::vector<BvhTri> all_tris;  // the triangle records of every mesh, concatenated: leaf links become absolute
+    // One triangle array for the scene (leaf links are absolute positions in it): mesh i owns the records
+    // [tri_base[i], tri_base[i] + cap[i]), cap = what its builder can emit at most (the scan-visible entries + a dummy).
+    std::vector<uint32_t> tri_base(scene->n_meshes, 0);
+    uint64_t tri_total = 0;
+    for (uint32_t i = 0; i < scene->n_meshes; ++i) {
+        tri_base[i] = uint32_t(tri_total);
+        tri_total += uint64_t(scene->meshes[i].n_total / 8u) * 8u + 1u;
+        if (tri_total >= (1ull << 25)) return bail(fail(RBRT_ERR_UNSUPPORTED, "more than 2^25 triangle records in one scene"));
+    }
+    {
+        void* p = nullptr;
+        const size_t bytes = std::max<size_t>(size_t(tri_total) * sizeof(BvhTri), 64);
+        HIP_TRY_BAIL(hipMalloc(&p, bytes));
+        s->allocs.push_back(p);
+        s->d_tris = static_cast<BvhTri*>(p);
+        HIP_TRY_BAIL(hipMemset(p, 0, bytes));  // (records no leaf points at: zero-area triangles)
+    }
+    // Builder: the GPU (bvh_device.hip: Morton-ordered radix tree, ~ms for a million triangles) for big meshes, the
+    // host's binned-SAH builder (bvh.cpp: a better tree, 5 us per triangle) for small ones; RBRT_BVH_BUILDER = host |
+    // device forces one. The device builder declines what it does not handle (tiny meshes, a tree deeper than the
+    // traversal stack allows) and the host builder takes over.
+    int builder_mode = 0;  // 0 auto, 1 host, 2 device
+    if (const char* e = std::getenv("RBRT_BVH_BUILDER")) builder_mode = !std::strcmp(e, "host") ? 1 : !std::strcmp(e, "device") ? 2 : 0;
+    uint32_t device_min_tris = 131072;
+    if (const char* e = std::getenv("RBRT_BVH_DEVICE_MIN")) device_min_tris = uint32_t(std::max(0, std::atoi(e)));
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         const rbrt_mesh_t& m = scene->meshes[i];
         put_mat(scene->n_spheres + i, m.mat);
-        BvhBuildResult bvh = build_bvh(m);
-        const uint32_t tri_base = uint32_t(all_tris.size());
-        if (uint64_t(tri_base) + bvh.tris.size() >= (1ull << 25))
-            return bail(fail(RBRT_ERR_UNSUPPORTED, "more than 2^25 triangle records in one scene"));
-        if (tri_base != 0)
-            for (BvhNode4& nd : bvh.nodes)
-                for (int c = 0; c < 4; ++c)
-                    if (nd.child[c] < 0 && nd.child[c] != kNoChild) {
-                        const uint32_t leaf = uint32_t(~nd.child[c]);
-                        nd.child[c] = ~int32_t((((leaf >> kLeafBits) + tri_base) << kLeafBits) | (leaf & uint32_t(kLeafMax - 1)));
-                    }
-        all_tris.insert(all_tris.end(), bvh.tris.begin(), bvh.tris.end());
-        std::vector<Normal4> normals(m.n_total);
-        for (uint32_t k = 0; k < m.n_total; ++k) normals[k] = Normal4{m.nx[k], m.ny[k], m.nz[k], 0.0f};
         DevMesh& dm = meshes[i];
-        BvhNode4* d_nodes = nullptr;
         Normal4* d_normals = nullptr;
-        if (int rc = upload(s, bvh.nodes, &d_nodes)) return bail(rc);
-        if (int rc = upload(s, normals, &d_normals)) return bail(rc);
-        dm.nodes = d_nodes, dm.tris = nullptr, dm.normals = d_normals;  // tris: set below, once the scene's array exists
+        {
+            void* p = nullptr;
+            HIP_TRY_BAIL(hipMalloc(&p, std::max<size_t>(size_t(m.n_total) * sizeof(Normal4), 16)));
+            s->allocs.push_back(p);
+            d_normals = static_cast<Normal4*>(p);
+        }
+        bool built = false;
+        const bool try_device = builder_mode == 2 || (builder_mode == 0 && m.n_total >= device_min_tris);
+        if (try_device && m.n_total >= 8) {
+            DeviceBvhResult r;
+            const hipError_t e = device_build_mesh(m, s->d_tris + tri_base[i], tri_base[i], d_normals, &r);
+            if (e != hipSuccess)
+                return bail(fail(e == hipErrorOutOfMemory ? RBRT_ERR_OOM : RBRT_ERR_HIP, std::string("device BVH build: ") + hipGetErrorString(e)));
+            if (r.ok) {
+                s->allocs.push_back(r.d_nodes);
+                dm.nodes = r.d_nodes;
+                dm.max_e12 = r.max_e12;
+                dm.n_nodes = r.n_nodes;
+                dm.n_tris = r.n_valid;
+                s->stack_need = std::max(s->stack_need, 3u * (r.max_depth + 1u) + 1u);
+                s->total_nodes += r.n_nodes;
+                s->total_tris += r.n_valid;
+                s->n_device_built += 1;
+                built = true;
+            }
+        }
+        if (!built) {
+            BvhBuildResult bvh = build_bvh(m);
+            if (tri_base[i] != 0)
+                for (BvhNode4& nd : bvh.nodes)
+                    for (int c = 0; c < 4; ++c)
+                        if (nd.child[c] < 0 && nd.child[c] != kNoChild) {
+                            const uint32_t leaf = uint32_t(~nd.child[c]);
+                            nd.child[c] = ~int32_t((((leaf >> kLeafBits) + tri_base[i]) << kLeafBits) | (leaf & uint32_t(kLeafMax - 1)));
+                        }
+            std::vector<Normal4> normals(m.n_total);
+            for (uint32_t k = 0; k < m.n_total; ++k) normals[k] = Normal4{m.nx[k], m.ny[k], m.nz[k], 0.0f};
+            BvhNode4* d_nodes = nullptr;
+            if (int rc = upload(s, bvh.nodes, &d_nodes)) return bail(rc);
+            if (!bvh.tris.empty())
+                HIP_TRY_BAIL(hipMemcpy(s->d_tris + tri_base[i], bvh.tris.data(), bvh.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
+            if (!normals.empty())
+                HIP_TRY_BAIL(hipMemcpy(d_normals, normals.data(), normals.size() * sizeof(Normal4), hipMemcpyHostToDevice));
+            dm.nodes = d_nodes;
+            dm.max_e12 = bvh.max_e12;
+            dm.n_nodes = uint32_t(bvh.nodes.size());
+            dm.n_tris = uint32_t(bvh.tris.size());
+            s->stack_need = std::max(s->stack_need, bvh.stack_need);
+            s->total_nodes += bvh.nodes.size();
+            s->total_tris += bvh.tris.size();
+        }
+        dm.tris = s->d_tris, dm.normals = d_normals;
         float diag2 = 0.0f;
         for (int c = 0; c < 3; ++c) {
             dm.bbox_lo[c] = m.bbox_lo[c];
@@ -409,15 +505,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         // Radius bounds |v - center| for every indexed vertex; padded a little for its own rounding.
         dm.radius = std::sqrt(diag2) * 1.0001f;
         if (!std::isfinite(dm.radius)) dm.radius = std::numeric_limits<float>::max();
-        dm.max_e12 = bvh.max_e12;
-        dm.n_nodes = uint32_t(bvh.nodes.size());
-        dm.n_tris = uint32_t(bvh.tris.size());
-        s->stack_need = std::max(s->stack_need, bvh.stack_need);
-        s->total_nodes += bvh.nodes.size();
-        s->total_tris += bvh.tris.size();
     }
-    if (int rc = upload(s, all_tris, &s->d_tris)) return bail(rc);
-    for (DevMesh& dm : meshes) dm.tris = s->d_tris;
     if (int rc = upload(s, spheres, &s->d_spheres)) return bail(rc);
     if (int rc = upload(s, mats, &s->d_materials)) return bail(rc);
     if (int rc = upload(s, meshes, &s->d_meshes)) return bail(rc);
@@ -887,6 +975,36 @@ int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n
     return RBRT_OK;
 }
 void rbrt_hip_free_host(void* p) { std::free(p); }
+
+// Diagnostic: the GPU builder alone (bvh_device.hip), results copied back in the layout of rbrt_hip_bvh_build_host.
+// *built = 0 when the builder declined the mesh (tiny, or a tree beyond the depth budget); nothing is returned then.
+int rbrt_hip_bvh_build_device(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out, size_t* n_tris,
+                              uint32_t* max_depth, float* max_e12, int* built) {
+    if (!mesh || !nodes_out || !n_nodes || !tris_out || !n_tris || !built)
+        return fail(RBRT_ERR_INVALID_ARG, "bvh_build_device: null argument");
+    *built = 0, *nodes_out = *tris_out = nullptr, *n_nodes = *n_tris = 0;
+    if (int rc = ensure_device(0)) return rc;
+    if (mesh->n_total < 8) return RBRT_OK;
+    BvhTri* d_tris = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tris), size_t(mesh->n_total) * sizeof(BvhTri)));
+    DeviceBvhResult r;
+    hipError_t e = device_build_mesh(*mesh, d_tris, 0, nullptr, &r);
+    if (e == hipSuccess && r.ok) {
+        *nodes_out = std::malloc(size_t(r.n_nodes) * sizeof(BvhNode4));
+        *tris_out = std::malloc(std::max<size_t>(1, size_t(r.n_valid) * sizeof(BvhTri)));
+        if (*nodes_out && *tris_out) {
+            e = hipMemcpy(*nodes_out, r.d_nodes, size_t(r.n_nodes) * sizeof(BvhNode4), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(*tris_out, d_tris, size_t(r.n_valid) * sizeof(BvhTri), hipMemcpyDeviceToHost);
+            *n_nodes = r.n_nodes, *n_tris = r.n_valid, *built = 1;
+            if (max_depth) *max_depth = r.max_depth;
+            if (max_e12) *max_e12 = r.max_e12;
+        }
+    }
+    if (r.d_nodes) (void)hipFree(r.d_nodes);
+    (void)hipFree(d_tris);
+    if (e != hipSuccess) return fail(RBRT_ERR_HIP, std::string("bvh_build_device: ") + hipGetErrorString(e));
+    return RBRT_OK;
+}
 
 // Test hook: BoundingBox::hit (aabbox.rs:28-58) on n rays against one box, by the division-free form the megakernel
 // uses (out_fast) and by the verbatim IEEE form (out_exact). Host arrays.

@@ -38,7 +38,13 @@ def test_bvh4_invariants(oracle, n_tris):
         md = oracle.mesh_prep(np.zeros((0, 3, 3), np.float32))
     else:
         md = scenes.standin_mesh(oracle, n_tris, **scenes.EXAMPLE_MESH)
-    N, T, depth, max_e12 = build(md)
+    check_invariants(md, *build(md))
+
+
+def check_invariants(md, N, T, depth, max_e12):
+    """What every builder (host bvh.cpp, GPU bvh_device.hip) owes the traversal: bvh.h's contract."""
+    import sys
+    sys.setrecursionlimit(10000)
     child = N[:, 24:28].view(np.int32)
     n_tested = (md.n_total // 8) * 8
     want = [i for i in range(n_tested) if not md.is_padding[i]]   # triangle.rs:166-167, :400
