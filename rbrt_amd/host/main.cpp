@@ -1,7 +1,8 @@
 // main.cpp — the `rbrt` command line, same flags and defaults as the reference (src/main.rs:10-50):
 //   -t/--target_file dbg_out.png   --height 600   -w/--width 800
 //   -c/--config scenes/example_scene.yaml   -s/--samples 5   -h/--help   -V/--version
-// plus, not in the reference: --seed N (default 1), --gpus N (default 1).
+// plus, not in the reference: --seed N (default 1), --gpus N (default 1), --gather rccl|host, --pass-samples N,
+// --checkpoint FILE, --checkpoint-every N.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +25,10 @@ void usage() {
         "  -s, --samples <samples>          number of rays per pixel [default: 5]\n"
         "      --seed <seed>                seed of the per-(pixel,sample) random streams [default: 1]\n"
         "      --gpus <gpus>                number of MI355X GPUs to shard pixel tiles over [default: 1]\n"
+        "      --gather <how>               multi-GPU image gather: rccl (GPU to GPU over xGMI) or host [default: rccl]\n"
+        "      --pass-samples <n>           samples per pass (a progress line, and a checkpoint, per pass) [default: automatic]\n"
+        "      --checkpoint <file>          write the running per-pixel sums there after passes and resume from it\n"
+        "      --checkpoint-every <n>       checkpoint after every n-th pass [default: 1]\n"
         "  -h, --help                       Print help\n"
         "  -V, --version                    Print version\n");
 }
@@ -40,7 +45,8 @@ bool parse_u32(const char* s, uint32_t& out) {
 
 int main(int argc, char** argv) {
     std::string target = "dbg_out.png", config = "scenes/example_scene.yaml";
-    uint32_t height = 600, width = 800, samples = 5, gpus = 1;
+    uint32_t height = 600, width = 800, samples = 5, gpus = 1, pass_samples = 0, checkpoint_every = 1;
+    std::string gather = "rccl", checkpoint;
     unsigned long long seed = 1;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -85,6 +91,18 @@ int main(int argc, char** argv) {
             u32(samples);
         } else if (a == "--gpus") {
             u32(gpus);
+        } else if (a == "--pass-samples") {
+            u32(pass_samples);
+        } else if (a == "--checkpoint-every") {
+            u32(checkpoint_every);
+        } else if (a == "--checkpoint") {
+            checkpoint = value();
+        } else if (a == "--gather") {
+            gather = value();
+            if (gather != "rccl" && gather != "host") {
+                std::fprintf(stderr, "error: invalid value '%s' for '--gather' [possible values: rccl, host]\n", gather.c_str());
+                return 2;
+            }
         } else if (a == "--seed") {
             seed = std::strtoull(value(), nullptr, 10);
         } else {
@@ -102,6 +120,10 @@ int main(int argc, char** argv) {
         rbrt::RenderConfig cfg;
         cfg.seed = seed;
         cfg.n_gpus = int(gpus);
+        cfg.pass_spp = pass_samples;
+        cfg.checkpoint_path = checkpoint;
+        cfg.checkpoint_every = int(checkpoint_every);
+        cfg.gather = gather;
         rbrt::ImageBuffer img = rbrt::render_scene(cam, samples, scene, cfg);
         std::printf("Saving rendered image to %s\n", target.c_str());
         img.save(target);

@@ -167,6 +167,10 @@ struct RenderConfig {  // additions that the reference hard-codes or lacks
     uint64_t seed = 1;
     int n_gpus = 1;
     bool quiet = false;
+    uint32_t pass_spp = 0;            // samples per pass (progress line / checkpoint granularity); 0 = automatic
+    std::string checkpoint_path;      // non-empty: resume from / write per-pass checkpoints of the running sums here
+    int checkpoint_every = 1;         // ... after every n-th pass
+    std::string gather = "rccl";      // multi-GPU: "rccl" (device-to-device over xGMI) or "host" (merge through host memory)
 };
 // rbrt_lib::render_scene (lib.rs:75-79): blocks until the image is complete. Runs on the GPU(s)
 // through the C ABI; there is no CPU path.

@@ -1,14 +1,84 @@
-// render.cpp — rbrt::render_scene: the call the reference makes at src/main.rs:82, routed through the
-// C ABI to the GPU(s). One worker thread per GPU renders its interleaved 8x8 pixel tiles
-// (rbrt_render_opts_t::tile_rank / tile_world); partial images are merged on the host.
+// render.cpp — rbrt::render_scene: the call the reference makes at src/main.rs:82, routed through the C ABI to the
+// GPU(s).
+//
+// One worker thread per GPU. Every GPU holds the scene + BVH and renders its interleaved 8x8 pixel tiles
+// (rbrt_render_opts_t::tile_rank / tile_world) in PASSES of samples (rbrt_hip_render_pass: per-pixel sums in sample
+// order, so the image does not depend on how the samples are cut into passes). After each pass the reference's
+// progress line is printed (lib.rs:105-110 prints one per finished column; here a pass is the unit of progress) and,
+// if asked for, a checkpoint is written: the running sums of every rank plus the number of samples done. A later run
+// with the same scene, size, sample count, seed and GPU count resumes from it.
+// When all samples are in, the packed fp32 radiance of ranks 1..N-1 goes to rank 0's GPU with ONE grouped RCCL
+// send/recv (each peer over its own xGMI link: SURVEY 8(e)), rank 0 de-interleaves it with rbrt_hip_unpack_tiles and
+// quantises; only then does the image cross PCIe. `--gather host` keeps the staging-through-host merge as a fallback.
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
 #include <thread>
 
 #include "rbrt.hpp"
 
 namespace rbrt {
+namespace {
+
+class Barrier {  // all-ranks rendezvous between passes (checkpoint consistency, RCCL group entry)
+  public:
+    explicit Barrier(int n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(m_);
+        const uint64_t gen = gen_;
+        if (++count_ == n_) {
+            count_ = 0;
+            ++gen_;
+            cv_.notify_all();
+        } else {
+            cv_.wait(lk, [&] { return gen_ != gen; });
+        }
+    }
+
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int n_, count_ = 0;
+    uint64_t gen_ = 0;
+};
+
+uint64_t fnv1a(const void* p, size_t n, uint64_t h) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 0x100000001B3ull;
+    return h;
+}
+
+// What a checkpoint must match to be resumed: everything the running sums depend on.
+uint64_t scene_fingerprint(const rbrt_camera_t& cam, const rbrt_scene_t& sc) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    h = fnv1a(&cam, sizeof(cam), h);
+    for (uint32_t i = 0; i < sc.n_spheres; ++i) h = fnv1a(&sc.spheres[i], sizeof(rbrt_sphere_t), h);
+    for (uint32_t i = 0; i < sc.n_meshes; ++i) {
+        const rbrt_mesh_t& m = sc.meshes[i];
+        h = fnv1a(&m.n_total, sizeof(m.n_total), h);
+        h = fnv1a(&m.mat, sizeof(m.mat), h);
+        const float* arrs[12] = {m.v0x, m.v0y, m.v0z, m.e1x, m.e1y, m.e1z, m.e2x, m.e2y, m.e2z, m.nx, m.ny, m.nz};
+        for (const float* a : arrs) h = fnv1a(a, size_t(m.n_total) * sizeof(float), h);
+        h = fnv1a(m.is_padding, m.n_total, h);
+    }
+    return h;
+}
+
+struct CheckpointHeader {
+    char magic[8];  // "RBRTCKP1"
+    uint32_t width, height, spp, world;
+    uint64_t seed, fingerprint;
+    uint32_t samples_done, reserved;
+};
+
+}  // namespace
 
 ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& scene, const RenderConfig& cfg) {
     if (!cfg.quiet) std::printf("Starting rendering...\n");
@@ -25,63 +95,227 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     const size_t n = size_t(img.width) * img.height * 3;
     img.rgb.assign(n, 0);
     img.radiance.assign(n, 0.0f);
+    if (num_samples == 0) throw Error("the number of samples must be at least 1");
 
     const int n_dev = rbrt_hip_device_count();
     if (n_dev < 1) throw Error(std::string("no HIP device: ") + rbrt_hip_last_error());
-    int world = cfg.n_gpus < 1 ? 1 : cfg.n_gpus;
+    const int world = cfg.n_gpus < 1 ? 1 : cfg.n_gpus;
     if (world > n_dev) throw Error("requested " + std::to_string(world) + " GPUs, " + std::to_string(n_dev) + " present");
 
+    // samples per pass: what was asked for, else passes of about 2^31 path samples each (a second or so of one GPU's
+    // share), so that long renders report progress and can checkpoint; a short render is one pass
+    uint32_t pass_spp = cfg.pass_spp;
+    if (pass_spp == 0) {
+        const uint64_t per_spp = uint64_t(img.width) * img.height / uint64_t(world) + 1u;
+        pass_spp = uint32_t(std::min<uint64_t>(num_samples, std::max<uint64_t>(1, (1ull << 31) / per_spp)));
+    }
+    const uint32_t ckpt_every = cfg.checkpoint_every < 1 ? 1u : uint32_t(cfg.checkpoint_every);
+    const bool use_rccl = world > 1 && cfg.gather != "host";
+    // test hook: give up after this many passes of THIS run (as an interrupted run would), checkpoint left on disk
+    int stop_after = 0;
+    if (const char* e = std::getenv("RBRT_TEST_STOP_AFTER_PASS")) stop_after = std::atoi(e);
+
+    // ---- resume ------------------------------------------------------------------------------------------------
+    CheckpointHeader want{};
+    std::memcpy(want.magic, "RBRTCKP1", 8);
+    want.width = img.width, want.height = img.height, want.spp = num_samples, want.world = uint32_t(world);
+    want.seed = cfg.seed;
+    want.fingerprint = cfg.checkpoint_path.empty() ? 0 : scene_fingerprint(c, view.scene);
+    uint32_t start_sample = 0;
+    std::vector<std::vector<float>> resume_acc(world);
+    if (!cfg.checkpoint_path.empty()) {
+        std::ifstream in(cfg.checkpoint_path, std::ios::binary);
+        CheckpointHeader h{};
+        if (in && in.read(reinterpret_cast<char*>(&h), sizeof(h))) {
+            const bool same = !std::memcmp(h.magic, want.magic, 8) && h.width == want.width && h.height == want.height &&
+                              h.spp == want.spp && h.world == want.world && h.seed == want.seed &&
+                              h.fingerprint == want.fingerprint && h.samples_done > 0 && h.samples_done < num_samples;
+            bool ok = same;
+            for (int r = 0; ok && r < world; ++r) {
+                uint64_t cnt = 0;
+                ok = bool(in.read(reinterpret_cast<char*>(&cnt), sizeof(cnt)));
+                const size_t expect = world > 1 ? rbrt_hip_packed_pixels(img.width, img.height, uint32_t(r), uint32_t(world)) * 3 : n;
+                ok = ok && cnt == expect;
+                if (ok) {
+                    resume_acc[r].resize(cnt);
+                    ok = bool(in.read(reinterpret_cast<char*>(resume_acc[r].data()), std::streamsize(cnt * sizeof(float))));
+                }
+            }
+            if (ok) {
+                start_sample = h.samples_done;
+                if (!cfg.quiet) std::printf("Resuming from checkpoint %s at sample %u of %u\n", cfg.checkpoint_path.c_str(), start_sample, num_samples);
+            } else {
+                for (auto& v : resume_acc) v.clear();
+                if (!cfg.quiet) std::printf("Checkpoint %s does not match this render (scene, size, samples, seed or GPU count): starting over\n",
+                                            cfg.checkpoint_path.c_str());
+            }
+        }
+    }
+
+    // ---- RCCL communicators (one process, one communicator per GPU) -----------------------------------------------
+    std::vector<ncclComm_t> comms(world, nullptr);
+    if (use_rccl) {
+        std::vector<int> devs(world);
+        for (int r = 0; r < world; ++r) devs[r] = r;
+        const ncclResult_t rc = ncclCommInitAll(comms.data(), world, devs.data());
+        if (rc != ncclSuccess) throw Error(std::string("ncclCommInitAll: ") + ncclGetErrorString(rc));
+    }
+
     std::vector<std::string> errors(world);
+    std::vector<std::vector<float>> ckpt_acc(world);  // host copies of the running sums for the checkpoint writer
+    Barrier barrier(world);
+    std::vector<float*> d_slots(1, nullptr);  // rank 0: world equal-size slots of packed tiles
+    const size_t slot_pixels = world > 1 ? rbrt_hip_packed_pixels(img.width, img.height, 0, uint32_t(world)) : 0;
+    auto any_error = [&]() {
+        for (const auto& e : errors)
+            if (!e.empty()) return true;
+        return false;
+    };
+
     auto worker = [&](int rank) {
         rbrt_hip_scene_t* hs = nullptr;
-        float* d_rad = nullptr;
+        float *d_acc = nullptr, *d_rad = nullptr, *d_img = nullptr;
         uint8_t* d_rgb = nullptr;
-        auto fail = [&](const std::string& m) { errors[rank] = m.empty() ? "unknown error" : m; };
-        if (rbrt_hip_scene_create(&view.scene, rank, &hs) != RBRT_OK) return fail(rbrt_hip_last_error());
+        hipStream_t stream = nullptr;
+        auto fail = [&](const std::string& m) {
+            if (errors[rank].empty()) errors[rank] = m.empty() ? "unknown error" : m;
+        };
+        auto hip_ok = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess) fail(std::string(what) + ": " + hipGetErrorString(e));
+            return e == hipSuccess;
+        };
         rbrt_render_opts_t o = opts;
         o.tile_rank = uint32_t(rank);
         o.tile_world = uint32_t(world);
         const size_t npix = world > 1 ? rbrt_hip_packed_pixels(img.width, img.height, o.tile_rank, o.tile_world)
                                       : size_t(img.width) * img.height;
-        bool ok = npix == 0 || (hipMalloc(reinterpret_cast<void**>(&d_rad), npix * 3 * sizeof(float)) == hipSuccess &&
-                                hipMalloc(reinterpret_cast<void**>(&d_rgb), npix * 3) == hipSuccess);
-        if (!ok) fail("hipMalloc failed for the output image");
-        if (ok && npix) {
-            if (rbrt_hip_render_device(hs, &c, &o, nullptr, d_rad, d_rgb) != RBRT_OK) {
-                fail(rbrt_hip_last_error());
-            } else if (hipDeviceSynchronize() != hipSuccess) {
-                fail("kernel execution failed");
-            } else if (world == 1) {
-                (void)hipMemcpy(img.radiance.data(), d_rad, n * sizeof(float), hipMemcpyDeviceToHost);
-                (void)hipMemcpy(img.rgb.data(), d_rgb, n, hipMemcpyDeviceToHost);
-            } else {
-                std::vector<float> hr(npix * 3);
-                std::vector<uint8_t> hb(npix * 3);
-                (void)hipMemcpy(hr.data(), d_rad, hr.size() * sizeof(float), hipMemcpyDeviceToHost);
-                (void)hipMemcpy(hb.data(), d_rgb, hb.size(), hipMemcpyDeviceToHost);
+        if (rbrt_hip_scene_create(&view.scene, rank, &hs) != RBRT_OK) fail(rbrt_hip_last_error());
+        if (hs && npix) {
+            hip_ok(hipSetDevice(rank), "hipSetDevice");
+            hip_ok(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&d_acc), npix * 3 * sizeof(float)), "hipMalloc(sums)");
+            hip_ok(hipMalloc(reinterpret_cast<void**>(&d_rad), npix * 3 * sizeof(float)), "hipMalloc(radiance)");
+            if (world == 1) hip_ok(hipMalloc(reinterpret_cast<void**>(&d_rgb), npix * 3), "hipMalloc(rgb8)");
+            if (rank == 0 && world > 1) {
+                hip_ok(hipMalloc(reinterpret_cast<void**>(&d_slots[0]), size_t(world) * slot_pixels * 3 * sizeof(float)), "hipMalloc(slots)");
+                hip_ok(hipMalloc(reinterpret_cast<void**>(&d_img), n * sizeof(float)), "hipMalloc(image)");
+                hip_ok(hipMalloc(reinterpret_cast<void**>(&d_rgb), n), "hipMalloc(rgb8)");
+            }
+            if (errors[rank].empty() && start_sample != 0)
+                hip_ok(hipMemcpy(d_acc, resume_acc[rank].data(), npix * 3 * sizeof(float), hipMemcpyHostToDevice), "upload of the checkpoint");
+        }
+        // ---- passes ----
+        uint32_t pass_no = 0;
+        for (uint32_t b = start_sample; b < num_samples; b += pass_spp, ++pass_no) {
+            const uint32_t e = std::min(num_samples, b + pass_spp);
+            const bool last = e == num_samples;
+            if (errors[rank].empty() && npix) {
+                if (rbrt_hip_render_pass(hs, &c, &o, stream, b, e, d_acc, last ? d_rad : nullptr, last ? (world == 1 ? d_rgb : nullptr) : nullptr) != RBRT_OK)
+                    fail(rbrt_hip_last_error());
+                else
+                    hip_ok(hipStreamSynchronize(stream), "render pass");
+            }
+            const bool ckpt_now = !cfg.checkpoint_path.empty() && !last && (pass_no + 1) % ckpt_every == 0;
+            if (ckpt_now && errors[rank].empty() && npix) {
+                ckpt_acc[rank].resize(npix * 3);
+                hip_ok(hipMemcpy(ckpt_acc[rank].data(), d_acc, npix * 3 * sizeof(float), hipMemcpyDeviceToHost), "download of the running sums");
+            }
+            if (world > 1 && (ckpt_now || !cfg.quiet)) barrier.wait();  // every rank has finished the pass
+            if (rank == 0) {
+                if (!cfg.quiet) {  // lib.rs:105-110
+                    std::printf("\rRendering %.1f%% complete!", double(e) / double(num_samples) * 100.0);
+                    std::fflush(stdout);
+                }
+                if (ckpt_now && !any_error()) {
+                    const std::string tmp = cfg.checkpoint_path + ".tmp";
+                    std::ofstream out(tmp, std::ios::binary | std::ios::trunc);
+                    CheckpointHeader h = want;
+                    h.samples_done = e;
+                    out.write(reinterpret_cast<const char*>(&h), sizeof(h));
+                    for (int r = 0; r < world; ++r) {
+                        const uint64_t cnt = ckpt_acc[r].size();
+                        out.write(reinterpret_cast<const char*>(&cnt), sizeof(cnt));
+                        out.write(reinterpret_cast<const char*>(ckpt_acc[r].data()), std::streamsize(cnt * sizeof(float)));
+                    }
+                    out.close();
+                    if (!out || std::rename(tmp.c_str(), cfg.checkpoint_path.c_str()) != 0) fail("cannot write checkpoint " + cfg.checkpoint_path);
+                }
+            }
+            if (world > 1 && ckpt_now) barrier.wait();  // the sums may change again only after they are on disk
+            if (stop_after > 0 && int(pass_no) + 1 == stop_after && !last) fail("stopped after pass " + std::to_string(stop_after) + " (RBRT_TEST_STOP_AFTER_PASS)");
+        }
+        // ---- the reference would have panicked on a NaN discriminant (sphere.rs:33): surface it ----
+        if (hs && errors[rank].empty() && rbrt_hip_scene_check(hs) != RBRT_OK) fail(rbrt_hip_last_error());
+        // ---- gather ----
+        if (world == 1) {
+            if (errors[rank].empty() && npix) {
+                hip_ok(hipMemcpy(img.radiance.data(), d_rad, n * sizeof(float), hipMemcpyDeviceToHost), "download");
+                hip_ok(hipMemcpy(img.rgb.data(), d_rgb, n, hipMemcpyDeviceToHost), "download");
+            }
+        } else if (use_rccl) {
+            barrier.wait();  // every rank knows whether any rank failed: either all enter the group call or none
+            if (!any_error()) {
+                // one grouped exchange: rank r > 0 sends its packed tiles, rank 0 receives each into that rank's slot
+                ncclResult_t rc = ncclGroupStart();
+                if (rank == 0) {
+                    hip_ok(hipMemcpyAsync(d_slots[0], d_rad, npix * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream), "own tiles");
+                    for (int r = 1; r < world && rc == ncclSuccess; ++r) {
+                        const size_t cnt = rbrt_hip_packed_pixels(img.width, img.height, uint32_t(r), uint32_t(world)) * 3;
+                        if (cnt) rc = ncclRecv(d_slots[0] + size_t(r) * slot_pixels * 3, cnt, ncclFloat, r, comms[0], stream);
+                    }
+                } else if (npix && rc == ncclSuccess) {
+                    rc = ncclSend(d_rad, npix * 3, ncclFloat, 0, comms[rank], stream);
+                }
+                const ncclResult_t rc2 = ncclGroupEnd();
+                if (rc != ncclSuccess || rc2 != ncclSuccess) fail(std::string("RCCL gather: ") + ncclGetErrorString(rc != ncclSuccess ? rc : rc2));
+                if (rank == 0 && errors[0].empty()) {
+                    if (rbrt_hip_unpack_tiles_strided(0, stream, d_slots[0], img.width, img.height, uint32_t(world), slot_pixels, d_img, d_rgb) != RBRT_OK)
+                        fail(rbrt_hip_last_error());
+                }
+                hip_ok(hipStreamSynchronize(stream), "gather");
+                if (rank == 0 && errors[0].empty()) {
+                    hip_ok(hipMemcpy(img.radiance.data(), d_img, n * sizeof(float), hipMemcpyDeviceToHost), "download");
+                    hip_ok(hipMemcpy(img.rgb.data(), d_rgb, n, hipMemcpyDeviceToHost), "download");
+                }
+            }
+        } else if (errors[rank].empty() && npix) {  // --gather host: every rank's tiles through host memory
+            std::vector<float> hr(npix * 3);
+            if (hip_ok(hipMemcpy(hr.data(), d_rad, hr.size() * sizeof(float), hipMemcpyDeviceToHost), "download")) {
                 const uint32_t tiles_x = (img.width + RBRT_TILE - 1) / RBRT_TILE;
                 for (size_t tl = 0; tl < npix / 64; ++tl) {
-                    const uint32_t tile = uint32_t(tl) * world + rank;
+                    const uint32_t tile = uint32_t(tl) * uint32_t(world) + uint32_t(rank);
                     const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
                     for (uint32_t p = 0; p < 64; ++p) {
                         const uint32_t row = ty * RBRT_TILE + p / 8, col = tx * RBRT_TILE + p % 8;
                         if (row >= img.height || col >= img.width) continue;
                         const size_t src = (tl * 64 + p) * 3, dst = (size_t(row) * img.width + col) * 3;
-                        for (int k = 0; k < 3; ++k) img.radiance[dst + k] = hr[src + k], img.rgb[dst + k] = hb[src + k];
+                        for (int k = 0; k < 3; ++k) {  // lib.rs:116-122 on the host for this fallback
+                            const float v = hr[src + k];
+                            img.radiance[dst + k] = v;
+                            const float q = std::sqrt(v) * 256.0f;
+                            img.rgb[dst + k] = !(q == q) || q <= 0.0f ? 0 : q >= 255.0f ? 255 : uint8_t(q);
+                        }
                     }
                 }
             }
         }
+        if (d_acc) (void)hipFree(d_acc);
         if (d_rad) (void)hipFree(d_rad);
         if (d_rgb) (void)hipFree(d_rgb);
+        if (d_img) (void)hipFree(d_img);
+        if (rank == 0 && d_slots[0]) (void)hipFree(d_slots[0]);
+        if (stream) (void)hipStreamDestroy(stream);
         rbrt_hip_scene_destroy(hs);
     };
     std::vector<std::thread> threads;
     for (int r = 1; r < world; ++r) threads.emplace_back(worker, r);
     worker(0);
     for (auto& t : threads) t.join();
+    for (ncclComm_t cm : comms)
+        if (cm) (void)ncclCommDestroy(cm);
     for (int r = 0; r < world; ++r)
         if (!errors[r].empty()) throw Error("GPU " + std::to_string(r) + ": " + errors[r]);
+    if (!cfg.checkpoint_path.empty()) std::remove(cfg.checkpoint_path.c_str());  // (only reached when the render is complete)
     if (!cfg.quiet) std::printf("\rRendering 100%% complete!\n");
     return img;
 }

@@ -319,6 +319,13 @@ TriangleMesh TriangleMesh::from_triangles(std::vector<std::array<Vec3, 3>> pre_v
     for (const auto& t : pre_vertices) pre_normals.push_back(get_triangle_normal(t));
     for (const auto& t : pre_vertices) pre_edges.push_back({t[1] - t[0], t[2] - t[0]});
     compute_min_max_3d(pre_vertices, m.bbox_lower, m.bbox_upper);
+    // mesh.rs:27-38 determine_num_vector_lanes(): the reference announces the SIMD layout it picked, once per mesh,
+    // after the "Successfully loaded" line. This host always lays meshes out 8 lanes wide (the AVX layout is the one
+    // the GPU path restates); on a CPU without AVX the line says so instead of claiming a capability.
+    if (__builtin_cpu_supports("avx"))
+        std::printf("AVX capability detected!\n");
+    else
+        std::printf("AVX capability not detected - the GPU path uses the 8-lane (AVX) mesh layout regardless!\n");
     const size_t n = pre_vertices.size();
     const size_t n_pad = n % kNumVectorLanes;
     m.is_padding_triangle.assign(n, 0);

@@ -523,3 +523,41 @@ def test_render_pass_checkpoint_and_resume(hip, oracle):
         torch.cuda.synchronize()
     from rbrt_amd import tiles
     assert np.array_equal(outp.cpu().numpy().view(np.uint32), tiles.pack(exp, 1, 2).view(np.uint32))
+
+
+def test_cli_progress_checkpoint_and_resume(hip, oracle, tmp_path):
+    """The C++ host end to end with passes: the reference's stdout lines (mesh.rs:29-35 ISA banner, lib.rs:105-110
+    progress), a checkpoint left behind by an interrupted run, and a second run that resumes from it: the PNG is
+    the oracle's image, the checkpoint is gone."""
+    import os
+    import subprocess
+    from pathlib import Path
+
+    from PIL import Image
+    root = Path(__file__).resolve().parent.parent
+    v, f = standin.make_mesh(1203)
+    standin.write_obj(tmp_path / "bunny.obj", v, f)
+    text = (root / "scenes" / "example_scene.yaml").read_text().replace("bunny.obj", str(tmp_path / "bunny.obj"))
+    (tmp_path / "scene.yaml").write_text(text)
+    out, ck = tmp_path / "out.png", tmp_path / "render.ckpt"
+    cmd = [str(root / "rbrt_amd" / "bin" / "rbrt"), "-c", str(tmp_path / "scene.yaml"), "-t", str(out), "--height", "96", "-w", "128",
+           "-s", "11", "--seed", "4", "--pass-samples", "3", "--checkpoint", str(ck)]
+    r1 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, RBRT_TEST_STOP_AFTER_PASS="2"))
+    assert r1.returncode == 101 and "stopped after pass 2" in r1.stderr
+    assert ck.exists() and not out.exists()
+    assert "AVX capability detected!" in r1.stdout or "AVX capability not detected" in r1.stdout
+    assert "Rendering 27.3% complete!" in r1.stdout and "Rendering 54.5% complete!" in r1.stdout  # 3/11, 6/11
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "Resuming from checkpoint" in r2.stdout and "at sample 6 of 11" in r2.stdout
+    assert "Rendering 81.8% complete!" in r2.stdout and "Rendering 100% complete!" in r2.stdout
+    assert not ck.exists()
+    _, exp8, _ = oracle.render(scenes.camera(oracle, 128, 96), scenes.example_scene(oracle, 1203), abi.default_opts(spp=11, seed=4))
+    assert np.array_equal(np.array(Image.open(out)), exp8)
+    # a checkpoint of a different render is not resumed
+    r3 = subprocess.run(cmd[:-2] + ["--checkpoint", str(ck), "--seed", "5"], capture_output=True, text=True, timeout=300,
+                        env=dict(os.environ, RBRT_TEST_STOP_AFTER_PASS="1"))
+    assert r3.returncode == 101 and ck.exists()
+    r4 = subprocess.run(cmd, capture_output=True, text=True, timeout=300)  # seed 4 again: must start over
+    assert r4.returncode == 0 and "does not match this render" in r4.stdout
+    assert np.array_equal(np.array(Image.open(out)), exp8)
