@@ -29,8 +29,12 @@ host:
 oracle:
 	$(MAKE) -C oracle
 
+# CPU-side C++ under AddressSanitizer + UBSan / ThreadSanitizer (tests/cpp/host_selftest.cpp)
+asan tsan:
+	$(MAKE) -C tests/cpp $@
+
 clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all host oracle clean
+.PHONY: all host oracle clean asan tsan
