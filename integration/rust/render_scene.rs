@@ -2,21 +2,19 @@
 // It is the binding INTEGRATION.md describes; the same C ABI (include/rbrt_hip.h) is exercised by the C++ host
 // (rbrt_amd/host/render.cpp) and by the ctypes mirror (rbrt_amd/abi.py, checked against the header's layout).
 //
-// Replacement body of `render_scene` in rbrt_lib/src/lib.rs (reference lib.rs:75-124), plus the one method the
-// material trait gains.
-
-// materials.rs
-pub trait RayScattering { /* scatter(..) unchanged */  fn as_ffi(&self) -> crate::hip_ffi::RbrtMaterial; }
-// lambertian.rs:  RbrtMaterial { kind: 0, albedo: [self.albedo.x, self.albedo.y, self.albedo.z], param: 0.0 }
-// metal.rs:       RbrtMaterial { kind: 1, albedo: [..],            param: self.roughness }
-// dielectric.rs:  RbrtMaterial { kind: 2, albedo: [0.0; 3],        param: self.ref_idx }
+// Replacement body of `render_scene` in rbrt_lib/src/lib.rs (reference lib.rs:75-124). It reads the scene exactly
+// as the reference stores it (scene.rs:12-16): spheres come out of `scene.elements` through
+// `Intersectable::as_sphere` (trait_additions.rs), meshes out of `scene.triangle_meshes`.
 
 pub fn render_scene(cam: Camera, num_samples: u32, scene: Scene) -> image::ImageBuffer<Rgb<u8>, Vec<u8>> {
     use crate::hip_ffi::*;
     println!("Starting rendering...");
     let v3 = |v: Vec3| [v.x, v.y, v.z];
-    let spheres: Vec<RbrtSphere> = scene.spheres.iter()                       // see note above
-        .map(|s| RbrtSphere { center: v3(s.center), radius: s.radius, mat: s.material.as_ffi() }).collect();
+    // Scene::hit tests `elements` in order, then `triangle_meshes` in order (scene.rs:23-41): keep both orders.
+    let spheres: Vec<RbrtSphere> = scene.elements.iter().map(|e| {
+        let s = e.as_sphere().expect("the GPU path supports Sphere elements only (blueprints.rs:144-149 creates no others)");
+        RbrtSphere { center: v3(s.center), radius: s.radius, mat: s.material.as_ffi() }
+    }).collect();
     let meshes: Vec<RbrtMesh> = scene.triangle_meshes.iter().map(|m| RbrtMesh {
         n_total: m.is_padding_triangle.len() as u32,
         n_real: m.is_padding_triangle.iter().filter(|p| !**p).count() as u32,
@@ -24,7 +22,7 @@ pub fn render_scene(cam: Camera, num_samples: u32, scene: Scene) -> image::Image
         e1x: m.edges[0][0].as_ptr(),    e1y: m.edges[0][1].as_ptr(),    e1z: m.edges[0][2].as_ptr(),
         e2x: m.edges[1][0].as_ptr(),    e2y: m.edges[1][1].as_ptr(),    e2z: m.edges[1][2].as_ptr(),
         nx: m.normals[0].as_ptr(), ny: m.normals[1].as_ptr(), nz: m.normals[2].as_ptr(),
-        is_padding: m.is_padding_triangle.as_ptr() as *const u8,
+        is_padding: m.is_padding_triangle.as_ptr() as *const u8,   // Vec<bool>: one byte per element, 0 or 1
         bbox_lo: v3(m.bbox.lower_bound), bbox_hi: v3(m.bbox.upper_bound),
         mat: m.material.as_ffi(),
     }).collect();
