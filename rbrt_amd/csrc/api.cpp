@@ -75,6 +75,7 @@ struct rbrt_hip_scene {
     DevMaterial* d_materials = nullptr;
     DevMesh* d_meshes = nullptr;
     BvhTri* d_tris = nullptr;  // all meshes' triangle records
+    const BvhNode4* d_root0 = nullptr;  // mesh 0's nodes
     DevCounters* d_counters = nullptr;
     // workspace, grown on demand
     // Frame pipeline: consecutive trace launches (the batches of one render, or successive renders) alternate
@@ -272,6 +273,7 @@ int fill_trace_params(const rbrt_hip_scene* s, const rbrt_camera_t* cam, const r
     P.materials = s->d_materials;
     P.meshes = s->d_meshes;
     P.tris = s->d_tris;
+    P.root0 = s->d_root0;
     P.counters = s->d_counters;
     return RBRT_OK;
 }
@@ -494,6 +496,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             s->total_tris += bvh.tris.size();
         }
         dm.tris = s->d_tris, dm.normals = d_normals;
+        if (i == 0) s->d_root0 = dm.nodes;
         float diag2 = 0.0f;
         for (int c = 0; c < 3; ++c) {
             dm.bbox_lo[c] = m.bbox_lo[c];

@@ -273,16 +273,27 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {
 
 // Fetch one 128-B node (8 x dwordx4 by this lane) and test its four children; k[] comes back sorted by
 // entry distance (misses last) -- or, with SORTED = false, in slot order --, links = the four child links.
+// `lds_root` (experiment RBRT_ROOT_LDS, DESIGN.md "top of the tree in LDS"): when not null and this lane is at the
+// root, the eight 16-byte pieces come from a copy of node 0 in LDS instead of global memory / L1.
 template <bool SORTED = true>
 __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull& rc, float eps, float best_t,
-                                            uint32_t k[4], f32x4& links) {
+                                            uint32_t k[4], f32x4& links, const char* lds_root = nullptr, bool at_root = false) {
     const char* nb = reinterpret_cast<const char*>(node);
-    const f32x4 nx = *RBRT_AS1(f32x4, nb + rc.near_x), ny = *RBRT_AS1(f32x4, nb + rc.near_y),
-                nz = *RBRT_AS1(f32x4, nb + rc.near_z);
-    const f32x4 fx = *RBRT_AS1(f32x4, nb + (rc.near_x ^ 48u)), fy = *RBRT_AS1(f32x4, nb + (rc.near_y ^ 80u)),
-                fz = *RBRT_AS1(f32x4, nb + (rc.near_z ^ 112u));
-    const f32x4 me = *RBRT_AS1(f32x4, nb + 112);
-    links = *RBRT_AS1(f32x4, nb + 96);
+    f32x4 nx, ny, nz, fx, fy, fz, me;
+    if (lds_root != nullptr && at_root) {
+        typedef const __attribute__((address_space(3))) f32x4 lds_f32x4;
+        const char* lb = lds_root;
+        nx = *(lds_f32x4*)(lb + rc.near_x), ny = *(lds_f32x4*)(lb + rc.near_y), nz = *(lds_f32x4*)(lb + rc.near_z);
+        fx = *(lds_f32x4*)(lb + (rc.near_x ^ 48u)), fy = *(lds_f32x4*)(lb + (rc.near_y ^ 80u)), fz = *(lds_f32x4*)(lb + (rc.near_z ^ 112u));
+        me = *(lds_f32x4*)(lb + 112);
+        links = *(lds_f32x4*)(lb + 96);
+    } else {
+        nx = *RBRT_AS1(f32x4, nb + rc.near_x), ny = *RBRT_AS1(f32x4, nb + rc.near_y), nz = *RBRT_AS1(f32x4, nb + rc.near_z);
+        fx = *RBRT_AS1(f32x4, nb + (rc.near_x ^ 48u)), fy = *RBRT_AS1(f32x4, nb + (rc.near_y ^ 80u));
+        fz = *RBRT_AS1(f32x4, nb + (rc.near_z ^ 112u));
+        me = *RBRT_AS1(f32x4, nb + 112);
+        links = *RBRT_AS1(f32x4, nb + 96);
+    }
     // one pad for the node: the largest of its children's error terms (siblings have similar triangles)
     const float pad = __builtin_fmaf(rc.pad_k, __builtin_fmaxf(__builtin_fmaxf(me.x, me.y), __builtin_fmaxf(me.z, me.w)),
                                      rc.pad_base);
@@ -641,7 +652,8 @@ size_t megakernel_gseq_bytes(uint32_t n_waves) { return size_t(n_waves) * kPoolM
 size_t megakernel_gstack_bytes(uint32_t n_waves) { return size_t(n_waves) * kStackMax * 64u * sizeof(uint32_t); }
 
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
-    const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw + kGenDw;
+    const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw + kGenDw +
+                         (RBRT_ROOT_LDS ? 32u + 3u : 0u);  // experiment: mesh 0's root node, 16-byte aligned
     const size_t pool_pad = (size_t(pool) + 63u) & ~size_t(63);  // status + list: one byte per (padded) slot each
     return (size_t(kFields) * pool + kCellDw + kTqDw + pool_pad / 2u + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
 }

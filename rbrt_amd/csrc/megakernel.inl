@@ -26,6 +26,9 @@
 #ifndef RBRT_FAST_GATE
 #define RBRT_FAST_GATE 1  // mesh bbox gate through bbox_gate_fast (same decisions, no IEEE divisions on the common path)
 #endif
+#ifndef RBRT_ROOT_LDS
+#define RBRT_ROOT_LDS 0  // experiment: the root node of mesh 0 is read from a copy in LDS (measured: no gain)
+#endif
 #ifndef RBRT_PUSH_ORDER
 #define RBRT_PUSH_ORDER 0  // 0: children pushed far-to-near (sorted); 1: nearest next, the rest in slot order
 #endif
@@ -205,6 +208,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         }
     }
     const uint32_t* const gp = sc_base + P.n_spheres * kSphDw + n_obj * kMatDw + P.n_meshes * kMeshDw;
+    const char* lds_root = nullptr;
+    if (RBRT_ROOT_LDS && P.n_meshes != 0) {  // a copy of mesh 0's root node behind the generation parameters
+        uint32_t* rp = const_cast<uint32_t*>(gp) + kGenDw;
+        rp += (4u - ((rp - lds) & 3u)) & 3u;  // 16-byte alignment for ds_read_b128
+        if (lane < 32u) rp[lane] = reinterpret_cast<const uint32_t*>(P.root0)[lane];
+        lds_root = reinterpret_cast<const char*>(rp);
+    }
     const float* const gpf = reinterpret_cast<const float*>(gp);
     const SceneLds sc = {reinterpret_cast<const float*>(sc_base), sc_base + P.n_spheres * kSphDw,
                          sc_base + P.n_spheres * kSphDw + n_obj * kMatDw};
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 if (can_walk) {
                     uint32_t k[4];
                     f32x4 links;
-                    node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links);
+                    node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links, lds_root, t_cur == 0 && t_mesh == 0u);
                     if (STATS) ++lc.nodes;
 #if RBRT_PUSH_ORDER == 0
                     if (k[0] != kMissKey) {  // farthest first, so that the nearest is popped first
