@@ -27,6 +27,7 @@ hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height,
 hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, float* out_t, int32_t* out_obj,
                              int32_t* out_tri, float* out_dist, hipStream_t stream);
 hipError_t launch_gate_selftest(const float* d_box, const float* d_rays, size_t n, uint8_t* d_fast, uint8_t* d_exact);
+bool megakernel_has_handover();
 uint64_t host_splitmix64(uint64_t x);
 }  // namespace rbrt
 
@@ -91,6 +92,8 @@ struct rbrt_hip_scene {
         unsigned long long* d_work_counter = nullptr;
         uint32_t* d_gseq = nullptr;
         uint32_t* d_gstack = nullptr;
+        uint32_t* d_xready = nullptr;  // drain hand-over: per-wave published counts (zero between launches)
+        uint32_t* d_xrec = nullptr;    // ... and the path records
         hipEvent_t ev_traced = nullptr, ev_resolved = nullptr;
         bool in_use = false;  // ev_resolved has been recorded at least once
     };
@@ -117,6 +120,8 @@ struct rbrt_hip_scene {
     uint32_t leaf_round = 6;      // RBRT_LEAF_ROUND
     uint32_t leaf_tris = 32;      // RBRT_LEAF_TRIS
     uint32_t drain_mode = 1;      // RBRT_DRAIN_MODE
+    uint32_t xgroup = 0;          // RBRT_XGROUP: drain hand-over group size (0 = off; builds with -DRBRT_HANDOVER=1 only)
+    uint32_t xthreshold = 256;    // RBRT_XTHRESH: a donor hands over once it holds at most this many paths
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
     // stats / timing
@@ -230,6 +235,15 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
         s->allocs.push_back(p);
         L.d_gstack = static_cast<uint32_t*>(p);
+        HIP_TRY(hipMalloc(&p, size_t(s->scratch_waves) * sizeof(uint32_t)));
+        s->allocs.push_back(p);
+        L.d_xready = static_cast<uint32_t*>(p);
+        HIP_TRY(hipMemset(p, 0, size_t(s->scratch_waves) * sizeof(uint32_t)));
+        if (s->xgroup != 0) {  // (experiment builds only)
+            HIP_TRY(hipMalloc(&p, size_t(s->scratch_waves) * s->pool * 128u));  // one 128-B record per path slot of every wave
+            s->allocs.push_back(p);
+            L.d_xrec = static_cast<uint32_t*>(p);
+        }
         // the lane is recorded before its stream and events exist, so that a failure below leaves them to
         // rbrt_hip_scene_destroy instead of leaking them (a lane without a stream is never selected: the caller
         // gets the error)
@@ -560,7 +574,13 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             int v = std::atoi(e);
             if (v >= 1 && v <= 256) s->leaf_tris = uint32_t(v);
         }
-        if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 3u;
+        if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 7u;
+        if (const char* e = std::getenv("RBRT_XGROUP")) {
+            int v = std::atoi(e);
+            if (v == 0 || (v >= 2 && v <= 64)) s->xgroup = uint32_t(v);  // (lanes 1..group-1 of the collector track the donors)
+        }
+        if (!megakernel_has_handover()) s->xgroup = 0;
+        if (const char* e = std::getenv("RBRT_XTHRESH")) s->xthreshold = uint32_t(std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("RBRT_SHADE_ROUNDS")) {
             int v = std::atoi(e);
             if (v >= 1 && v <= int(kMaxShadeRounds)) s->shade_rounds = uint32_t(v);
@@ -703,6 +723,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.leaf_round = s->leaf_round;
     P.leaf_tris = s->leaf_tris;
     P.drain_mode = s->drain_mode;
+    P.xgroup = s->xgroup;
+    P.xthreshold = s->xthreshold;
     P.shade_rounds = s->shade_rounds;
     P.shade_cont_min = s->shade_cont_min;
 
@@ -758,6 +780,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.work_counter = L.d_work_counter;
         P.gseq = L.d_gseq;
         P.gstack = L.d_gstack;
+        P.xready = L.d_xready;
+        P.xrec = L.d_xrec;
         // (L.d_work_counter is zero: from its allocation, afterwards from the resolve kernel of the lane's last launch)
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
@@ -770,6 +794,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         }
         R.sample_buf = L.d_sample_buf;
         R.work_counter = L.d_work_counter;
+        R.xready = L.d_xready;
+        R.n_xready = s->scratch_waves;
         R.batch = nb;
         R.first_batch = base == 0;
         R.last_batch = base + nb == o->spp;

@@ -126,6 +126,10 @@ struct TraceParams {
     uint32_t y_high_water, y_high_min_parked;  // ... or fewer than y_high_water while at least that many rays are parked
     uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one ...
     uint32_t leaf_tris;                // ... or once the pending leaves hold this many triangles (a leaf round deals them out to all lanes)
+    uint32_t xgroup;                   // drain hand-over: workgroups per group (0 = off), the first of each is the collector
+    uint32_t xthreshold;               // ... a donor hands its paths over once it holds at most this many
+    uint32_t* xready;                  // [n_waves] published record count + 1 per donor (zeroed before every launch)
+    uint32_t* xrec;                    // [n_waves / xgroup][xgroup - 1][pool][32] handed-over path records
     uint32_t drain_mode;               // scheduling once the work items have run out (bits: megakernel.inl "drain")
     uint32_t shade_rounds;             // shading pass: rounds a sphere-only bounce chain may stay in registers
     uint32_t shade_cont_min;           // ... as long as at least this many lanes continue (ignored once the work has run out)
@@ -142,6 +146,8 @@ struct ResolveParams {
     float* out_radiance;  // row-major image if tile_world <= 1, else packed tiles; may be null
     uint8_t* out_rgb8;    // same indexing; may be null
     unsigned long long* work_counter;  // the finished launch's work counters, zeroed here for the lane's next launch
+    uint32_t* xready;                  // ... and its hand-over counts
+    uint32_t n_xready;
 };
 
 }  // namespace rbrt

@@ -534,6 +534,8 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) 
     // waits for this kernel), saving a memset launch that would have to queue behind the resident megakernels
     static_assert(kWorkShards * kWorkCounterStride <= kBlock, "one thread per counter word");
     if (blockIdx.x == 0 && threadIdx.x < kWorkShards * kWorkCounterStride) R.work_counter[threadIdx.x] = 0ull;
+    if (blockIdx.x == 0)
+        for (uint32_t j = threadIdx.x; j < R.n_xready; j += kBlock) R.xready[j] = 0u;
     if (i >= npix) return;
     const uint32_t tile_local = uint32_t(i >> 6), p = uint32_t(i & 63u);
     const uint32_t tile = tile_local * R.tile_world + R.tile_rank;
@@ -719,6 +721,8 @@ hipError_t launch_gate_selftest(const float* d_box, const float* d_rays, size_t 
                        d_fast, d_exact);
     return hipGetLastError();
 }
+
+bool megakernel_has_handover() { return RBRT_HANDOVER != 0; }
 
 uint64_t host_splitmix64(uint64_t x) { return splitmix64(x); }
 
