@@ -39,8 +39,10 @@
 #define RBRT_MK_WAVES_PER_SIMD 4  // register budget: 512 / 4 = 128 VGPRs per lane
 #endif
 
-// (the distance of the closest hit so far is not stored: it is a pure function of the ray and F_T -- the same
-// `length(o - (o + t*d))` expression that produced it -- and is recomputed where scene.rs:27,37 compares it)
+// (F_TRI is the winning triangle while the closest hit is a mesh; while it is a SPHERE the word holds the bits of
+// that hit's distance instead -- what scene.rs:27,37 compares the meshes' distances with. For a mesh hit the
+// distance is a pure function of the ray and F_T, the same `length(o - (o + t*d))` expression that produced it,
+// and is recomputed in the rare case that a later mesh has to be compared with an earlier one.)
 enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_S0, F_S1, F_ITEM, F_META, F_T, F_TRI, F_WORD, kFields };
 constexpr uint32_t kXRecDw = 32u;  // one handed-over path: kFields pool dwords, status, kSeqWords record words (128 B)
 constexpr uint32_t kCellDw = 128u, kTqDw = 64u;  // LDS behind the pool: 64 x u64 result cells, 64 x u32 triangle-test queue
@@ -307,9 +309,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 const uint32_t meta = POOL(F_META, slot);
                 int32_t obj = int32_t((meta >> 14) & 255u) - 1;
                 float closest = 3.40282347e+38f;  // f32::MAX (scene.rs:21)
-                if (obj >= 0) {                   // dist_from_ray_orig of the closest hit so far, recomputed as it was computed
-                    const V3 pc = t_o + __uint_as_float(POOL(F_T, slot)) * t_d;
-                    closest = length(t_o - pc);
+                if (obj >= 0) {                   // dist_from_ray_orig of the closest hit so far
+                    if (uint32_t(obj) < P.n_spheres) {
+                        closest = __uint_as_float(POOL(F_TRI, slot));  // a sphere: stored by the pass that found it
+                    } else {                      // an earlier mesh of this ray: recomputed as it was computed
+                        const V3 pc = t_o + __uint_as_float(POOL(F_T, slot)) * t_d;
+                        closest = length(t_o - pc);
+                    }
                 }
                 if (t_best > eps && t_best < 100000.0f) {  // triangle.rs:405
                     const V3 p = t_o + t_best * t_d;
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 POOL(F_ITEM, slot) = item;
                 POOL(F_WORD, slot) = word;
                 POOL(F_T, slot) = __float_as_uint(s_ht);
-                POOL(F_TRI, slot) = 0u;
+                POOL(F_TRI, slot) = __float_as_uint(closest);  // (meaningful while the closest hit is a sphere)
                 POOL(F_META, slot) = pack_meta(depth, nrec, s_obj, gated < P.n_meshes ? gated : 0u);
                 status[slot] = uint8_t(next);
             } else if (round == 1 && kind == ST_TERM && !have_ray && (is_main || is_gen)) {
