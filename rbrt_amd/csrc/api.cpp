@@ -120,6 +120,8 @@ struct rbrt_hip_scene {
     uint32_t leaf_round = 6;      // RBRT_LEAF_ROUND
     uint32_t leaf_tris = 32;      // RBRT_LEAF_TRIS
     uint32_t drain_mode = 1;      // RBRT_DRAIN_MODE
+    uint32_t work_stripes = 16;   // RBRT_WORK_STRIPES: chunks (of 64 work items) per stripe, long launches only; 0 = contiguous shards
+    int work_stripes_short = 0;   // RBRT_WORK_STRIPES_SHORT: the same for launches under 24 M samples
     uint32_t xgroup = 0;          // RBRT_XGROUP: drain hand-over group size (0 = off; builds with -DRBRT_HANDOVER=1 only)
     uint32_t xthreshold = 256;    // RBRT_XTHRESH: a donor hands over once it holds at most this many paths
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
@@ -574,6 +576,8 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             int v = std::atoi(e);
             if (v >= 1 && v <= 256) s->leaf_tris = uint32_t(v);
         }
+        if (const char* e = std::getenv("RBRT_WORK_STRIPES")) s->work_stripes = uint32_t(std::max(0, std::atoi(e)));
+        if (const char* e = std::getenv("RBRT_WORK_STRIPES_SHORT")) s->work_stripes_short = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 7u;
         if (const char* e = std::getenv("RBRT_XGROUP")) {
             int v = std::atoi(e);
@@ -723,6 +727,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.leaf_round = s->leaf_round;
     P.leaf_tris = s->leaf_tris;
     P.drain_mode = s->drain_mode;
+    P.work_stripes = s->work_stripes;  // (per launch: set where the launch's size is known)
     P.xgroup = s->xgroup;
     P.xthreshold = s->xthreshold;
     P.shade_rounds = s->shade_rounds;
@@ -776,6 +781,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.batch = nb;
         P.batch_magic = div_magic_of(nb);
         P.n_items = uint64_t(npix) * nb;
+        P.work_stripes = short_launch(P.n_items) ? uint32_t(s->work_stripes_short) : s->work_stripes;
         P.sample_buf = L.d_sample_buf;
         P.work_counter = L.d_work_counter;
         P.gseq = L.d_gseq;

@@ -130,6 +130,7 @@ struct TraceParams {
     uint32_t xthreshold;               // ... a donor hands its paths over once it holds at most this many
     uint32_t* xready;                  // [n_waves] published record count + 1 per donor (zeroed before every launch)
     uint32_t* xrec;                    // [n_waves / xgroup][xgroup - 1][pool][32] handed-over path records
+    uint32_t work_stripes;             // chunks per stripe when the work shards interleave over the item range (0: contiguous eighths)
     uint32_t drain_mode;               // scheduling once the work items have run out (bits: megakernel.inl "drain")
     uint32_t shade_rounds;             // shading pass: rounds a sphere-only bounce chain may stay in registers
     uint32_t shade_cont_min;           // ... as long as at least this many lanes continue (ignored once the work has run out)

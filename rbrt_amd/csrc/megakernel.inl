@@ -109,12 +109,15 @@ __device__ __forceinline__ uint32_t classify(const SceneLds& sc, int32_t obj, ui
     return ST_LAMB + sc.mat[uint32_t(obj) * kMatDw + 4];
 }
 
-// Work items (tile, sample, pixel) are handed out in chunks of 64 from kWorkShards global counters, each
-// covering a contiguous eighth of the item range. A wave starts on the shard of its XCD (blocks that share
-// an L2 then work on neighbouring tiles and the counters do not all sit on one address: a single word
-// saturates near 90 atomics/us, MI355X_MICROARCH.md "dequeue"), and moves on to the next shard when its
-// own is exhausted, so every item is handed out exactly once whatever the placement is. The next chunk is
-// requested one TERM pass ahead, so the atomic's latency is off the critical path.
+// Work items (tile, sample, pixel) are handed out in chunks of 64 from kWorkShards global counters. A wave starts
+// on the shard of its XCD (the counters do not all sit on one address: a single word saturates near 90 atomics/us,
+// MI355X_MICROARCH.md "dequeue"), and moves on to the next shard when its own is exhausted, so every item is handed
+// out exactly once whatever the placement is. The next chunk is requested one TERM pass ahead, so the atomic's
+// latency is off the critical path.
+// Shards INTERLEAVE over the item range in stripes of P.work_stripes chunks (0: contiguous eighths, the round-1
+// layout): stripe b of shard k is global stripe 8b + k, so all shards sweep the image in the same order and the
+// launch ENDS on the tiles api.cpp put last (the empty ones: short paths, a short drain). With contiguous eighths
+// the cheap shards ran dry first and the launch ended wherever the longest paths are.
 constexpr uint32_t kWorkChunk = 64;
 struct WorkSource {
     uint32_t res_next = 0, res_end = 0;  // wave-uniform: the chunk being handed out (global item numbers)
@@ -146,12 +149,24 @@ struct WorkSource {
             const unsigned long long local = (unsigned long long)__shfl(int(uint32_t(pend_base)), 0) |
                                              ((unsigned long long)__shfl(int(uint32_t(pend_base >> 32)), 0) << 32);
             pending = false;
-            const unsigned long long base = shard_lo(P, pend_shard), end = shard_lo(P, pend_shard + 1u);
-            if (base + local < end) {
-                lo = uint32_t(base + local);
-                hi = uint32_t(base + local + kWorkChunk < end ? base + local + kWorkChunk : end);
-                n_dry = 0;
-                return true;
+            if (P.work_stripes) {
+                const unsigned long long l = local / kWorkChunk;  // chunk number inside the shard
+                const unsigned long long stripe = P.work_stripes;
+                const unsigned long long g = ((l / stripe) * kWorkShards + pend_shard) * stripe + l % stripe;
+                if (g * kWorkChunk < P.n_items) {  // (n_items is a multiple of the chunk size: 64 pixel slots per tile)
+                    lo = uint32_t(g * kWorkChunk);
+                    hi = lo + kWorkChunk;
+                    n_dry = 0;
+                    return true;
+                }
+            } else {
+                const unsigned long long base = shard_lo(P, pend_shard), end = shard_lo(P, pend_shard + 1u);
+                if (base + local < end) {
+                    lo = uint32_t(base + local);
+                    hi = uint32_t(base + local + kWorkChunk < end ? base + local + kWorkChunk : end);
+                    n_dry = 0;
+                    return true;
+                }
             }
             shard = (pend_shard + 1u) % kWorkShards;  // this shard is exhausted: move on
             if (++n_dry >= kWorkShards) {
