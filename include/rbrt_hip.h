@@ -256,6 +256,12 @@ int rbrt_hip_trace_rays(rbrt_hip_scene_t* scene, const float* rays, size_t n, fl
 int rbrt_hip_selftest_gate(const float lo[3], const float hi[3], const float* rays, size_t n, uint8_t* out_fast,
                            uint8_t* out_exact);
 
+/* Test hook: the image needs correctly rounded sqrt and / (vec3.rs:111-126); the kernels use short forms of them when
+ * every lane's operands are in the everyday range (kernels.hip "IEEE square root and division, the short way"). Runs n
+ * pseudo-random operands through the short forms and the compiler's: counts[0] / counts[1] = differing sqrt results /
+ * normalize components (must be 0), counts[2] = lanes that really took the short path. */
+int rbrt_hip_selftest_ieee(uint64_t seed, size_t n, uint64_t counts[3]);
+
 /* Diagnostic: pass statistics of the persistent megakernel from the last render with
  * RBRT_FLAG_COLLECT_STATS: out[0..5] passes per kind (empty, traverse, terminate, lambertian, metal,
  * dielectric), out[6..11] path slots handled per kind, out[12] traversal wave-steps, out[13] busy

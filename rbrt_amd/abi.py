@@ -129,6 +129,7 @@ HIP_SYMBOLS = {
     "rbrt_hip_scene_check": (C.c_int, [C.c_void_p]),
     "rbrt_hip_scene_last_batching": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rbrt_hip_trace_rays": (C.c_int, [C.c_void_p, f32p, C.c_size_t, C.c_float, C.c_float, f32p, i32p, i32p, f32p]),
+    "rbrt_hip_selftest_ieee": (C.c_int, [C.c_uint64, C.c_size_t, C.POINTER(C.c_uint64)]),
     "rbrt_hip_selftest_gate": (C.c_int, [f32p, f32p, f32p, C.c_size_t, u8p, u8p]),
     "rbrt_hip_bvh_build_host": (C.c_int, [C.POINTER(Mesh), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),

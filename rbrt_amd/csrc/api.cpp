@@ -27,6 +27,7 @@ hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height,
 hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, float* out_t, int32_t* out_obj,
                              int32_t* out_tri, float* out_dist, hipStream_t stream);
 hipError_t launch_gate_selftest(const float* d_box, const float* d_rays, size_t n, uint8_t* d_fast, uint8_t* d_exact);
+hipError_t launch_ieee_selftest(uint64_t seed, size_t n, unsigned long long* d_counts);
 bool megakernel_has_handover();
 uint64_t host_splitmix64(uint64_t x);
 }  // namespace rbrt
@@ -1064,6 +1065,24 @@ int rbrt_hip_selftest_gate(const float lo[3], const float hi[3], const float* ra
     if (e == hipSuccess) e = hipMemcpy(out_exact, d_e, n, hipMemcpyDeviceToHost);
     cleanup();
     if (e != hipSuccess) return fail(RBRT_ERR_HIP, std::string("selftest_gate: ") + hipGetErrorString(e));
+    return RBRT_OK;
+}
+
+// Test hook: the kernels' short forms of IEEE sqrt / normalize against the compiler's, on n pseudo-random operands.
+int rbrt_hip_selftest_ieee(uint64_t seed, size_t n, uint64_t counts[3]) {
+    if (!counts) return fail(RBRT_ERR_INVALID_ARG, "selftest_ieee: null argument");
+    if (n >= (1ull << 32) * 256ull) return fail(RBRT_ERR_INVALID_ARG, "selftest_ieee: n too large");
+    if (int rc = ensure_device(0)) return rc;
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d, 0, 3 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = launch_ieee_selftest(seed, n, d);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RBRT_ERR_HIP, std::string("selftest_ieee: ") + hipGetErrorString(e));
+    for (int k = 0; k < 3; ++k) counts[k] = h[k];
     return RBRT_OK;
 }
 

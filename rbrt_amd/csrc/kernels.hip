@@ -38,12 +38,63 @@ __device__ __forceinline__ V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y *
 __device__ __forceinline__ V3 operator*(float s, V3 b) { return V3{s * b.x, s * b.y, s * b.z}; }
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ float length(V3 a) {
-    return __builtin_sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+
+// ---- IEEE square root and division, the short way ----------------------------------------------------------
+// The image needs correctly rounded sqrt and / (the reference's f32::sqrt and `/`). hipcc's expansions are 17 and
+// 13 instructions: v_sqrt / v_rcp plus correction steps, wrapped in range handling (input scaling for tiny
+// operands, v_div_scale / v_div_fixup, class checks for 0 and inf). For operands in the everyday range that
+// wrapping is the identity, and the correction steps -- reproduced below instruction for instruction -- give the same
+// bits. RBRT_FAST_IEEE: a wave takes the short forms when EVERY active lane's operands are in range (one compare or
+// two per call) and the compiler's forms otherwise. tests: test_short_ieee_forms_match_the_compilers (2^28 operands).
+#ifndef RBRT_FAST_IEEE
+#define RBRT_FAST_IEEE 1
+#endif
+__device__ __forceinline__ float sqrt_core(float x) {  // x in [2^-80, 2^100]: hipcc's sqrt without its scaling / class steps
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float r_dn = __uint_as_float(__float_as_uint(r) - 1u), r_up = __uint_as_float(__float_as_uint(r) + 1u);
+    const float e_dn = __builtin_fmaf(-r_dn, r, x), e_up = __builtin_fmaf(-r_up, r, x);
+    float s = e_dn <= 0.0f ? r_dn : r;
+    s = e_up > 0.0f ? r_up : s;
+    return s;
 }
-__device__ __forceinline__ V3 normalize(V3 a) {  // three divisions, vec3.rs:119-126
-    float len = length(a);
+__device__ __forceinline__ bool sqrt_in_range(float x) { return x > 0x1p-80f && x < 0x1p100f; }  // (false for NaN)
+__device__ __forceinline__ float ieee_sqrt(float x) {
+    if (RBRT_FAST_IEEE && __builtin_amdgcn_ballot_w64(!sqrt_in_range(x)) == 0ull) return sqrt_core(x);
+    return __builtin_sqrtf(x);
+}
+__device__ __forceinline__ float length(V3 a) { return ieee_sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ __attribute__((noinline)) V3 normalize_ieee(V3 a) {  // the compiler's forms, out of line: the rare path
+    const float len = __builtin_sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
     return V3{a.x / len, a.y / len, a.z / len};
+}
+__device__ __forceinline__ V3 normalize(V3 a) {  // three divisions by the length, vec3.rs:119-126
+    if (!RBRT_FAST_IEEE) {
+        const float len = __builtin_sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+        return V3{a.x / len, a.y / len, a.z / len};
+    }
+    const float s = (a.x * a.x + a.y * a.y) + a.z * a.z;
+    const float mn = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    // in range: no scaling in sqrt; len in [2^-40, 2^50]; every |component| >= 2^-100 (so v_div_scale leaves numerator
+    // and denominator alone: exponent(num) > 23, |num/len| <= 1 is normal) and <= len; nothing is 0, inf or NaN
+    const bool ok = sqrt_in_range(s) && mn > 0x1p-100f;
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) return normalize_ieee(a);
+    const float len = sqrt_core(s);
+    // hipcc's fdiv, minus v_div_scale / v_div_fixup, the reciprocal refinement shared by the three numerators
+    float rc = __builtin_amdgcn_rcpf(len);
+    rc = __builtin_fmaf(__builtin_fmaf(-len, rc, 1.0f), rc, rc);
+    V3 q;
+    {
+        float v = a.x * rc;
+        v = __builtin_fmaf(__builtin_fmaf(-len, v, a.x), rc, v);
+        q.x = __builtin_fmaf(__builtin_fmaf(-len, v, a.x), rc, v);
+        v = a.y * rc;
+        v = __builtin_fmaf(__builtin_fmaf(-len, v, a.y), rc, v);
+        q.y = __builtin_fmaf(__builtin_fmaf(-len, v, a.y), rc, v);
+        v = a.z * rc;
+        v = __builtin_fmaf(__builtin_fmaf(-len, v, a.z), rc, v);
+        q.z = __builtin_fmaf(__builtin_fmaf(-len, v, a.z), rc, v);
+    }
+    return q;
 }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
@@ -108,9 +159,9 @@ __device__ __forceinline__ bool sphere_hit(V3 c, float radius, V3 o, V3 d, float
         return false;
     }
     if (sol < 0.0f) return false;
-    float t = (-b - __builtin_sqrtf(sol)) / (2.0f * a);
+    float t = (-b - ieee_sqrt(sol)) / (2.0f * a);
     if (sol > 0.0f && t < 0.0f) {
-        t = (-b + __builtin_sqrtf(sol)) / (2.0f * a);
+        t = (-b + ieee_sqrt(sol)) / (2.0f * a);
         if (t < 0.0f) return false;
     }
     V3 p = o + t * d;
@@ -637,6 +688,47 @@ __global__ __launch_bounds__(kRaysBlock) void trace_rays_kernel(const TraceParam
     if (out_dist) out_dist[i] = hit ? h.dist : nanv;
 }
 
+// Test hook (rbrt_hip_selftest_ieee): the short IEEE forms (sqrt_core inside ieee_sqrt, normalize) against the
+// compiler's on pseudo-random operands. Waves 0,1,2 (mod 4) draw every lane's operands from the in-range domain, so
+// the short forms are what runs; waves 3 (mod 4) mix in zeros, denormals, huge, inf and NaN: the ballot sends those
+// waves through the compiler's forms, which must then be what comes out. counts[0] = mismatching sqrt results,
+// counts[1] = mismatching normalize components, counts[2] = lanes that took the short path (in-range waves).
+__global__ __launch_bounds__(kBlock) void ieee_selftest_kernel(uint64_t seed, size_t n, unsigned long long* counts) {
+    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Rng rng;
+    rng.init(seed, uint32_t(i >> 20), uint32_t(i));
+    const uint32_t mode = uint32_t(i >> 6) & 3u;
+    auto draw = [&](int e_lo, int e_hi) {  // +-(1.m) * 2^e, e uniform in [e_lo, e_hi]
+        const uint32_t r = rng.next_u32(), q = rng.next_u32();
+        const int e = e_lo + int(q % uint32_t(e_hi - e_lo + 1));
+        return __uint_as_float((r & 0x807FFFFFu) | (uint32_t(e + 127) << 23));
+    };
+    V3 a;
+    float x;
+    if (mode != 3u) {
+        a = mk(draw(-39, 49), draw(-39, 49), draw(-39, 49));
+        x = __builtin_fabsf(draw(-79, 99));
+    } else {
+        const uint32_t pick = rng.next_u32();
+        a = mk(draw(-126, 127), draw(-126, 127), draw(-126, 127));
+        x = __builtin_fabsf(draw(-126, 127));
+        const float specials[8] = {0.0f, -0.0f, __uint_as_float(1u), __uint_as_float(0x007FFFFFu), __uint_as_float(0x7F7FFFFFu),
+                                   __uint_as_float(0x7F800000u), __uint_as_float(0xFF800000u), __uint_as_float(0x7FC00000u)};
+        if ((pick & 3u) == 0u) a.x = specials[(pick >> 2) & 7u];
+        if ((pick & 12u) == 0u) a.y = specials[(pick >> 5) & 7u];
+        if ((pick & 48u) == 0u) x = __builtin_fabsf(specials[(pick >> 8) & 7u]);
+    }
+    auto same = [](float p, float q) { return __float_as_uint(p) == __float_as_uint(q) || (p != p && q != q); };
+    const float s_fast = ieee_sqrt(x), s_ref = __builtin_sqrtf(x);
+    const V3 n_fast = normalize(a), n_ref = normalize_ieee(a);
+    unsigned long long bad_s = same(s_fast, s_ref) ? 0ull : 1ull;
+    unsigned long long bad_n = (same(n_fast.x, n_ref.x) ? 0ull : 1ull) + (same(n_fast.y, n_ref.y) ? 0ull : 1ull) + (same(n_fast.z, n_ref.z) ? 0ull : 1ull);
+    if (bad_s) atomicAdd(&counts[0], bad_s);
+    if (bad_n) atomicAdd(&counts[1], bad_n);
+    if (mode != 3u && threadIdx.x % 64 == 0) atomicAdd(&counts[2], 64ull);
+}
+
 // Test hook (rbrt_hip_selftest_gate): both forms of the mesh gate on arbitrary rays against one box.
 __global__ __launch_bounds__(kBlock) void gate_selftest_kernel(const float* __restrict__ box, const float* __restrict__ rays, size_t n,
                                                                uint8_t* out_fast, uint8_t* out_exact) {
@@ -719,6 +811,12 @@ hipError_t launch_gate_selftest(const float* d_box, const float* d_rays, size_t 
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(gate_selftest_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, d_box, d_rays, n,
                        d_fast, d_exact);
+    return hipGetLastError();
+}
+
+hipError_t launch_ieee_selftest(uint64_t seed, size_t n, unsigned long long* d_counts) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(ieee_selftest_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, seed, n, d_counts);
     return hipGetLastError();
 }
 
