@@ -179,7 +179,9 @@ hipError_t device_build_mesh(const rbrt_mesh_t& m, BvhTri* d_tris_out, uint32_t 
     if (e == hipSuccess) {
         const DeviceMeshSoa soa = {d_soa, d_soa + stride, d_soa + 2 * stride, d_soa + 3 * stride, d_soa + 4 * stride,
                                    d_soa + 5 * stride, d_soa + 6 * stride, d_soa + 7 * stride, d_soa + 8 * stride, d_pad};
-        e = build_bvh_device(soa, m.n_total, d_tris_out, tri_base, r, nullptr);
+        int algo = 0;
+        if (const char* a = std::getenv("RBRT_BVH_DEVICE_ALGO")) algo = !std::strcmp(a, "lbvh") ? 1 : 0;
+        e = build_bvh_device(soa, m.n_total, d_tris_out, tri_base, r, nullptr, algo);
     }
     if (e == hipSuccess && r->ok && d_normals)
         e = device_normals(d_soa + 9 * stride, d_soa + 10 * stride, d_soa + 11 * stride, m.n_total, d_normals, nullptr);

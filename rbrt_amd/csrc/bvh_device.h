@@ -26,8 +26,9 @@ struct DeviceBvhResult {
 // Builds the BVH of one mesh on `stream` and writes its triangle records, in leaf order, to d_tris_out (room for
 // 8*floor(n_total/8) records). Leaf links are absolute positions in the scene's triangle array: tri_base is the
 // position of d_tris_out[0] in it. Synchronises the stream (the sizes of the later stages depend on counts).
+// algo: 0 = parallel locally-ordered clustering (PLOC), 1 = binary radix tree over the Morton codes (LBVH).
 hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* d_tris_out, uint32_t tri_base,
-                            DeviceBvhResult* res, hipStream_t stream);
+                            DeviceBvhResult* res, hipStream_t stream, int algo = 0);
 
 // normals[i] = (nx[i], ny[i], nz[i], 0) on the device.
 hipError_t device_normals(const float* d_nx, const float* d_ny, const float* d_nz, uint32_t n, Normal4* d_out, hipStream_t stream);

@@ -1,5 +1,6 @@
-// bvh_device.hip — BVH construction on the GPU (gfx950): Morton-ordered binary radix tree (Karras 2012), bottom-up
-// box fit, collapse into the same 4-wide nodes and <= kLeafMax-triangle leaves the host builder (bvh.cpp) emits.
+// bvh_device.hip — BVH construction on the GPU (gfx950): Morton order, a binary tree by parallel locally-ordered
+// clustering (or a binary radix tree), collapse into the same 4-wide nodes and <= kLeafMax-triangle leaves the host
+// builder (bvh.cpp) emits.
 //
 // Why: the host builder's binned-SAH tree takes 0.4 s for an 871k-triangle mesh, two orders of magnitude more than
 // rendering a frame of it. The reference has no acceleration structure at all (mesh.rs:232-243), so
@@ -12,8 +13,9 @@
 //   prim_setup   per SoA entry: validity, box, centroid, |e1||e2|; centroid bounds by atomic min/max; valid count
 //   morton_keys  63-bit Morton code of the centroid (21 bits per axis) | invalid entries sort last
 //   rocprim::radix_sort_pairs (key = code, value = reference index)
-//   radix_tree   one thread per internal node of the binary radix tree (ties broken by position)
-//   fit          bottom-up: second arrival at a node merges its children's boxes
+//   binary tree  (A, default) PLOC: rounds of nearest-neighbour search in a window of the Morton order, mutual pairs
+//                merge, order-preserving compaction; (B, fallback / RBRT_BVH_DEVICE_ALGO=lbvh) binary radix tree
+//                (Karras 2012, ties broken by position) + bottom-up fit (second arrival merges its children's boxes)
 //   collapse     level by level from the root: a binary subtree of <= kLeafMax triangles becomes a leaf, larger
 //                ones are opened (largest surface first) until a node has four children; unused slots get NaN boxes
 //   emit_tris    48-byte records in leaf order, links absolute in the scene's triangle array
@@ -23,6 +25,10 @@
 #include <cstring>  // (rocprim 7.2 headers use memset without including it)
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <cstdlib>
 
 #include "bvh_device.h"
 #include "device_types.h"
@@ -32,10 +38,14 @@ namespace {
 
 constexpr int kTpb = 256;
 
-struct Bin {  // internal node i of the binary radix tree (n_valid - 1 of them); leaves are positions in sorted order
-    int32_t left, right;  // >= 0: internal node; < 0: ~position of a leaf
-    int32_t parent;
-    uint32_t first, last;  // covered positions [first, last]
+// The binary tree both constructions produce, as flat arrays over node ids: leaves are ids 0 .. n-1 (positions in
+// Morton order), internal nodes ids n .. 2n-2. nbox[id] = lo.xyz, max|e1||e2|, hi.xyz, half surface area.
+struct Tree {
+    float* nbox;       // [2n-1][8]
+    int32_t* left;     // [2n-1] (internal ids only)
+    int32_t* right;
+    uint32_t* size;    // [2n-1] triangles below
+    int32_t* parent;   // [2n-1] (radix tree only: the bottom-up fit walks it)
 };
 
 struct Work {  // build state shared by the kernels
@@ -46,6 +56,8 @@ struct Work {  // build state shared by the kernels
     uint32_t max_depth;
     uint32_t q_count[2];        // collapse queues
     float max_e12;
+    uint32_t n_internal;        // PLOC: internal nodes created so far
+    uint32_t root;              // id of the root
 };
 
 __device__ __forceinline__ uint32_t fenc(float f) {  // order-preserving float -> uint
@@ -149,8 +161,20 @@ __device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, i
     return __clzll(a ^ b);
 }
 
-__global__ __launch_bounds__(kTpb) void radix_tree(const uint64_t* __restrict__ keys, const Work* w, Bin* __restrict__ bin,
-                                                   int32_t* __restrict__ leaf_parent) {
+__global__ __launch_bounds__(kTpb) void init_leaves(const Work* w, const uint32_t* __restrict__ sorted, const float* __restrict__ boxes,
+                                                   Tree t) {
+    const uint32_t p = blockIdx.x * kTpb + threadIdx.x;
+    if (p >= w->n_valid) return;
+    const float* src = boxes + size_t(sorted[p]) * 8u;
+    float* dst = t.nbox + size_t(p) * 8u;
+    const float dx = src[4] - src[0], dy = src[5] - src[1], dz = src[6] - src[2];
+    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+    dst[4] = src[4], dst[5] = src[5], dst[6] = src[6], dst[7] = dx * dy + dy * dz + dz * dx;
+    t.size[p] = 1u;
+}
+
+// ---- construction A: binary radix tree over the Morton codes (Karras 2012) + bottom-up fit -------------------------
+__global__ __launch_bounds__(kTpb) void radix_tree(const uint64_t* __restrict__ keys, const Work* w, Tree t) {
     const int n = int(w->n_valid);
     const int i = blockIdx.x * kTpb + threadIdx.x;
     if (i >= n - 1) return;
@@ -159,96 +183,155 @@ __global__ __launch_bounds__(kTpb) void radix_tree(const uint64_t* __restrict__ 
     int lmax = 2;
     while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
     int l = 0;
-    for (int t = lmax >> 1; t >= 1; t >>= 1)
-        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    for (int s = lmax >> 1; s >= 1; s >>= 1)
+        if (delta(keys, n, i, i + (l + s) * d) > dmin) l += s;
     const int j = i + l * d;
     const int dnode = delta(keys, n, i, j);
-    int s = 0;
-    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
-        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-        if (t == 1) break;
+    int sp = 0;
+    for (int s = (l + 1) >> 1;; s = (s + 1) >> 1) {
+        if (delta(keys, n, i, i + (sp + s) * d) > dnode) sp += s;
+        if (s == 1) break;
     }
-    const int gamma = i + s * d + min(d, 0);
+    const int gamma = i + sp * d + min(d, 0);
     const int first = min(i, j), last = max(i, j);
-    const int32_t left = first == gamma ? ~gamma : gamma;
-    const int32_t right = last == gamma + 1 ? ~(gamma + 1) : gamma + 1;
-    // (field by field: a node's `parent` is written by its parent's thread, the rest by its own)
-    bin[i].left = left, bin[i].right = right, bin[i].first = uint32_t(first), bin[i].last = uint32_t(last);
-    if (left >= 0) bin[left].parent = i; else leaf_parent[~left] = i;
-    if (right >= 0) bin[right].parent = i; else leaf_parent[~right] = i;
-    if (i == 0) bin[0].parent = -1;
+    const int32_t me = n + i;
+    const int32_t left = first == gamma ? gamma : n + gamma;          // a leaf position, or internal node gamma
+    const int32_t right = last == gamma + 1 ? gamma + 1 : n + gamma + 1;
+    t.left[me] = left, t.right[me] = right, t.size[me] = uint32_t(last - first + 1);
+    t.parent[left] = me, t.parent[right] = me;
+    if (i == 0) t.parent[me] = -1;
 }
 
-// nbox: [n_valid - 1][8] = lo.xyz, max e12, hi.xyz, half area
-__global__ __launch_bounds__(kTpb) void fit(const Work* w, const Bin* __restrict__ bin, const int32_t* __restrict__ leaf_parent,
-                                            const uint32_t* __restrict__ sorted, const float* __restrict__ boxes,
-                                            float* __restrict__ nbox, uint32_t* __restrict__ arrived) {
+__global__ __launch_bounds__(kTpb) void fit(const Work* w, Tree t, uint32_t* __restrict__ arrived) {
     const uint32_t n = w->n_valid;
     const uint32_t p = blockIdx.x * kTpb + threadIdx.x;
     if (p >= n || n < 2) return;
-    int32_t node = leaf_parent[p];
+    int32_t node = t.parent[p];
     while (node >= 0) {
-        __threadfence();  // the first arrival's box writes (made by another thread) before this thread reads them
+        __threadfence();  // this thread's box writes, before it announces its arrival
         if (atomicAdd(&arrived[node], 1u) == 0u) return;  // the second arrival does the merge
-        __threadfence();
+        __threadfence();  // ... and the other arrival's writes, before they are read
         float lo[3], hi[3], e = 0.0f;
         for (int k = 0; k < 3; ++k) lo[k] = 3.40282347e+38f, hi[k] = -3.40282347e+38f;
-        const int32_t ch[2] = {bin[node].left, bin[node].right};
+        const int32_t ch[2] = {t.left[node], t.right[node]};
         for (int c = 0; c < 2; ++c) {
-            const float* src = ch[c] >= 0 ? nbox + size_t(ch[c]) * 8u : boxes + size_t(sorted[~ch[c]]) * 8u;
-            float v[8];  // (a node's box was written by a thread of possibly another workgroup: after the fences above)
+            const float* src = t.nbox + size_t(ch[c]) * 8u;
+            float v[8];
             for (int k = 0; k < 8; ++k) v[k] = src[k];
             for (int k = 0; k < 3; ++k) lo[k] = __builtin_fminf(lo[k], v[k]), hi[k] = __builtin_fmaxf(hi[k], v[4 + k]);
             e = __builtin_fmaxf(e, v[3]);
         }
-        float* dst = nbox + size_t(node) * 8u;
+        float* dst = t.nbox + size_t(node) * 8u;
         const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
         dst[0] = lo[0], dst[1] = lo[1], dst[2] = lo[2], dst[3] = e;
         dst[4] = hi[0], dst[5] = hi[1], dst[6] = hi[2], dst[7] = dx * dy + dy * dz + dz * dx;
-        node = bin[node].parent;
+        node = t.parent[node];
     }
 }
+
+// ---- construction B: parallel locally-ordered clustering (PLOC, Meister & Bittner 2018) ----------------------------
+// The clusters -- at first the triangles in Morton order -- are merged bottom-up: every cluster looks for the
+// neighbour within kPlocRadius positions whose union with it has the smallest surface, mutual choices merge, the
+// array is compacted (order kept) and the round repeats until one cluster is left. Unlike the radix tree, whose
+// splits are the Morton grid's, this looks at surfaces, and gives trees close to a top-down SAH build's.
+constexpr int kPlocRadius = 16;  // default search radius (RBRT_PLOC_RADIUS overrides: experiments)
+
+__global__ __launch_bounds__(kTpb) void ploc_nearest(const uint32_t* __restrict__ cl, uint32_t m, const float* __restrict__ nbox,
+                                                    uint32_t* __restrict__ nn, uint32_t radius) {
+    const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    if (i >= m) return;
+    const float4 a0 = reinterpret_cast<const float4*>(nbox + size_t(cl[i]) * 8u)[0];
+    const float4 a1 = reinterpret_cast<const float4*>(nbox + size_t(cl[i]) * 8u)[1];
+    const uint32_t j0 = i > radius ? i - radius : 0u;
+    const uint32_t j1 = i + radius < m - 1u ? i + radius : m - 1u;
+    float best = 3.40282347e+38f;
+    uint32_t bj = i == 0u ? 1u : i - 1u;
+    for (uint32_t j = j0; j <= j1; ++j) {
+        if (j == i) continue;
+        const float4 b0 = reinterpret_cast<const float4*>(nbox + size_t(cl[j]) * 8u)[0];
+        const float4 b1 = reinterpret_cast<const float4*>(nbox + size_t(cl[j]) * 8u)[1];
+        const float dx = __builtin_fmaxf(a1.x, b1.x) - __builtin_fminf(a0.x, b0.x);
+        const float dy = __builtin_fmaxf(a1.y, b1.y) - __builtin_fminf(a0.y, b0.y);
+        const float dz = __builtin_fmaxf(a1.z, b1.z) - __builtin_fminf(a0.z, b0.z);
+        const float area = dx * dy + dy * dz + dz * dx;
+        if (area < best) best = area, bj = j;  // (ties: the lower position; the same value from both sides of a pair)
+    }
+    nn[i] = bj;
+}
+
+__global__ __launch_bounds__(kTpb) void ploc_merge(Work* w, const uint32_t* __restrict__ cl, uint32_t m, const uint32_t* __restrict__ nn,
+                                                  Tree t, uint32_t n_leaves, uint32_t* __restrict__ cl_out, uint32_t* __restrict__ valid) {
+    const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nn[i];
+    uint32_t id = cl[i], keep = 1u;
+    if (nn[j] == i) {  // a mutual pair: the lower position carries the merged cluster, the higher one disappears
+        if (i < j) {
+            const uint32_t a = cl[i], b = cl[j];
+            id = n_leaves + atomicAdd(&w->n_internal, 1u);
+            const float* pa = t.nbox + size_t(a) * 8u;
+            const float* pb = t.nbox + size_t(b) * 8u;
+            float* dst = t.nbox + size_t(id) * 8u;
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) lo[k] = __builtin_fminf(pa[k], pb[k]), hi[k] = __builtin_fmaxf(pa[4 + k], pb[4 + k]);
+            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            dst[0] = lo[0], dst[1] = lo[1], dst[2] = lo[2], dst[3] = __builtin_fmaxf(pa[3], pb[3]);
+            dst[4] = hi[0], dst[5] = hi[1], dst[6] = hi[2], dst[7] = dx * dy + dy * dz + dz * dx;
+            t.left[id] = int32_t(a), t.right[id] = int32_t(b);
+            t.size[id] = t.size[a] + t.size[b];
+        } else {
+            keep = 0u;
+        }
+    }
+    cl_out[i] = id;
+    valid[i] = keep;
+}
+
+__global__ __launch_bounds__(kTpb) void ploc_compact(const uint32_t* __restrict__ cl_in, const uint32_t* __restrict__ valid,
+                                                    const uint32_t* __restrict__ pos, uint32_t m, uint32_t* __restrict__ cl_next,
+                                                    uint32_t* m_next) {
+    const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    if (i >= m) return;
+    if (valid[i]) cl_next[pos[i]] = cl_in[i];
+    if (i == m - 1u) *m_next = pos[i] + valid[i];
+}
+
+__global__ void ploc_root(Work* w, const uint32_t* cl) { w->root = cl[0]; }
+__global__ void radix_root(Work* w) { w->root = w->n_valid; }  // internal node 0
 
 struct QItem {
-    int32_t bnode;   // binary node to turn into a 4-wide node
-    uint32_t out;    // its index in the 4-wide node array
+    uint32_t bnode;   // binary node to turn into a 4-wide node
+    uint32_t out;     // its index in the 4-wide node array
+    uint32_t offset;  // position of its first triangle in the output order
 };
 
-__device__ __forceinline__ void cand_box(int32_t ref, const float* __restrict__ nbox, const float* __restrict__ boxes,
-                                         const uint32_t* __restrict__ sorted, float v[8]) {
-    const float* src = ref >= 0 ? nbox + size_t(ref) * 8u : boxes + size_t(sorted[~ref]) * 8u;
-    for (int k = 0; k < 8; ++k) v[k] = src[k];
-    if (ref < 0) {  // a single triangle: half area from its box
-        const float dx = v[4] - v[0], dy = v[5] - v[1], dz = v[6] - v[2];
-        v[7] = dx * dy + dy * dz + dz * dx;
-    }
-}
-
-// One level of the collapse. A candidate is a binary node (>= 0) or a single leaf position (~p < 0). A binary node
-// covering <= kLeafMax positions becomes a leaf; a larger one may be opened into its two children.
-__global__ __launch_bounds__(kTpb) void collapse_level(Work* w, const Bin* __restrict__ bin, const float* __restrict__ nbox,
-                                                       const float* __restrict__ boxes, uint32_t* __restrict__ sorted,
-                                                       const QItem* __restrict__ q_in, uint32_t n_in, QItem* __restrict__ q_out,
-                                                       uint32_t* q_out_count, BvhNode4* __restrict__ nodes, uint32_t node_cap,
-                                                       uint32_t tri_base, uint32_t depth) {
-    const uint32_t t = blockIdx.x * kTpb + threadIdx.x;
-    if (t >= n_in) return;
-    const QItem it = q_in[t];
-    int32_t c[4] = {bin[it.bnode].left, bin[it.bnode].right, 0, 0};
+// One level of the collapse. A candidate is a node of the binary tree; one with <= kLeafMax triangles below it becomes
+// a leaf, a larger one may be opened into its two children (the left child's triangles come first in the output).
+__global__ __launch_bounds__(kTpb) void collapse_level(Work* w, Tree t, uint32_t n_leaves, const uint32_t* __restrict__ sorted,
+                                                       uint32_t* __restrict__ order, const QItem* __restrict__ q_in, uint32_t n_in,
+                                                       QItem* __restrict__ q_out, uint32_t* q_out_count, BvhNode4* __restrict__ nodes,
+                                                       uint32_t node_cap, uint32_t tri_base, uint32_t depth) {
+    const uint32_t tid = blockIdx.x * kTpb + threadIdx.x;
+    if (tid >= n_in) return;
+    const QItem it = q_in[tid];
+    uint32_t c[4] = {uint32_t(t.left[it.bnode]), uint32_t(t.right[it.bnode]), 0u, 0u};
+    uint32_t off[4] = {it.offset, it.offset + t.size[c[0]], 0u, 0u};
     int n = 2;
-    auto expandable = [&](int32_t ref) { return ref >= 0 && bin[ref].last - bin[ref].first + 1u > uint32_t(kLeafMax); };
+    auto expandable = [&](uint32_t id) { return t.size[id] > uint32_t(kLeafMax); };
     while (n < 4) {  // open the expandable candidate with the largest surface (as bvh.cpp's collapse does)
         int pick = -1;
         float best = -1.0f;
         for (int k = 0; k < n; ++k)
             if (expandable(c[k])) {
-                const float a = nbox[size_t(c[k]) * 8u + 7u];
+                const float a = t.nbox[size_t(c[k]) * 8u + 7u];
                 if (a > best) best = a, pick = k;
             }
         if (pick < 0) break;
-        const int32_t open = c[pick];
-        c[pick] = bin[open].left;
-        c[n++] = bin[open].right;
+        const uint32_t open = c[pick], o0 = off[pick];
+        c[pick] = uint32_t(t.left[open]);
+        c[n] = uint32_t(t.right[open]);
+        off[n] = o0 + t.size[c[pick]];
+        ++n;
     }
     BvhNode4 o;
     const float qnan = __uint_as_float(0x7fc00000u);
@@ -259,8 +342,7 @@ __global__ __launch_bounds__(kTpb) void collapse_level(Work* w, const Bin* __res
             o.max_e12[k] = 0.0f;
             continue;
         }
-        float v[8];
-        cand_box(c[k], nbox, boxes, sorted, v);
+        const float* v = t.nbox + size_t(c[k]) * 8u;
         o.lo_x[k] = v[0], o.lo_y[k] = v[1], o.lo_z[k] = v[2];
         o.hi_x[k] = v[4], o.hi_y[k] = v[5], o.hi_z[k] = v[6];
         o.max_e12[k] = v[3];
@@ -272,18 +354,27 @@ __global__ __launch_bounds__(kTpb) void collapse_level(Work* w, const Bin* __res
                 continue;
             }
             o.child[k] = int32_t(idx);
-            q_out[atomicAdd(q_out_count, 1u)] = QItem{c[k], idx};
+            q_out[atomicAdd(q_out_count, 1u)] = QItem{c[k], idx, off[k]};
             atomicMax(&w->max_depth, depth + 1u);
-        } else {  // a leaf: positions [first, last] of the sorted order = records tri_base + first .. in the scene's array
-            const uint32_t first = c[k] >= 0 ? bin[c[k]].first : uint32_t(~c[k]);
-            const uint32_t last = c[k] >= 0 ? bin[c[k]].last : uint32_t(~c[k]);
-            for (uint32_t a = first + 1; a <= last; ++a) {  // ascending reference index inside a leaf (as bvh.cpp)
-                const uint32_t x = sorted[a];
-                uint32_t b = a;
-                while (b > first && sorted[b - 1] > x) sorted[b] = sorted[b - 1], --b;
-                sorted[b] = x;
+        } else {  // a leaf: its (<= kLeafMax) triangles go to positions off[k] .. of the output order
+            uint32_t stack[2 * kLeafMax], sp = 0, cnt = 0;
+            stack[sp++] = c[k];
+            while (sp != 0) {
+                const uint32_t id = stack[--sp];
+                if (id < n_leaves) {
+                    order[off[k] + cnt++] = sorted[id];
+                } else {
+                    stack[sp++] = uint32_t(t.right[id]);
+                    stack[sp++] = uint32_t(t.left[id]);
+                }
             }
-            o.child[k] = ~int32_t(((tri_base + first) << kLeafBits) | (last - first));
+            for (uint32_t a = 1; a < cnt; ++a) {  // ascending reference index inside a leaf (as bvh.cpp)
+                const uint32_t x = order[off[k] + a];
+                uint32_t b = a;
+                while (b > 0 && order[off[k] + b - 1] > x) order[off[k] + b] = order[off[k] + b - 1], --b;
+                order[off[k] + b] = x;
+            }
+            o.child[k] = ~int32_t(((tri_base + off[k]) << kLeafBits) | (cnt - 1u));
         }
     }
     nodes[it.out] = o;
@@ -308,6 +399,11 @@ __global__ __launch_bounds__(kTpb) void normals4(const float* __restrict__ nx, c
     if (i < n) out[i] = Normal4{nx[i], ny[i], nz[i], 0.0f};
 }
 
+__global__ __launch_bounds__(kTpb) void iota_kernel(uint32_t* a, uint32_t n) {
+    const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+
 __global__ void init_work(Work* w) {
     w->n_valid = 0;
     for (int k = 0; k < 3; ++k) w->cmin[k] = 0xFFFFFFFFu, w->cmax[k] = 0u;
@@ -316,8 +412,10 @@ __global__ void init_work(Work* w) {
     w->max_depth = 0;
     w->q_count[0] = w->q_count[1] = 0;
     w->max_e12 = 0.0f;
+    w->n_internal = 0;
+    w->root = 0;
 }
-__global__ void root_info(Work* w, const float* nbox) { w->max_e12 = nbox[3]; }
+__global__ void root_info(Work* w, const float* nbox) { w->max_e12 = nbox[size_t(w->root) * 8u + 3u]; }
 
 #define DEV_TRY(expr)                 \
     do {                              \
@@ -340,7 +438,7 @@ hipError_t device_normals(const float* d_nx, const float* d_ny, const float* d_n
 
 // See bvh_device.h.
 hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* d_tris_out, uint32_t tri_base,
-                            DeviceBvhResult* res, hipStream_t stream) {
+                            DeviceBvhResult* res, hipStream_t stream, int algo) {
     res->ok = false;
     res->d_nodes = nullptr;
     const uint32_t n_tested = (n_total / 8u) * 8u;  // triangle.rs:166-167
@@ -348,26 +446,28 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
     const Soa m = {soa.v0x, soa.v0y, soa.v0z, soa.e1x, soa.e1y, soa.e1z, soa.e2x, soa.e2y, soa.e2z, soa.is_padding};
     const uint32_t node_cap = n_tested / 2u + 8u;
     Work* w = nullptr;
-    float *boxes = nullptr, *nbox = nullptr;
+    float* boxes = nullptr;
     uint64_t *keys = nullptr, *keys2 = nullptr;
-    uint32_t *vals = nullptr, *sorted = nullptr, *arrived = nullptr;
-    int32_t* leaf_parent = nullptr;
-    Bin* bin = nullptr;
+    uint32_t *vals = nullptr, *sorted = nullptr, *order = nullptr, *arrived = nullptr;
+    uint32_t *cl[2] = {nullptr, nullptr}, *cl_tmp = nullptr, *nn = nullptr, *valid = nullptr, *pos = nullptr, *d_m = nullptr;
+    Tree t = {nullptr, nullptr, nullptr, nullptr, nullptr};
     QItem* queue[2] = {nullptr, nullptr};
-    void* tmp = nullptr;
+    void *tmp = nullptr, *scan_tmp = nullptr;
     BvhNode4* nodes = nullptr;
     auto cleanup = [&]() {
-        (void)hipFree(w), (void)hipFree(boxes), (void)hipFree(nbox), (void)hipFree(keys), (void)hipFree(keys2);
-        (void)hipFree(vals), (void)hipFree(sorted), (void)hipFree(arrived), (void)hipFree(leaf_parent), (void)hipFree(bin);
-        (void)hipFree(queue[0]), (void)hipFree(queue[1]), (void)hipFree(tmp);
+        (void)hipFree(w), (void)hipFree(boxes), (void)hipFree(keys), (void)hipFree(keys2), (void)hipFree(vals), (void)hipFree(sorted);
+        (void)hipFree(order), (void)hipFree(arrived), (void)hipFree(cl[0]), (void)hipFree(cl[1]), (void)hipFree(cl_tmp), (void)hipFree(nn);
+        (void)hipFree(valid), (void)hipFree(pos), (void)hipFree(d_m), (void)hipFree(t.nbox), (void)hipFree(t.left), (void)hipFree(t.right);
+        (void)hipFree(t.size), (void)hipFree(t.parent), (void)hipFree(queue[0]), (void)hipFree(queue[1]), (void)hipFree(tmp), (void)hipFree(scan_tmp);
         if (!res->ok) (void)hipFree(nodes);
     };
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&w), sizeof(Work)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&boxes), size_t(n_total) * 8u * sizeof(float)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&keys), size_t(n_total) * sizeof(uint64_t)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&keys2), size_t(n_total) * sizeof(uint64_t)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&vals), size_t(n_total) * sizeof(uint32_t)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&sorted), size_t(n_total) * sizeof(uint32_t)));
+    auto alloc = [&](auto** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(**p)); };
+    DEV_TRY(alloc(&w, 1));
+    DEV_TRY(alloc(&boxes, size_t(n_total) * 8u));
+    DEV_TRY(alloc(&keys, n_total));
+    DEV_TRY(alloc(&keys2, n_total));
+    DEV_TRY(alloc(&vals, n_total));
+    DEV_TRY(alloc(&sorted, n_total));
     hipLaunchKernelGGL(init_work, dim3(1), dim3(1), 0, stream, w);
     hipLaunchKernelGGL(prim_setup, dim3(blocks(n_total)), dim3(kTpb), 0, stream, m, n_total, n_tested, boxes, w);
     hipLaunchKernelGGL(morton_keys, dim3(blocks(n_total)), dim3(kTpb), 0, stream, boxes, n_total, w, keys, vals);
@@ -385,33 +485,74 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
         cleanup();
         return hipSuccess;
     }
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&bin), size_t(n) * sizeof(Bin)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&leaf_parent), size_t(n) * sizeof(int32_t)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&nbox), size_t(n) * 8u * sizeof(float)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&arrived), size_t(n) * sizeof(uint32_t)));
-    DEV_TRY(hipMemsetAsync(arrived, 0, size_t(n) * sizeof(uint32_t), stream));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&queue[0]), size_t(node_cap) * sizeof(QItem)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&queue[1]), size_t(node_cap) * sizeof(QItem)));
-    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&nodes), size_t(node_cap) * sizeof(BvhNode4)));
-    hipLaunchKernelGGL(radix_tree, dim3(blocks(n - 1)), dim3(kTpb), 0, stream, keys2, w, bin, leaf_parent);
-    hipLaunchKernelGGL(fit, dim3(blocks(n)), dim3(kTpb), 0, stream, w, bin, leaf_parent, sorted, boxes, nbox, arrived);
-    hipLaunchKernelGGL(root_info, dim3(1), dim3(1), 0, stream, w, nbox);
+    const size_t n_ids = 2u * size_t(n) - 1u;
+    DEV_TRY(alloc(&t.nbox, n_ids * 8u));
+    DEV_TRY(alloc(&t.left, n_ids));
+    DEV_TRY(alloc(&t.right, n_ids));
+    DEV_TRY(alloc(&t.size, n_ids));
+    DEV_TRY(alloc(&order, n));
+    DEV_TRY(alloc(&queue[0], node_cap));
+    DEV_TRY(alloc(&queue[1], node_cap));
+    DEV_TRY(alloc(&nodes, node_cap));
+    hipLaunchKernelGGL(init_leaves, dim3(blocks(n)), dim3(kTpb), 0, stream, w, sorted, boxes, t);
+    bool built = false;
+    if (algo == 0) {  // PLOC
+        DEV_TRY(alloc(&cl[0], n));
+        DEV_TRY(alloc(&cl[1], n));
+        DEV_TRY(alloc(&cl_tmp, n));
+        DEV_TRY(alloc(&nn, n));
+        DEV_TRY(alloc(&valid, n));
+        DEV_TRY(alloc(&pos, n));
+        DEV_TRY(alloc(&d_m, 1));
+        size_t scan_bytes = 0;
+        DEV_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, valid, pos, 0u, n, rocprim::plus<uint32_t>(), stream));
+        DEV_TRY(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 16));
+        hipLaunchKernelGGL(iota_kernel, dim3(blocks(n)), dim3(kTpb), 0, stream, cl[0], n);
+        uint32_t mcur = n, radius = uint32_t(kPlocRadius);
+        if (const char* e = std::getenv("RBRT_PLOC_RADIUS")) radius = uint32_t(std::min(256, std::max(1, std::atoi(e))));
+        int cur = 0, rounds = 0;
+        while (mcur > 1u && rounds < 400) {  // (every round merges at least the globally best pair; typically ~45 % of the clusters)
+            hipLaunchKernelGGL(ploc_nearest, dim3(blocks(mcur)), dim3(kTpb), 0, stream, cl[cur], mcur, t.nbox, nn, radius);
+            hipLaunchKernelGGL(ploc_merge, dim3(blocks(mcur)), dim3(kTpb), 0, stream, w, cl[cur], mcur, nn, t, n, cl_tmp, valid);
+            DEV_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, valid, pos, 0u, mcur, rocprim::plus<uint32_t>(), stream));
+            hipLaunchKernelGGL(ploc_compact, dim3(blocks(mcur)), dim3(kTpb), 0, stream, cl_tmp, valid, pos, mcur, cl[cur ^ 1], d_m);
+            DEV_TRY(hipMemcpyAsync(&mcur, d_m, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            DEV_TRY(hipStreamSynchronize(stream));
+            cur ^= 1;
+            ++rounds;
+        }
+        if (mcur == 1u) {
+            hipLaunchKernelGGL(ploc_root, dim3(1), dim3(1), 0, stream, w, cl[cur]);
+            built = true;
+        }
+    }
+    if (!built) {  // binary radix tree (also the fallback if the clustering did not converge)
+        DEV_TRY(alloc(&t.parent, n_ids));
+        DEV_TRY(alloc(&arrived, n_ids));
+        DEV_TRY(hipMemsetAsync(arrived, 0, n_ids * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(radix_tree, dim3(blocks(n - 1)), dim3(kTpb), 0, stream, keys2, w, t);
+        hipLaunchKernelGGL(fit, dim3(blocks(n)), dim3(kTpb), 0, stream, w, t, arrived);
+        hipLaunchKernelGGL(radix_root, dim3(1), dim3(1), 0, stream, w);
+    }
+    hipLaunchKernelGGL(root_info, dim3(1), dim3(1), 0, stream, w, t.nbox);
+    DEV_TRY(hipMemcpyAsync(&hw, w, sizeof(hw), hipMemcpyDeviceToHost, stream));
+    DEV_TRY(hipStreamSynchronize(stream));
     // collapse, level by level: the queue sizes come back to the host once per level (a 4-byte read each)
-    const QItem root = {0, 0u};
+    const QItem root = {hw.root, 0u, 0u};
     DEV_TRY(hipMemcpyAsync(queue[0], &root, sizeof(root), hipMemcpyHostToDevice, stream));
     uint32_t n_in = 1, depth = 0;
     uint32_t* d_q_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(w) + offsetof(Work, q_count));
     while (n_in != 0 && depth <= uint32_t(kMaxBvhDepth)) {
-        const int cur = int(depth & 1u);
-        DEV_TRY(hipMemsetAsync(d_q_count + (cur ^ 1), 0, sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(collapse_level, dim3(blocks(n_in)), dim3(kTpb), 0, stream, w, bin, nbox, boxes, sorted, queue[cur], n_in,
-                           queue[cur ^ 1], d_q_count + (cur ^ 1), nodes, node_cap, tri_base, depth);
-        DEV_TRY(hipMemcpyAsync(&n_in, d_q_count + (cur ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        const int curq = int(depth & 1u);
+        DEV_TRY(hipMemsetAsync(d_q_count + (curq ^ 1), 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(collapse_level, dim3(blocks(n_in)), dim3(kTpb), 0, stream, w, t, n, sorted, order, queue[curq], n_in,
+                           queue[curq ^ 1], d_q_count + (curq ^ 1), nodes, node_cap, tri_base, depth);
+        DEV_TRY(hipMemcpyAsync(&n_in, d_q_count + (curq ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         DEV_TRY(hipStreamSynchronize(stream));
         if (n_in > node_cap) n_in = node_cap;  // (overflow is flagged in w)
         ++depth;
     }
-    hipLaunchKernelGGL(emit_tris, dim3(blocks(n)), dim3(kTpb), 0, stream, m, w, sorted, d_tris_out);
+    hipLaunchKernelGGL(emit_tris, dim3(blocks(n)), dim3(kTpb), 0, stream, m, w, order, d_tris_out);
     DEV_TRY(hipMemcpyAsync(&hw, w, sizeof(hw), hipMemcpyDeviceToHost, stream));
     DEV_TRY(hipStreamSynchronize(stream));
     DEV_TRY(hipGetLastError());

@@ -28,8 +28,15 @@ def build_device(md):
     return N, T, depth.value, me.value
 
 
+@pytest.fixture(params=["ploc", "lbvh"])
+def algo(request, monkeypatch):
+    """Both constructions of the binary tree (bvh_device.hip): clustering (default) and the radix tree."""
+    monkeypatch.setenv("RBRT_BVH_DEVICE_ALGO", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("n_tris", [3, 8, 11, 12, 14, 333, 5003, 70003])
-def test_device_bvh_invariants(hip, oracle, n_tris):
+def test_device_bvh_invariants(hip, oracle, algo, n_tris):
     md = scenes.standin_mesh(oracle, n_tris, **scenes.EXAMPLE_MESH)
     r = build_device(md)
     n_indexed = sum(1 for i in range((md.n_total // 8) * 8) if not md.is_padding[i])
@@ -39,7 +46,7 @@ def test_device_bvh_invariants(hip, oracle, n_tris):
     check_invariants(md, *r)
 
 
-def test_device_bvh_adversarial_inputs(hip, oracle):
+def test_device_bvh_adversarial_inputs(hip, oracle, algo):
     """Coincident triangles (every Morton code equal: ties are broken by position), a soup with a few huge triangles,
     non-finite entries (never indexed), a flat mesh (zero extent on one axis)."""
     tri = np.float32([[0, 0, -5], [1, 0, -5], [0, 1, -5]])
@@ -65,7 +72,7 @@ def test_device_bvh_adversarial_inputs(hip, oracle):
 
 
 @pytest.mark.parametrize("n_tris", [2003, 20000])
-def test_device_built_tree_renders_the_oracle_image(hip, oracle, monkeypatch, n_tris):
+def test_device_built_tree_renders_the_oracle_image(hip, oracle, monkeypatch, algo, n_tris):
     monkeypatch.setenv("RBRT_BVH_BUILDER", "device")
     sc = scenes.example_scene(oracle, n_tris)
     cam = scenes.camera(oracle, 160, 120)
@@ -86,7 +93,7 @@ def test_device_built_tree_renders_the_oracle_image(hip, oracle, monkeypatch, n_
     assert (go == 4).sum() > 1000
 
 
-def test_device_built_config2_frame_equals_the_oracle(hip, oracle, monkeypatch):
+def test_device_built_config2_frame_equals_the_oracle(hip, oracle, monkeypatch, algo):
     """Config 2's whole frame through a GPU-built tree: the same SHA-256 as through the host-built one and the oracle."""
     import hashlib
     from pathlib import Path
