@@ -576,3 +576,48 @@ def test_short_ieee_forms_match_the_compilers(hip):
         assert counts[0] == 0 and counts[1] == 0, list(counts)
         total_fast += counts[2]
     assert total_fast == 2 * 3 * (1 << 27) // 4  # the in-range waves really ran the short forms' domain
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RBRT_FUZZ_SCENES", "10"))))
+def test_random_scenes_bit_exact(hip, oracle, seed):
+    """Randomised scenes: 0-9 spheres and 0-3 overlapping triangle soups / stand-in meshes with random materials and
+    transforms, ragged image sizes, random depth limits. Exercises mesh order, ties between meshes and spheres, the
+    per-scene triangle array with absolute leaf links, and both BVH builders (small meshes forced to the GPU builder
+    on odd seeds)."""
+    import os
+    rng = np.random.default_rng(1000 + seed)
+    kinds = [abi.MAT_LAMBERTIAN, abi.MAT_METAL, abi.MAT_DIELECTRIC]
+
+    def rand_mat():
+        k = kinds[int(rng.integers(3))]
+        return abi.material(k, tuple(rng.uniform(0.05, 0.95, 3)), float(rng.uniform(0.0, 0.6) if k == abi.MAT_METAL else rng.uniform(0.3, 2.2)))
+    spheres = [((0.0, -1000.0, -5.0), 1000.0, rand_mat())] if rng.random() < 0.7 else []
+    for _ in range(int(rng.integers(0, 9))):
+        spheres.append((tuple(rng.uniform(-6, 6, 3) + np.array([0, 2, -10])), float(rng.uniform(0.3, 2.5)), rand_mat()))
+    meshes = []
+    for _ in range(int(rng.integers(0, 4))):
+        n = int(rng.integers(1, 700))
+        if rng.random() < 0.5:
+            tri = scenes.random_soup(rng, n, extent=float(rng.uniform(0.5, 3.0)), size=float(rng.uniform(0.05, 1.0)))
+            meshes.append(oracle.mesh_prep(tri, float(rng.uniform(0.5, 2.0)), tuple(rng.uniform(-1, 1, 3)),
+                                           tuple(rng.uniform(-3, 3, 3) + np.array([0, 1.5, -9])), rand_mat()))
+        else:
+            meshes.append(scenes.standin_mesh(oracle, n + 50, float(rng.uniform(15, 60)), tuple(rng.uniform(-4, 4, 3) + np.array([0, 0, -10])),
+                                              tuple(rng.uniform(-1, 1, 3)), rand_mat()))
+    sc = abi.SceneData(spheres=spheres, meshes=meshes)
+    w, h = int(rng.integers(20, 90)), int(rng.integers(20, 70))
+    cam = scenes.camera(oracle, w, h, position=tuple(rng.uniform(-2, 2, 3) + np.array([0, 4, 4])))
+    spp, depth = int(rng.integers(1, 5)), int(rng.choice([1, 3, 50]))
+    old = os.environ.get("RBRT_BVH_BUILDER")
+    if seed % 2:
+        os.environ["RBRT_BVH_BUILDER"] = "device"
+    try:
+        exp, exp8, _ = oracle.render(cam, sc, abi.default_opts(spp=spp, seed=seed, max_depth=depth))
+        got, got8 = hip.render_scene(cam, spp, sc, seed=seed, max_depth=depth)
+    finally:
+        if old is None:
+            os.environ.pop("RBRT_BVH_BUILDER", None)
+        else:
+            os.environ["RBRT_BVH_BUILDER"] = old
+    assert_same_image(got, exp, f"random scene {seed}: {len(spheres)} spheres, {[m.n_real for m in meshes]} triangles, {w}x{h}x{spp}, depth {depth}")
+    assert np.array_equal(got8, exp8)
