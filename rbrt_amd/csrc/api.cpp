@@ -581,7 +581,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         }
         if (const char* e = std::getenv("RBRT_WORK_STRIPES")) s->work_stripes = uint32_t(std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("RBRT_WORK_STRIPES_SHORT")) s->work_stripes_short = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 7u;
+        if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 15u;
         if (const char* e = std::getenv("RBRT_XGROUP")) {
             int v = std::atoi(e);
             if (v == 0 || (v >= 2 && v <= 64)) s->xgroup = uint32_t(v);  // (lanes 1..group-1 of the collector track the donors)

@@ -756,6 +756,9 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 uint32_t new_lo = 0, new_hi = 0;
                 if (avail < n_want) {
                     more_work = work.next_chunk(P, lane, new_lo, new_hi);
+                    // drain_mode bit 3: a wave whose launch has run out of work items issues ahead of the bulk waves of
+                    // other launches on its SIMD: the drain is a chain of dependent rounds, the bulk fills the gaps
+                    if (!more_work && (P.drain_mode & 8u)) __builtin_amdgcn_s_setprio(2);
                     if (STATS && !more_work) dg_rt_workout = __builtin_amdgcn_s_memrealtime();
                 }
                 if (need_new) {
