@@ -119,7 +119,7 @@ struct rbrt_hip_scene {
     uint32_t y_low_water = 28;    // RBRT_Y_LOW
     uint32_t y_high_water = 28, y_high_min_parked = 16;  // RBRT_Y_HIGH, RBRT_Y_HIGH_PARKED
     uint32_t leaf_round = 6;      // RBRT_LEAF_ROUND
-    uint32_t leaf_tris = 32;      // RBRT_LEAF_TRIS
+    uint32_t leaf_leaves = 16;    // RBRT_LEAF_LEAVES
     uint32_t drain_mode = 1;      // RBRT_DRAIN_MODE
     uint32_t work_stripes = 16;   // RBRT_WORK_STRIPES: chunks (of 64 work items) per stripe, long launches only; 0 = contiguous shards
     int work_stripes_short = 0;   // RBRT_WORK_STRIPES_SHORT: the same for launches under 24 M samples
@@ -575,9 +575,9 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         }
         s->n_waves = uint32_t(cus * per_cu);
         s->n_cus = uint32_t(cus);
-        if (const char* e = std::getenv("RBRT_LEAF_TRIS")) {
+        if (const char* e = std::getenv("RBRT_LEAF_LEAVES")) {
             int v = std::atoi(e);
-            if (v >= 1 && v <= 256) s->leaf_tris = uint32_t(v);
+            if (v >= 1 && v <= 128) s->leaf_leaves = uint32_t(v);
         }
         if (const char* e = std::getenv("RBRT_WORK_STRIPES")) s->work_stripes = uint32_t(std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("RBRT_WORK_STRIPES_SHORT")) s->work_stripes_short = std::max(0, std::atoi(e));
@@ -728,7 +728,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.y_high_water = s->y_high_water < s->y_low_water ? s->y_low_water : s->y_high_water;
     P.y_high_min_parked = s->y_high_min_parked;
     P.leaf_round = s->leaf_round;
-    P.leaf_tris = s->leaf_tris;
+    P.leaf_leaves = s->leaf_leaves;
     P.drain_mode = s->drain_mode;
     P.work_stripes = s->work_stripes;  // (per launch: set where the launch's size is known)
     P.xgroup = s->xgroup;

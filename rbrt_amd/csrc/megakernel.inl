@@ -295,6 +295,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     uint32_t t_sp = 0;
     int32_t t_cur = kNoChild;   // node to visit next: >= 0 inner, < 0 leaf, kNoChild = none (stack ran empty)
     int32_t t_pend = kNoChild;  // a leaf reached earlier whose triangles have not been tested yet
+    int32_t t_pend2 = kNoChild;  // a second one (only ever set while t_pend is)
     // The first P.stack_entries stack slots of a lane live in LDS, deeper ones in this wave's global scratch.
     uint32_t* const gstack = P.gstack + size_t(blockIdx.x) * kStackMax * 64u + lane;
     const uint32_t n_lds_stack = P.stack_entries;
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     t_sp = 0;
                     t_cur = 0;
                     t_pend = kNoChild;
+                    t_pend2 = kNoChild;
                     t_active = 1;
                     if (STATS) ++dg_lanes[ST_TRAV];
                 }
@@ -546,46 +548,52 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     if (!more_work) ++dg_dr_steps, dg_dr_lane_steps += uint32_t(__popcll(wballot(t_active != 0u)));
                     dg_lane_steps += uint32_t(__popcll(wballot(t_active != 0u)));
                 }
-                // Leaves are deferred: a lane that reaches a leaf remembers it (one pending leaf per lane) and
-                // keeps walking; triangles are tested in LEAF ROUNDS. Testing later only delays the shrinking of
-                // t_best, it cannot change the result.
-                if (t_cur < 0 && t_cur != kNoChild && t_pend == kNoChild) {
-                    t_pend = t_cur;
+                // Leaves are deferred: a lane that reaches a leaf remembers it (up to two pending leaves per lane)
+                // and keeps walking; triangles are tested in LEAF ROUNDS. Testing later only delays the shrinking
+                // of t_best, it cannot change the result.
+                if (t_cur < 0 && t_cur != kNoChild && t_pend2 == kNoChild) {
+                    if (t_pend == kNoChild) t_pend = t_cur; else t_pend2 = t_cur;
                     t_cur = t_sp != 0 ? pop() : kNoChild;
                 }
                 const bool can_walk = t_cur >= 0;
                 const uint64_t walk_mask = wballot(t_cur >= 0), active_mask = wballot(t_active != 0u);
-                // A lane is stalled when it holds a pending leaf and has reached another one (or the end of its
-                // walk). A leaf round runs when the pending leaves hold a full wave of triangles, when enough
-                // lanes are stalled, or when nobody can walk.
+                // A lane is stalled when both its pending places are taken and it has reached another leaf, or when
+                // its walk has ended with leaves pending. A leaf round runs when enough leaves are pending to fill
+                // the wave with triangles, when enough lanes are stalled, or when nobody can walk.
                 const bool pend = t_pend != kNoChild;
-                const uint32_t pleaf = pend ? uint32_t(~t_pend) : 0u;  // (first << kLeafBits) | (count - 1)
-                const uint64_t mp = wballot(t_pend != kNoChild);
-                uint64_t mb[kLeafBits];  // per bit of (count - 1): the lanes that have it set
-                uint32_t n_pend_tris = uint32_t(__popcll(mp));
-#pragma unroll
-                for (int b = 0; b < kLeafBits; ++b) {
-                    mb[b] = wballot(((pleaf >> b) & 1u) != 0u);  // (pleaf is 0 in lanes without a pending leaf)
-                    n_pend_tris += uint32_t(__popcll(mb[b])) << b;
-                }
+                const uint64_t mp = wballot(t_pend != kNoChild), mp2 = wballot(t_pend2 != kNoChild);
+                const uint32_t n_pend_leaves = uint32_t(__popcll(mp)) + uint32_t(__popcll(mp2));
                 const uint32_t n_stalled = uint32_t(__popcll(active_mask & ~walk_mask));
                 if (STATS && walk_mask != 0ull) {
                     ++dg_walk_rounds;
                     dg_walk_lanes += uint32_t(__popcll(walk_mask));
                 }
-                if (n_pend_tris >= P.leaf_tris || (n_pend_tris != 0 && (n_stalled >= P.leaf_round || walk_mask == 0ull))) {
+                if (n_pend_leaves >= P.leaf_leaves || (n_pend_leaves != 0 && (n_stalled >= P.leaf_round || walk_mask == 0ull))) {
         RBRT_MARK("leaf_round");
                     // ---- leaf round: the pending triangles are dealt out to ALL lanes, one triangle each ----
                     // (a leaf holds 1..4 triangles and only some lanes hold a leaf: testing them where they are
-                    // pending ran at a third of the lanes.) Position p of the concatenated triangle list belongs to
-                    // the owner lane whose [prefix, prefix + count) contains it; lane j of a chunk tests position
-                    // B + j for its owner's ray (fetched with ds_bpermute) and merges the result into the owner's
-                    // cell with one LDS 64-bit atomic min on (t bits, reference index): t > eps > 0, so the integer
-                    // order of the key IS the lexicographic (t, index) order of triangle.rs:400's strict `<` scan.
-                    uint32_t prefix = lane_rank(mp);
+                    // pending ran at a third of the lanes.) The list is every lane's first pending leaf, then every
+                    // lane's second. Position p of the concatenated triangle list belongs to the owner lane whose
+                    // [prefix, prefix + count) contains it; lane j of a chunk tests position B + j for its owner's
+                    // ray (fetched with ds_bpermute) and merges the result into the owner's cell with one LDS
+                    // 64-bit atomic min on (t bits, reference index): t > eps > 0, so the integer order of the key
+                    // IS the lexicographic (t, index) order of triangle.rs:400's strict `<` scan.
+                    const uint32_t pleaf = pend ? uint32_t(~t_pend) : 0u;
+                    const uint32_t pleaf2 = t_pend2 != kNoChild ? uint32_t(~t_pend2) : 0u;
+                    uint32_t prefix = lane_rank(mp), total1 = uint32_t(__popcll(mp));
+                    uint32_t prefix2 = lane_rank(mp2), total2 = uint32_t(__popcll(mp2));
 #pragma unroll
-                    for (int b = 0; b < kLeafBits; ++b) prefix += lane_rank(mb[b]) << b;
+                    for (int b = 0; b < kLeafBits; ++b) {
+                        const uint64_t m1 = wballot(((pleaf >> b) & 1u) != 0u), m2 = wballot(((pleaf2 >> b) & 1u) != 0u);
+                        prefix += lane_rank(m1) << b;
+                        total1 += uint32_t(__popcll(m1)) << b;
+                        prefix2 += lane_rank(m2) << b;
+                        total2 += uint32_t(__popcll(m2)) << b;
+                    }
+                    prefix2 += total1;
+                    const uint32_t n_pend_tris = total1 + total2;
                     const uint32_t n_mine = pend ? (pleaf & uint32_t(kLeafMax - 1)) + 1u : 0u, first = pleaf >> kLeafBits;
+                    const uint32_t n_mine2 = t_pend2 != kNoChild ? (pleaf2 & uint32_t(kLeafMax - 1)) + 1u : 0u, first2 = pleaf2 >> kLeafBits;
                     if (STATS) {
                         ++dg_leaf_rounds;
                         dg_leaf_lanes += n_pend_tris;
@@ -594,8 +602,9 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     for (uint32_t B = 0; B < n_pend_tris; B += 64u) {
 #pragma unroll
                         for (uint32_t i = 0; i < uint32_t(kLeafMax); ++i) {
-                            const uint32_t pos = prefix + i - B;
+                            const uint32_t pos = prefix + i - B, pos2 = prefix2 + i - B;
                             if (i < n_mine && pos < 64u) tq[pos] = ((first + i) << 6) | lane;
+                            if (i < n_mine2 && pos2 < 64u) tq[pos2] = ((first2 + i) << 6) | lane;
                         }
                         __syncthreads();
                         const bool valid = B + lane < n_pend_tris;
@@ -623,6 +632,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                             t_best_idx = uint32_t(k);
                         }
                         t_pend = kNoChild;
+                        t_pend2 = kNoChild;
                     }
                 }
         RBRT_MARK("walk");
