@@ -16,7 +16,7 @@
 #include "device_types.h"
 
 namespace rbrt {
-hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats,
+hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats, bool share,
                                    hipStream_t stream);
 size_t megakernel_gseq_bytes(uint32_t n_waves);
 size_t megakernel_gstack_bytes(uint32_t n_waves);
@@ -114,12 +114,14 @@ struct rbrt_hip_scene {
     std::vector<Bound> h_bounds;
     uint32_t stack_need = 1;  // deepest BVH: 3 per level + 1
     uint32_t n_waves = 0;  // persistent megakernel grid: as many single-wave workgroups as fit the LDS
-    uint32_t pool = 128;          // path slots per wave (RBRT_POOL = 128 | 192 | 256)
+    uint32_t pool = 128;          // path slots per wave (RBRT_POOL = 128 | 256)
     uint32_t stack_entries = kLdsStack;  // per-lane stack entries kept in LDS (RBRT_LDS_STACK)
     uint32_t y_low_water = 28;    // RBRT_Y_LOW
     uint32_t y_high_water = 28, y_high_min_parked = 16;  // RBRT_Y_HIGH, RBRT_Y_HIGH_PARKED
     uint32_t leaf_round = 6;      // RBRT_LEAF_ROUND
     uint32_t leaf_leaves = 16;    // RBRT_LEAF_LEAVES
+    uint32_t share_idle = 4;      // RBRT_SHARE_IDLE (0: no shared traversals)
+    uint64_t share_below = ~0ull;  // RBRT_SHARE_BELOW: launches under this many samples use the sharing build (all)
     uint32_t drain_mode = 1;      // RBRT_DRAIN_MODE
     uint32_t work_stripes = 16;   // RBRT_WORK_STRIPES: chunks (of 64 work items) per stripe, long launches only; 0 = contiguous shards
     int work_stripes_short = 0;   // RBRT_WORK_STRIPES_SHORT: the same for launches under 24 M samples
@@ -542,7 +544,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("RBRT_POOL")) {
             int v = std::atoi(e);
-            if (v == 96 || v == 128 || v == 160 || v == 192 || v == 256) s->pool = uint32_t(v);
+            if (v == 128 || v == 256) s->pool = uint32_t(v);
         }
         if (const char* e = std::getenv("RBRT_LDS_STACK")) {
             int v = std::atoi(e);
@@ -579,6 +581,11 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             int v = std::atoi(e);
             if (v >= 1 && v <= 128) s->leaf_leaves = uint32_t(v);
         }
+        if (const char* e = std::getenv("RBRT_SHARE_IDLE")) {
+            int v = std::atoi(e);
+            if (v >= 0 && v <= 64) s->share_idle = uint32_t(v);
+        }
+        if (const char* e = std::getenv("RBRT_SHARE_BELOW")) s->share_below = std::strtoull(e, nullptr, 10);
         if (const char* e = std::getenv("RBRT_WORK_STRIPES")) s->work_stripes = uint32_t(std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("RBRT_WORK_STRIPES_SHORT")) s->work_stripes_short = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 15u;
@@ -729,6 +736,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.y_high_min_parked = s->y_high_min_parked;
     P.leaf_round = s->leaf_round;
     P.leaf_leaves = s->leaf_leaves;
+    P.share_idle = s->share_idle;
     P.drain_mode = s->drain_mode;
     P.work_stripes = s->work_stripes;  // (per launch: set where the launch's size is known)
     P.xgroup = s->xgroup;
@@ -795,7 +803,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
-        HIP_TRY(launch_trace_megakernel(P, stats ? s->n_waves : grid_for(s, P.n_items, depth), s->pool, stats, ts));
+        HIP_TRY(launch_trace_megakernel(P, stats ? s->n_waves : grid_for(s, P.n_items, depth), s->pool, stats,
+                                        s->share_idle != 0u && P.n_items < s->share_below, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
         if (piped) {
             HIP_TRY(hipEventRecord(L.ev_traced, ts));

@@ -125,6 +125,7 @@ struct TraceParams {
     uint32_t y_low_water;              // refill a traversal pass when fewer lanes than this are busy
     uint32_t y_high_water, y_high_min_parked;  // ... or fewer than y_high_water while at least that many rays are parked
     uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one ...
+    uint32_t share_idle;               // shared traversals: idle lanes needed for a round of giving (0: never)
     uint32_t leaf_leaves;              // ... or once this many leaves are pending (a leaf round deals their triangles out to all lanes)
     uint32_t xgroup;                   // drain hand-over: workgroups per group (0 = off), the first of each is the collector
     uint32_t xthreshold;               // ... a donor hands its paths over once it holds at most this many

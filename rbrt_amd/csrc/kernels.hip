@@ -749,34 +749,31 @@ size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_sp
     const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw + kGenDw +
                          (RBRT_ROOT_LDS ? 32u + 3u : 0u);  // experiment: mesh 0's root node, 16-byte aligned
     const size_t pool_pad = (size_t(pool) + 63u) & ~size_t(63);  // status + list: one byte per (padded) slot each
-    return (size_t(kFields) * pool + kCellDw + kTqDw + pool_pad / 2u + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
+    return (size_t(kFields) * pool + kCellDw + kTqDw + kHelpDw + pool_pad / 2u + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
 }
 
 // n_waves single-wave workgroups; each loops until the global work counter (zeroed by the caller on
 // this stream) runs out, so any grid size is correct and no wave ever waits on another.
-hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats,
+hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats, bool share,
                                    hipStream_t stream) {
     if (P.n_items == 0 || n_waves == 0) return hipSuccess;
     const size_t lds = megakernel_lds_bytes(pool, P.stack_entries, P.n_spheres, P.n_meshes);
-#define RBRT_LAUNCH_MK(POOLN)                                                                              \
-    do {                                                                                                   \
-        if (stats)                                                                                         \
-            hipLaunchKernelGGL((trace_megakernel<POOLN, true>), dim3(n_waves), dim3(64), lds, stream, P);  \
-        else                                                                                               \
-            hipLaunchKernelGGL((trace_megakernel<POOLN, false>), dim3(n_waves), dim3(64), lds, stream, P); \
+#define RBRT_LAUNCH_MK(POOLN, STATS, SHARE) \
+    hipLaunchKernelGGL((trace_megakernel<POOLN, STATS, SHARE>), dim3(n_waves), dim3(64), lds, stream, P)
+#define RBRT_LAUNCH_POOL(POOLN)                            \
+    do {                                                   \
+        if (stats && share) RBRT_LAUNCH_MK(POOLN, true, true);    \
+        else if (stats) RBRT_LAUNCH_MK(POOLN, true, false);       \
+        else if (share) RBRT_LAUNCH_MK(POOLN, false, true);       \
+        else RBRT_LAUNCH_MK(POOLN, false, false);                 \
     } while (0)
-    if (pool == 96)
-        RBRT_LAUNCH_MK(96);
-    else if (pool == 128)
-        RBRT_LAUNCH_MK(128);
-    else if (pool == 160)
-        RBRT_LAUNCH_MK(160);
-    else if (pool == 192)
-        RBRT_LAUNCH_MK(192);
+    if (pool == 128)
+        RBRT_LAUNCH_POOL(128);
     else if (pool == 256)
-        RBRT_LAUNCH_MK(256);
+        RBRT_LAUNCH_POOL(256);
     else
         return hipErrorInvalidValue;
+#undef RBRT_LAUNCH_POOL
 #undef RBRT_LAUNCH_MK
     return hipGetLastError();
 }

@@ -46,6 +46,8 @@
 enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_S0, F_S1, F_ITEM, F_META, F_T, F_TRI, F_WORD, kFields };
 constexpr uint32_t kXRecDw = 32u;  // one handed-over path: kFields pool dwords, status, kSeqWords record words (128 B)
 constexpr uint32_t kCellDw = 128u, kTqDw = 64u;  // LDS behind the pool: 64 x u64 result cells, 64 x u32 triangle-test queue
+constexpr uint32_t kHelpDw = 16u;                  // ... and 64 x u8 counts of helper lanes per owner lane (shared traversals)
+constexpr unsigned long long kNoHitKey = (unsigned long long)0x49742400u << 32;  // (t = 1000000.0f, index 0): triangle.rs:398
 enum : uint32_t { ST_EMPTY = 0u, ST_TRAV = 1u, ST_TERM = 2u, ST_LAMB = 3u, ST_METAL = 4u, ST_DIEL = 5u, kNumStatus = 6u,
                   ST_BUSY = 6u /* being traversed by a lane right now */ };
 constexpr int kSeqWords = kMaxPathDepth / 4;
@@ -177,26 +179,32 @@ struct WorkSource {
     }
 };
 
-template <int POOLN, bool STATS>
+// SHAREK: the build of the kernel that can share traversals between lanes in the drain (below). It is a separate
+// build because the second copy of the traversal loop costs the first one 3 % (register allocation at the
+// 128-VGPR limit): launches that are mostly bulk use the build without it.
+template <int POOLN, bool STATS, bool SHAREK>
 __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(const TraceParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t kPoolPad = (uint32_t(POOLN) + 63u) & ~63u;  // census loops run in groups of 64 slots
     uint32_t* const pool = lds;
     static_assert((kFields * POOLN) % 2 == 0, "the u64 cells must be 8-byte aligned");
-    // Leaf rounds (below): cell[l] collects the best (t, triangle index) found for lane l's ray by whichever lanes
-    // tested its triangles; tq is the queue of (triangle, owner lane) pairs of the chunk being tested.
+    // Leaf rounds (below): cell[l] is the best (t, triangle index) found so far for the ray that lane l OWNS, merged
+    // by whichever lanes tested its triangles; tq is the queue of (triangle, holder lane) pairs of the chunk being
+    // tested; helpers[l] counts the lanes that are walking a part of lane l's tree for it (shared traversals).
     unsigned long long* const cell = reinterpret_cast<unsigned long long*>(pool + kFields * POOLN);  // [64]
     uint32_t* const tq = pool + kFields * POOLN + kCellDw;                                            // [64]
-    uint8_t* const status = reinterpret_cast<uint8_t*>(tq + kTqDw);              // [kPoolPad] one byte per slot
+    uint32_t* const helpers = tq + kTqDw;                                         // [64] bytes, four to a word
+    uint8_t* const status = reinterpret_cast<uint8_t*>(helpers + kHelpDw);       // [kPoolPad] one byte per slot
     uint8_t* const list = status + kPoolPad;                                     // [kPoolPad] slot ids (< 256)
     const uint32_t lane = threadIdx.x;
-    uint32_t* const stack_base = tq + kTqDw + kPoolPad / 2u;                     // 2 * kPoolPad bytes of byte arrays
+    uint32_t* const stack_base = helpers + kHelpDw + kPoolPad / 2u;                     // 2 * kPoolPad bytes of byte arrays
     uint32_t* const stack = stack_base + lane;
     uint32_t* const gseq = P.gseq + size_t(blockIdx.x) * kPoolMax * kSeqWords;
 #define POOL(f, s) pool[(f) * POOLN + (s)]
 
     for (uint32_t s = lane; s < kPoolPad; s += 64) status[s] = s < uint32_t(POOLN) ? ST_EMPTY : ST_BUSY;  // pad slots never match
-    cell[lane] = ~0ull;
+    cell[lane] = kNoHitKey;
+    if (lane < kHelpDw) helpers[lane] = 0u;
     // scene tables behind the stacks
     const uint32_t n_obj = P.n_spheres + P.n_meshes;
     uint32_t* const sc_base = stack_base + P.stack_entries * 64u;
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     uint32_t dg_steps = 0, dg_lane_steps = 0, dg_refills = 0, dg_census = 0;
     uint32_t dg_dr_rounds = 0, dg_dr_steps = 0, dg_dr_passes = 0, dg_dr_lane_steps = 0;  // after the work ran out
     unsigned long long dg_t_trav = 0, dg_t_shade = 0, dg_t0 = 0, dg_tk = 0;
+    uint32_t dg_share_rounds = 0, dg_share_given = 0;
     uint32_t dg_leaf_rounds = 0, dg_leaf_lanes = 0, dg_walk_rounds = 0, dg_walk_lanes = 0, dg_shade_rounds = 0;
     unsigned long long dg_rt0 = 0, dg_rt_workout = 0;
     if (STATS) {
@@ -286,11 +295,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     // Invariant: a lane that is not traversing has t_cur == t_pend == kNoChild.)
     uint32_t t_active = 0;      // 1: this lane is in the middle of a traversal
     uint32_t t_has_result = 0;  // 1: this lane finished a traversal that is not finalised yet
-    uint32_t t_slot = 0;
+    // slot [0,8) | mesh [8,16) | owner lane [16,22) | stack entries given away [22,32): the lane whose ray this
+    // lane is walking is itself unless it is a HELPER (shared traversals, below); none of these is read per step
+    uint32_t t_ids = lane << 16;
     V3 t_o = mk(0.0f, 0.0f, 0.0f), t_d = t_o;
     RayCull t_rc = {t_o, t_o, 0u, 16u, 32u, 0.0f, 0.0f};
     float t_best = 0.0f;
-    uint32_t t_best_idx = 0, t_mesh = 0;
+    uint32_t t_best_idx = 0;
     const BvhNode4* t_nodes = nullptr;
     uint32_t t_sp = 0;
     int32_t t_cur = kNoChild;   // node to visit next: >= 0 inner, < 0 leaf, kNoChild = none (stack ran empty)
@@ -310,18 +321,22 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             gstack[(t_sp - n_lds_stack) * 64u] = uint32_t(v);
         ++t_sp;
     };
-    auto pop = [&]() -> int32_t {
-        --t_sp;
-        if (__builtin_expect(t_sp < n_lds_stack, 1)) return int32_t(stack_lds[t_sp * 64u]);
-        return int32_t(gstack[(t_sp - n_lds_stack) * 64u]);
+    auto stack_at = [&](uint32_t i) -> int32_t {
+        if (__builtin_expect(i < n_lds_stack, 1)) return int32_t(stack_lds[i * 64u]);
+        return int32_t(gstack[(i - n_lds_stack) * 64u]);
     };
+    auto pop = [&]() -> int32_t { return stack_at(--t_sp); };
+    auto id_slot = [&]() { return t_ids & 255u; };
+    auto id_mesh = [&]() { return (t_ids >> 8) & 255u; };
+    auto id_owner = [&]() { return (t_ids >> 16) & 63u; };
+    auto id_given = [&]() { return t_ids >> 22; };
 
     for (;;) {
         RBRT_MARK("finalise");
         // ---- finalise finished traversals in a batch (mesh.rs:245-266, scene.rs:33-41) ----
         if (wany(t_has_result != 0u)) {
             if (t_has_result) {
-                const uint32_t slot = t_slot;
+                const uint32_t slot = id_slot(), t_mesh = id_mesh();
                 const uint32_t meta = POOL(F_META, slot);
                 int32_t obj = int32_t((meta >> 14) & 255u) - 1;
                 float closest = 3.40282347e+38f;  // f32::MAX (scene.rs:21)
@@ -479,13 +494,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 const uint32_t k = lane_rank(idle);
                 if (k < ny) {
                     const uint32_t slot = list[k];
-                    t_slot = slot;
                     status[slot] = ST_BUSY;
                     t_o = mk(__uint_as_float(POOL(F_OX, slot)), __uint_as_float(POOL(F_OY, slot)),
                              __uint_as_float(POOL(F_OZ, slot)));
                     t_d = mk(__uint_as_float(POOL(F_DX, slot)), __uint_as_float(POOL(F_DY, slot)),
                              __uint_as_float(POOL(F_DZ, slot)));
-                    t_mesh = (POOL(F_META, slot) >> 22) & 255u;
+                    const uint32_t t_mesh = (POOL(F_META, slot) >> 22) & 255u;
+                    t_ids = slot | (t_mesh << 8) | (lane << 16);
                     const uint32_t* md = sc.mesh + t_mesh * kMeshDw;
                     t_nodes = lds_ptr<BvhNode4>(md + MD_NODES);
                     t_rc = make_cull(t_o, t_d, reinterpret_cast<const float*>(md) + MD_CENTER,
@@ -493,6 +508,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     t_best = 1000000.0f;  // triangle.rs:398
                     t_best_idx = 0;
                     t_sp = 0;
+                    cell[lane] = kNoHitKey;
                     t_cur = 0;
                     t_pend = kNoChild;
                     t_pend2 = kNoChild;
@@ -541,12 +557,70 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             const uint32_t keep = ((drain && (P.drain_mode & 1u)) || x_donating) ? 1u
                                   : (best != 0 || cnt[ST_TRAV] != 0) ? (n_active < y_keep ? n_active : y_keep)
                                                                      : n_active;
+            // (traversals are shared in the drain only: before it, a parked ray uses an idle lane better, and the
+            // per-step bookkeeping of sharing costs more than the lanes it fills)
+            const bool share = SHAREK && P.share_idle != 0u && drain;
+            // (two copies of the loop: the bulk of a frame runs the one without any of the sharing code)
+            auto burst = [&](auto share_tag) {
+            constexpr bool SHARE = decltype(share_tag)::value;
         RBRT_MARK("burst_top");
             do {
                 if (STATS) {
                     ++dg_steps;
                     if (!more_work) ++dg_dr_steps, dg_dr_lane_steps += uint32_t(__popcll(wballot(t_active != 0u)));
                     dg_lane_steps += uint32_t(__popcll(wballot(t_active != 0u)));
+                }
+                if (SHARE) {
+                    // ---- shared traversal: idle lanes take over stack entries of busy ones ----
+                    // A lane with entries on its stack gives the OLDEST one (the subtree nearest the root) to an idle
+                    // lane, which walks it for the same ray as a helper: same origin, direction and slot, its own
+                    // stack, results merged into the owner's cell by the leaf rounds, where every lane of the ray
+                    // also picks up the shrunken t_best. The BVH only culls and the cell keeps the lexicographic
+                    // (t, index) minimum, so who walks which subtree in which order cannot change the result. The
+                    // owner finishes when its own walk has ended and its helpers have.
+                    const uint64_t busy = wballot((t_active | t_has_result) != 0u);
+                    const uint64_t givers = wballot(t_active != 0u && t_sp > id_given());
+                    const uint32_t n_idle = 64u - uint32_t(__popcll(busy));
+                    if (n_idle >= P.share_idle && givers != 0ull) {
+                        const uint32_t n_givers = uint32_t(__popcll(givers)), n_pairs = n_idle < n_givers ? n_idle : n_givers;
+                        int32_t give = kNoChild;
+                        if (t_active != 0u && t_sp > id_given() && lane_rank(givers) < n_pairs) {
+                            // (the entry is replaced by "none": when the giver pops it, everything below has been
+                            // given away too, and its walk ends as if the stack had run empty)
+                            const uint32_t at = id_given();
+                            give = stack_at(at);
+                            if (at < n_lds_stack) stack_lds[at * 64u] = uint32_t(kNoChild);
+                            else gstack[(at - n_lds_stack) * 64u] = uint32_t(kNoChild);
+                            t_ids += 1u << 22;
+                            tq[lane_rank(givers)] = lane;
+                            atomicAdd(&helpers[id_owner() >> 2], 1u << ((id_owner() & 3u) * 8u));
+                        }
+                        __syncthreads();
+                        const uint32_t ir = lane_rank(~busy);
+                        const bool take = (t_active | t_has_result) == 0u && ir < n_pairs;
+                        const int sb = int((take ? tq[ir] : lane) << 2);
+                        const V3 so = mk(lane_get(t_o.x, sb), lane_get(t_o.y, sb), lane_get(t_o.z, sb));
+                        const V3 sd = mk(lane_get(t_d.x, sb), lane_get(t_d.y, sb), lane_get(t_d.z, sb));
+                        const int s_give = __builtin_amdgcn_ds_bpermute(sb, give);
+                        const uint32_t s_ids = uint32_t(__builtin_amdgcn_ds_bpermute(sb, int(t_ids)));
+                        if (take) {
+                            t_o = so, t_d = sd;
+                            t_ids = s_ids & 0x3FFFFFu;  // the giver's slot, mesh and owner; nothing given away yet
+                            const uint32_t* md = sc.mesh + id_mesh() * kMeshDw;
+                            t_nodes = lds_ptr<BvhNode4>(md + MD_NODES);
+                            t_rc = make_cull(t_o, t_d, reinterpret_cast<const float*>(md) + MD_CENTER,
+                                             __uint_as_float(md[MD_RADIUS]), P.eps_frac);
+                            const unsigned long long k = cell[id_owner()];
+                            t_best = __uint_as_float(uint32_t(k >> 32));
+                            t_best_idx = uint32_t(k);
+                            t_sp = 0;
+                            t_cur = s_give;
+                            t_pend = t_pend2 = kNoChild;
+                            t_active = 1;
+                        }
+                        __syncthreads();
+                        if (STATS) ++dg_share_rounds, dg_share_given += n_pairs;
+                    }
                 }
                 // Leaves are deferred: a lane that reaches a leaf remembers it (up to two pending leaves per lane)
                 // and keeps walking; triangles are tested in LEAF ROUNDS. Testing later only delays the shrinking
@@ -609,10 +683,10 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         __syncthreads();
                         const bool valid = B + lane < n_pend_tris;
                         const uint32_t e = valid ? tq[lane] : lane;
-                        const uint32_t owner = e & 63u;
-                        const int ob = int(owner << 2);  // ds_bpermute takes a byte index
+                        const int ob = int((e & 63u) << 2);  // the lane that holds the leaf; ds_bpermute takes a byte index
                         const V3 ro = mk(lane_get(t_o.x, ob), lane_get(t_o.y, ob), lane_get(t_o.z, ob));
                         const V3 rd = mk(lane_get(t_d.x, ob), lane_get(t_d.y, ob), lane_get(t_d.z, ob));
+                        const uint32_t ray_owner = SHARE ? (uint32_t(__builtin_amdgcn_ds_bpermute(ob, int(t_ids))) >> 16) & 63u : e & 63u;
                         const auto* tp = RBRT_AS1(f32x4, P.tris + (valid ? e >> 6 : 0u));
                         const f32x4 ta = tp[0], tb = tp[1];
                         const f32x2 tc = *RBRT_AS1(f32x2, tp + 2);  // the record's last 8 bytes are padding: not fetched
@@ -621,16 +695,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                                                   P.eps_frac, tt);
                         if (STATS && valid) ++lc.tris;
                         if (valid && hit)
-                            atomicMin(&cell[owner], ((unsigned long long)__float_as_uint(tt) << 32) | __float_as_uint(tc.y));
+                            atomicMin(&cell[ray_owner], ((unsigned long long)__float_as_uint(tt) << 32) | __float_as_uint(tc.y));
                         __syncthreads();
                     }
-                    if (pend) {
-                        const unsigned long long k = cell[lane];
-                        cell[lane] = ~0ull;
-                        if (k < (((unsigned long long)__float_as_uint(t_best) << 32) | t_best_idx)) {
-                            t_best = __uint_as_float(uint32_t(k >> 32));
-                            t_best_idx = uint32_t(k);
-                        }
+                    if (pend) {  // (the cell only ever shrinks, and holds everything this lane found before)
+                        const unsigned long long k = cell[SHARE ? id_owner() : lane];
+                        t_best = __uint_as_float(uint32_t(k >> 32));
+                        t_best_idx = uint32_t(k);
                         t_pend = kNoChild;
                         t_pend2 = kNoChild;
                     }
@@ -639,7 +710,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 if (can_walk) {
                     uint32_t k[4];
                     f32x4 links;
-                    node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links, lds_root, t_cur == 0 && t_mesh == 0u);
+                    node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links, lds_root, t_cur == 0 && id_mesh() == 0u);
                     if (STATS) ++lc.nodes;
 #if RBRT_PUSH_ORDER == 0
                     if (k[0] != kMissKey) {  // farthest first, so that the nearest is popped first
@@ -666,11 +737,28 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 #endif
                 }
                 if (t_active && t_cur == kNoChild && t_pend == kNoChild) {
-                    t_active = 0;
-                    t_has_result = 1;
+                    if (!SHARE) {  // (no helpers exist outside shared bursts: the registers hold the result)
+                        t_active = 0;
+                        t_has_result = 1;
+                    } else if (id_owner() != lane) {  // a helper: what it found is in the owner's cell already
+                        atomicSub(&helpers[id_owner() >> 2], 1u << ((id_owner() & 3u) * 8u));
+                        t_ids = lane << 16;
+                        t_active = 0;
+                    } else if (((helpers[lane >> 2] >> ((lane & 3u) * 8u)) & 255u) == 0u) {  // (else: wait for the helpers)
+                        const unsigned long long k = cell[lane];  // with what the helpers found
+                        t_best = __uint_as_float(uint32_t(k >> 32));
+                        t_best_idx = uint32_t(k);
+                        t_active = 0;
+                        t_has_result = 1;
+                    }
                 }
         RBRT_MARK("burst_end");
             } while (uint32_t(__popcll(wballot(t_active != 0u))) >= keep);
+            };
+            if (share)
+                burst(std::true_type{});
+            else
+                burst(std::false_type{});
             if (STATS) dg_t_trav += __builtin_amdgcn_s_memtime() - dg_tk;
             continue;
         }
@@ -990,6 +1078,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             atomicAdd(&P.counters->diag[16], dg_t_trav);
             atomicAdd(&P.counters->diag[17], dg_t_shade);
             atomicAdd(&P.counters->diag[18], (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
+            atomicAdd(&P.counters->diag[59], (unsigned long long)dg_share_given);
+            atomicAdd(&P.counters->diag[60], (unsigned long long)dg_share_rounds);
             atomicAdd(&P.counters->diag[19], (unsigned long long)dg_leaf_rounds);
             atomicAdd(&P.counters->diag[20], (unsigned long long)dg_leaf_lanes);
             atomicAdd(&P.counters->diag[29], (unsigned long long)dg_shade_rounds);

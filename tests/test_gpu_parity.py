@@ -221,6 +221,32 @@ def test_pipelined_launches_match_unpipelined(hip, oracle, monkeypatch, depth):
         assert_same_image(imgs[1].cpu().numpy(), exp[4], "frame after the counting frame")
 
 
+@pytest.mark.parametrize("env", [{"RBRT_SHARE_IDLE": "0"}, {"RBRT_SHARE_IDLE": "1"}, {"RBRT_SHARE_IDLE": "48"},
+                                 {"RBRT_SHARE_IDLE": "1", "RBRT_LDS_STACK": "1"}, {"RBRT_SHARE_BELOW": "0"}])
+def test_shared_traversals_do_not_change_the_image(hip, oracle, monkeypatch, env):
+    """In the drain idle lanes take over stack entries of busy ones (megakernel.inl, "shared traversal"): whoever
+    walks which subtree, the image is the oracle's. Covers the build without sharing (RBRT_SHARE_BELOW=0), sharing
+    switched off and at its most eager, and given-away entries that live in the global overflow of the stack."""
+    import torch
+    cam = scenes.camera(oracle, 96, 64)
+    sc = scenes.example_scene(oracle, 3000)
+    exp, _, _ = oracle.render(cam, sc, abi.default_opts(spp=3, seed=9))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = torch.empty((64, 96, 3), dtype=torch.float32, device="cuda")
+    with hip.HipScene(sc) as hs:
+        hs.render_device(cam, abi.default_opts(spp=3, seed=9), out.data_ptr())
+        torch.cuda.synchronize()
+        assert_same_image(out.cpu().numpy(), exp, f"{env}")
+        hs.render_device(cam, abi.default_opts(spp=3, seed=9, flags=abi.FLAG_COLLECT_STATS), out.data_ptr())
+        torch.cuda.synchronize()
+        assert_same_image(out.cpu().numpy(), exp, f"{env} (counting build)")
+        given = hs.debug_counters()["shared_entries_given"]
+        hs.check()
+    sharing = env.get("RBRT_SHARE_IDLE") != "0" and "RBRT_SHARE_BELOW" not in env
+    assert (given > 0) == sharing, (env, given)
+
+
 def test_stats_counters(hip, oracle):
     import torch
     cam = scenes.camera(oracle, 64, 48)

@@ -13,11 +13,11 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLE
 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS \
     --output-format csv -d "$OUT/tcp" -- $B > "$OUT/b2.json" 2> "$OUT/b2.err" || tail -3 "$OUT/b2.err"
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, re
 per = collections.defaultdict(float); nd = collections.defaultdict(set)
 for f in glob.glob(sys.argv[1] + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "trace_megakernel" in r["Kernel_Name"] and "false" in r["Kernel_Name"]:
+        if "trace_megakernel" in r["Kernel_Name"] and re.search(r"<\d+, false", r["Kernel_Name"]):
             per[r["Counter_Name"]] += float(r["Counter_Value"]); nd[r["Counter_Name"]].add(r["Dispatch_Id"])
 for k in sorted(per): print(f"{k:32s} {per[k] / max(1, len(nd[k])):.4g}")
 if "SQ_ACTIVE_INST_VALU" in per: print("valu_lane_utilisation", per["SQ_THREAD_CYCLES_VALU"] / (64 * per["SQ_ACTIVE_INST_VALU"]))

@@ -18,7 +18,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ff
        *flags, "-S", "--cuda-device-only", "-o", "/tmp/static_cost.s", str(ROOT / "rbrt_amd/csrc/kernels.hip")]
 subprocess.run(cmd, check=True, capture_output=True, cwd="/tmp")
 text = Path("/tmp/static_cost.s").read_text().splitlines()
-start = next(i for i, l in enumerate(text) if l.startswith("_ZN4rbrt16trace_megakernelILi128ELb0EEEvNS_11TraceParamsE:"))
+start = next(i for i, l in enumerate(text) if l.startswith("_ZN4rbrt16trace_megakernelILi128ELb0ELb0EEEvNS_11TraceParamsE:"))
 end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
 cur = "prologue"
 order, cnt = [], collections.defaultdict(lambda: collections.Counter())

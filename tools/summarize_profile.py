@@ -10,6 +10,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import shutil
 import sys
 from pathlib import Path
@@ -37,7 +38,7 @@ meta = {}
 for f in glob.glob(str(SRC / "*" / "*" / "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "trace_megakernel" not in k or "false" not in k:
+        if "trace_megakernel" not in k or not re.search(r"<\d+, false", k):  # (the build without counters)
             continue
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
         ndisp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
