@@ -28,7 +28,6 @@ hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, 
                              int32_t* out_tri, float* out_dist, hipStream_t stream);
 hipError_t launch_gate_selftest(const float* d_box, const float* d_rays, size_t n, uint8_t* d_fast, uint8_t* d_exact);
 hipError_t launch_ieee_selftest(uint64_t seed, size_t n, unsigned long long* d_counts);
-bool megakernel_has_handover();
 uint64_t host_splitmix64(uint64_t x);
 }  // namespace rbrt
 
@@ -93,8 +92,6 @@ struct rbrt_hip_scene {
         unsigned long long* d_work_counter = nullptr;
         uint32_t* d_gseq = nullptr;
         uint32_t* d_gstack = nullptr;
-        uint32_t* d_xready = nullptr;  // drain hand-over: per-wave published counts (zero between launches)
-        uint32_t* d_xrec = nullptr;    // ... and the path records
         hipEvent_t ev_traced = nullptr, ev_resolved = nullptr;
         bool in_use = false;  // ev_resolved has been recorded at least once
     };
@@ -125,8 +122,6 @@ struct rbrt_hip_scene {
     uint32_t drain_mode = 1;      // RBRT_DRAIN_MODE
     uint32_t work_stripes = 16;   // RBRT_WORK_STRIPES: chunks (of 64 work items) per stripe, long launches only; 0 = contiguous shards
     int work_stripes_short = 0;   // RBRT_WORK_STRIPES_SHORT: the same for launches under 24 M samples
-    uint32_t xgroup = 0;          // RBRT_XGROUP: drain hand-over group size (0 = off; builds with -DRBRT_HANDOVER=1 only)
-    uint32_t xthreshold = 256;    // RBRT_XTHRESH: a donor hands over once it holds at most this many paths
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
     // stats / timing
@@ -242,15 +237,6 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
         s->allocs.push_back(p);
         L.d_gstack = static_cast<uint32_t*>(p);
-        HIP_TRY(hipMalloc(&p, size_t(s->scratch_waves) * sizeof(uint32_t)));
-        s->allocs.push_back(p);
-        L.d_xready = static_cast<uint32_t*>(p);
-        HIP_TRY(hipMemset(p, 0, size_t(s->scratch_waves) * sizeof(uint32_t)));
-        if (s->xgroup != 0) {  // (experiment builds only)
-            HIP_TRY(hipMalloc(&p, size_t(s->scratch_waves) * s->pool * 128u));  // one 128-B record per path slot of every wave
-            s->allocs.push_back(p);
-            L.d_xrec = static_cast<uint32_t*>(p);
-        }
         // the lane is recorded before its stream and events exist, so that a failure below leaves them to
         // rbrt_hip_scene_destroy instead of leaking them (a lane without a stream is never selected: the caller
         // gets the error)
@@ -588,13 +574,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         if (const char* e = std::getenv("RBRT_SHARE_BELOW")) s->share_below = std::strtoull(e, nullptr, 10);
         if (const char* e = std::getenv("RBRT_WORK_STRIPES")) s->work_stripes = uint32_t(std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("RBRT_WORK_STRIPES_SHORT")) s->work_stripes_short = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 15u;
-        if (const char* e = std::getenv("RBRT_XGROUP")) {
-            int v = std::atoi(e);
-            if (v == 0 || (v >= 2 && v <= 64)) s->xgroup = uint32_t(v);  // (lanes 1..group-1 of the collector track the donors)
-        }
-        if (!megakernel_has_handover()) s->xgroup = 0;
-        if (const char* e = std::getenv("RBRT_XTHRESH")) s->xthreshold = uint32_t(std::max(0, std::atoi(e)));
+        if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 11u;
         if (const char* e = std::getenv("RBRT_SHADE_ROUNDS")) {
             int v = std::atoi(e);
             if (v >= 1 && v <= int(kMaxShadeRounds)) s->shade_rounds = uint32_t(v);
@@ -739,8 +719,6 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.share_idle = s->share_idle;
     P.drain_mode = s->drain_mode;
     P.work_stripes = s->work_stripes;  // (per launch: set where the launch's size is known)
-    P.xgroup = s->xgroup;
-    P.xthreshold = s->xthreshold;
     P.shade_rounds = s->shade_rounds;
     P.shade_cont_min = s->shade_cont_min;
 
@@ -797,8 +775,6 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.work_counter = L.d_work_counter;
         P.gseq = L.d_gseq;
         P.gstack = L.d_gstack;
-        P.xready = L.d_xready;
-        P.xrec = L.d_xrec;
         // (L.d_work_counter is zero: from its allocation, afterwards from the resolve kernel of the lane's last launch)
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
@@ -812,8 +788,6 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         }
         R.sample_buf = L.d_sample_buf;
         R.work_counter = L.d_work_counter;
-        R.xready = L.d_xready;
-        R.n_xready = s->scratch_waves;
         R.batch = nb;
         R.first_batch = base == 0;
         R.last_batch = base + nb == o->spp;

@@ -127,10 +127,6 @@ struct TraceParams {
     uint32_t leaf_round;               // test deferred leaves once this many lanes are stalled on one ...
     uint32_t share_idle;               // shared traversals: idle lanes needed for a round of giving (0: never)
     uint32_t leaf_leaves;              // ... or once this many leaves are pending (a leaf round deals their triangles out to all lanes)
-    uint32_t xgroup;                   // drain hand-over: workgroups per group (0 = off), the first of each is the collector
-    uint32_t xthreshold;               // ... a donor hands its paths over once it holds at most this many
-    uint32_t* xready;                  // [n_waves] published record count + 1 per donor (zeroed before every launch)
-    uint32_t* xrec;                    // [n_waves / xgroup][xgroup - 1][pool][32] handed-over path records
     uint32_t work_stripes;             // chunks per stripe when the work shards interleave over the item range (0: contiguous eighths)
     uint32_t drain_mode;               // scheduling once the work items have run out (bits: megakernel.inl "drain")
     uint32_t shade_rounds;             // shading pass: rounds a sphere-only bounce chain may stay in registers
@@ -148,8 +144,6 @@ struct ResolveParams {
     float* out_radiance;  // row-major image if tile_world <= 1, else packed tiles; may be null
     uint8_t* out_rgb8;    // same indexing; may be null
     unsigned long long* work_counter;  // the finished launch's work counters, zeroed here for the lane's next launch
-    uint32_t* xready;                  // ... and its hand-over counts
-    uint32_t n_xready;
 };
 
 }  // namespace rbrt

@@ -585,8 +585,6 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) 
     // waits for this kernel), saving a memset launch that would have to queue behind the resident megakernels
     static_assert(kWorkShards * kWorkCounterStride <= kBlock, "one thread per counter word");
     if (blockIdx.x == 0 && threadIdx.x < kWorkShards * kWorkCounterStride) R.work_counter[threadIdx.x] = 0ull;
-    if (blockIdx.x == 0)
-        for (uint32_t j = threadIdx.x; j < R.n_xready; j += kBlock) R.xready[j] = 0u;
     if (i >= npix) return;
     const uint32_t tile_local = uint32_t(i >> 6), p = uint32_t(i & 63u);
     const uint32_t tile = tile_local * R.tile_world + R.tile_rank;
@@ -817,7 +815,6 @@ hipError_t launch_ieee_selftest(uint64_t seed, size_t n, unsigned long long* d_c
     return hipGetLastError();
 }
 
-bool megakernel_has_handover() { return RBRT_HANDOVER != 0; }
 
 uint64_t host_splitmix64(uint64_t x) { return splitmix64(x); }
 

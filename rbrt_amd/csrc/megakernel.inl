@@ -26,9 +26,6 @@
 #ifndef RBRT_FAST_GATE
 #define RBRT_FAST_GATE 1  // mesh bbox gate through bbox_gate_fast (same decisions, no IEEE divisions on the common path)
 #endif
-#ifndef RBRT_HANDOVER
-#define RBRT_HANDOVER 0  // experiment: drain hand-over to collector waves (measured 4-60 % slower: DESIGN.md); needs RBRT_XGROUP too
-#endif
 #ifndef RBRT_ROOT_LDS
 #define RBRT_ROOT_LDS 0  // experiment: the root node of mesh 0 is read from a copy in LDS (measured: no gain)
 #endif
@@ -44,14 +41,12 @@
 // distance is a pure function of the ray and F_T, the same `length(o - (o + t*d))` expression that produced it,
 // and is recomputed in the rare case that a later mesh has to be compared with an earlier one.)
 enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_S0, F_S1, F_ITEM, F_META, F_T, F_TRI, F_WORD, kFields };
-constexpr uint32_t kXRecDw = 32u;  // one handed-over path: kFields pool dwords, status, kSeqWords record words (128 B)
 constexpr uint32_t kCellDw = 128u, kTqDw = 64u;  // LDS behind the pool: 64 x u64 result cells, 64 x u32 triangle-test queue
 constexpr uint32_t kHelpDw = 16u;                  // ... and 64 x u8 counts of helper lanes per owner lane (shared traversals)
 constexpr unsigned long long kNoHitKey = (unsigned long long)0x49742400u << 32;  // (t = 1000000.0f, index 0): triangle.rs:398
 enum : uint32_t { ST_EMPTY = 0u, ST_TRAV = 1u, ST_TERM = 2u, ST_LAMB = 3u, ST_METAL = 4u, ST_DIEL = 5u, kNumStatus = 6u,
                   ST_BUSY = 6u /* being traversed by a lane right now */ };
 constexpr int kSeqWords = kMaxPathDepth / 4;
-static_assert(kFields + 1 + kSeqWords <= int(kXRecDw), "a handed-over path must fit its 128-byte record");
 
 // Wave-wide vote. HIP's __ballot / __any take an int: the predicate is first materialised with v_cndmask and then
 // compared again (two VALU instructions per vote, and this kernel votes several times per traversal step); the
@@ -265,27 +260,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         dg_rt0 = __builtin_amdgcn_s_memrealtime();
     }
     bool more_work = true;  // wave-uniform: the global work counter has not run out yet
-    // ---- drain hand-over (P.xgroup != 0) ------------------------------------------------------------------------
-    // When the work items run out every wave still holds up to POOLN paths, and finishing them where they are means
-    // ~100 scheduling rounds per wave at a handful of busy lanes: 15 % of all VALU instructions of a full frame, 40 %
-    // of a GPU's eighth of one. Instead, the waves of a group of `xgroup` consecutive workgroups hand their paths to
-    // the group's first wave (the COLLECTOR) and exit: a DONOR finishes the traversals it has in flight, writes every
-    // live path slot (13 pool dwords, status, the attenuation record words) to its own region of the exchange buffer,
-    // publishes the count (agent-scope release; MI355X_MICROARCH.md "Valid forms") and leaves. The collector adopts
-    // donated paths into its free slots whenever it has room (relaxed poll -> agent-scope acquire -> plain loads) and
-    // ends when its pool is empty and every donor's region is consumed. Donors never wait for anybody, so the only
-    // wait -- the collector's, for donors that have not been scheduled yet -- always ends; it is bounded anyway.
-    const uint32_t x_group = RBRT_HANDOVER ? P.xgroup : 0u;  // (compiled out by default: measured slower)
-    const uint32_t x_div = x_group ? x_group : 1u;
-    const uint32_t x_gid = blockIdx.x / x_div, x_me = x_group ? blockIdx.x % x_div : 0u;
-    const bool x_collector = x_group != 0u && x_me == 0u;
-    const uint32_t x_members = x_group ? (gridDim.x - x_gid * x_group < x_group ? gridDim.x - x_gid * x_group : x_group) : 0u;
-    uint32_t* const x_ready = P.xready + size_t(x_gid) * x_group;                           // [x_group] (word 0 unused)
-    uint32_t* const x_rec = P.xrec + size_t(x_gid) * (x_group ? x_group - 1u : 0u) * POOLN * kXRecDw;  // donor d: region d - 1
-    bool x_prio_set = false;
-    bool x_donating = false;            // donor: no more refills / shading, in-flight traversals only
-    uint32_t x_state = 0;               // collector, lane d in [1, x_members): donor d's (published count + 1) << 16 | records taken
-    unsigned long long x_wait_t0 = 0;   // collector: start of the current wait for unpublished donors (0: not waiting)
     const size_t npix = size_t(P.n_local_tiles) * 64u;
     const float eps = P.min_dist;
 
@@ -381,104 +355,11 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (STATS) ++dg_census, dg_dr_rounds += more_work ? 0u : 1u;
         uint32_t n_active = uint32_t(__popcll(wballot(t_active != 0u)));
 
-        if (x_group != 0u && !more_work) {
-            const uint32_t live = uint32_t(POOLN) - cnt[ST_EMPTY];
-            if (!x_collector) {
-                // ---- donor ----
-                if (!x_donating && live <= P.xthreshold) x_donating = true;
-                if (x_donating && n_active == 0u) {  // (results were finalised at the top of this round: no slot is BUSY)
-                    uint32_t n_rec = 0;
-#pragma unroll
-                    for (uint32_t g = 0; g < kPoolPad; g += 64) {
-                        const uint32_t st = status[g + lane];
-                        const bool m = st != ST_EMPTY && st < kNumStatus;
-                        const uint64_t mask = wballot(m);
-                        if (m) list[n_rec + lane_rank(mask)] = uint8_t(g + lane);
-                        n_rec += uint32_t(__popcll(mask));
-                    }
-                    __syncthreads();
-                    uint32_t* const my = x_rec + size_t(x_me - 1u) * POOLN * kXRecDw;
-                    for (uint32_t k = lane; k < n_rec; k += 64u) {
-                        const uint32_t slot = list[k];
-                        uint32_t* r = my + size_t(k) * kXRecDw;
-#pragma unroll
-                        for (uint32_t f = 0; f < uint32_t(kFields); ++f) r[f] = POOL(f, slot);
-                        r[kFields] = status[slot];
-                        const uint32_t nw = ((POOL(F_META, slot) >> 7) & 127u) >> 2;  // completed attenuation record words
-                        for (uint32_t q = 0; q < nw; ++q) r[kFields + 1u + q] = gseq[size_t(slot) * kSeqWords + q];
-                    }
-                    // publish: every store of this wave has left it, then an agent-scope release, then the count
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(x_ready + x_me, n_rec + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (STATS && lane == 0) atomicAdd(&P.counters->diag[58], (unsigned long long)n_rec);
-                    break;
-                }
-            } else if (!x_prio_set && (P.drain_mode & 4u)) {
-                __builtin_amdgcn_s_setprio(2);  // the collector's rounds decide when the launch ends: ahead of bulk waves
-                x_prio_set = true;
-            }
-            if (x_collector && (cnt[ST_EMPTY] >= 32u || live == 0u)) {
-                // ---- collector with room: look at the donors' published counts, adopt what fits ----
-                const bool is_donor_lane = lane >= 1u && lane < x_members;
-                if (is_donor_lane && (x_state >> 16) == 0u)
-                    x_state = __hip_atomic_load(x_ready + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 16;
-                const uint32_t x_seen = x_state >> 16, x_next = x_state & 0xFFFFu;
-                const uint32_t avail = is_donor_lane && x_seen != 0u ? x_seen - 1u - x_next : 0u;
-                const uint64_t have = wballot(avail != 0u);
-                const uint64_t unpublished = wballot(is_donor_lane && x_seen == 0u);
-                if (have != 0ull) {
-                    x_wait_t0 = 0;
-                    const int dl = __builtin_ctzll(have);  // one donor per round
-                    const uint32_t d_avail = uint32_t(__builtin_amdgcn_readlane(int(avail), dl));
-                    const uint32_t d_next = uint32_t(__builtin_amdgcn_readlane(int(x_next), dl));
-                    const uint32_t n_take = d_avail < cnt[ST_EMPTY] ? d_avail : cnt[ST_EMPTY];
-                    uint32_t n_free = 0;
-#pragma unroll
-                    for (uint32_t g = 0; g < kPoolPad; g += 64) {
-                        const bool m = status[g + lane] == ST_EMPTY;
-                        const uint64_t mask = wballot(m);
-                        if (m) list[n_free + lane_rank(mask)] = uint8_t(g + lane);
-                        n_free += uint32_t(__popcll(mask));
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the donor's records, published before its count
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    const uint32_t* const src = x_rec + size_t(uint32_t(dl) - 1u) * POOLN * kXRecDw + size_t(d_next) * kXRecDw;
-                    for (uint32_t k = lane; k < n_take; k += 64u) {
-                        const uint32_t slot = list[k];
-                        const uint32_t* r = src + size_t(k) * kXRecDw;
-#pragma unroll
-                        for (uint32_t f = 0; f < uint32_t(kFields); ++f) POOL(f, slot) = r[f];
-                        const uint32_t nw = ((r[F_META] >> 7) & 127u) >> 2;
-                        for (uint32_t q = 0; q < nw; ++q) gseq[size_t(slot) * kSeqWords + q] = r[kFields + 1u + q];
-                        status[slot] = uint8_t(r[kFields]);
-                    }
-                    if (lane == uint32_t(dl)) x_state += n_take;
-                    __syncthreads();
-                    continue;  // new census
-                }
-                if (live == 0u && n_active == 0u) {
-                    if (unpublished == 0ull) break;  // pool empty, every donor's region consumed: done
-                    // donors still running (or not scheduled yet): wait, bounded
-                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                    if (x_wait_t0 == 0) x_wait_t0 = now;
-                    if (now - x_wait_t0 > 400000000ull) {  // 4 s at 100 MHz: give up loudly (rbrt_hip_scene_check reports it)
-                        if (lane == 0) atomicAdd(&P.counters->diag[57], 1ull);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(32);
-                    continue;
-                }
-            }
-        }
-
         RBRT_MARK("refill");
         // ---- idle lanes take parked rays (in batches: only when enough lanes are idle) ----
         // with plenty of parked rays the lanes are topped up sooner (y_high_water) than when few wait
         const uint32_t y_refill = cnt[ST_TRAV] >= P.y_high_min_parked ? P.y_high_water : P.y_low_water;
-        if (!x_donating && cnt[ST_TRAV] != 0 && (n_active < y_refill || n_active + cnt[ST_TRAV] <= 64u)) {
+        if (cnt[ST_TRAV] != 0 && (n_active < y_refill || n_active + cnt[ST_TRAV] <= 64u)) {
             uint32_t ny = 0;
 #pragma unroll
             for (uint32_t g = 0; g < kPoolPad; g += 64) {
@@ -529,12 +410,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (cnt[ST_LAMB] > best) kind = ST_LAMB, best = cnt[ST_LAMB];
         if (cnt[ST_METAL] > best) kind = ST_METAL, best = cnt[ST_METAL];
         if (cnt[ST_DIEL] > best) kind = ST_DIEL, best = cnt[ST_DIEL];
-        if (best == 0 && n_active == 0) {  // nothing waits, nothing runs, no work left
-            if (x_group == 0u || more_work) break;
-            if (x_collector) continue;  // (a collector ends in the hand-over block above, once its donors are consumed)
-            x_donating = true;          // a donor with an empty pool still publishes its (zero) count
-            continue;
-        }
+        if (best == 0 && n_active == 0) break;  // nothing waits, nothing runs, no work left
 
         // Traverse while the lanes are well filled; shade when they are not (that is what parks new
         // rays) or when shading work has piled up to a full wave.
@@ -542,7 +418,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         // is how few, and how full, the remaining rounds are. drain_mode bit 1: all traversals first.)
         const bool drain = !more_work;
         const bool traverse = n_active != 0 && (best == 0 || (n_active >= P.y_low_water && best < 64u) ||
-                                                (drain && (P.drain_mode & 2u)) || x_donating);
+                                                (drain && (P.drain_mode & 2u)));
         if (traverse) {
             if (STATS) {
                 ++dg_pass[ST_TRAV];
@@ -554,7 +430,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             // other work exists, as soon as one lane has a result (it creates shading work)
             const uint32_t y_keep = cnt[ST_TRAV] >= P.y_high_min_parked ? P.y_high_water : P.y_low_water;
             // (drain_mode bit 0: in the drain a burst runs until every lane has finished)
-            const uint32_t keep = ((drain && (P.drain_mode & 1u)) || x_donating) ? 1u
+            const uint32_t keep = (drain && (P.drain_mode & 1u)) ? 1u
                                   : (best != 0 || cnt[ST_TRAV] != 0) ? (n_active < y_keep ? n_active : y_keep)
                                                                      : n_active;
             // (traversals are shared in the drain only: before it, a parked ray uses an idle lane better, and the
