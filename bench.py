@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=0,
                     help="frame pipeline depth (rbrt_hip_scene_set_pipeline): consecutive steps' trace launches overlap "
-                         "on this many internal streams; 0 = the library's automatic choice (2, or 3 for short launches)")
+                         "on this many internal streams; 0 = the library's automatic choice (3)")
     ap.add_argument("--vary-seed", type=int, default=0, help="1: every step renders a new frame (seed + step number)")
     ap.add_argument("--triangles", type=int, default=69451)
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
@@ -301,7 +301,7 @@ def main():
         "config": {"workload": f"example_scene.yaml, {args.triangles}-triangle "
                                f"{'bunny.obj' if real_asset else 'stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
-                   "pipeline": (f"{args.pipeline or 'auto: 2 or 3'} trace launches in flight (consecutive steps overlap)")
+                   "pipeline": (f"{args.pipeline or 'auto: 3'} trace launches in flight, half-size grids while they overlap (consecutive steps overlap)")
                    if args.pipeline != 1 else "1 (no overlap between steps)",
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                    "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,

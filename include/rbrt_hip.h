@@ -230,8 +230,9 @@ int rbrt_hip_scene_last_batching(rbrt_hip_scene_t* scene, uint32_t* samples_per_
 /* Counters of the last render on this scene that had RBRT_FLAG_COLLECT_STATS set. */
 int rbrt_hip_scene_stats(rbrt_hip_scene_t* scene, rbrt_hip_stats_t* out);
 
-/* Frame pipeline depth of a scene handle: 1..8, or 0 = automatic (the default, or $RBRT_PIPELINE): 2 for
- * launches that fill the GPU for long, 3 (and half-size grids, api.cpp grid_for) for launches under 24 M samples.
+/* Frame pipeline depth of a scene handle: 1..8, or 0 = automatic (the default, or $RBRT_PIPELINE): 3. A launch
+ * issued while another launch of the scene is still running takes half of the GPU's wave slots, one that finds the
+ * GPU idle takes them all (api.cpp grid_for).
  * With depth d > 1 consecutive
  * trace launches -- the sample batches of one render and successive rbrt_hip_render_device calls -- alternate
  * over d internal streams and d sets of work buffers, so that a launch's last, poorly filled waves overlap

@@ -120,8 +120,8 @@ struct rbrt_hip_scene {
     uint32_t share_idle = 4;      // RBRT_SHARE_IDLE (0: no shared traversals)
     uint64_t share_below = ~0ull;  // RBRT_SHARE_BELOW: launches under this many samples use the sharing build (all)
     uint32_t drain_mode = 1;      // RBRT_DRAIN_MODE
-    uint32_t work_stripes = 16;   // RBRT_WORK_STRIPES: chunks (of 64 work items) per stripe, long launches only; 0 = contiguous shards
-    int work_stripes_short = 0;   // RBRT_WORK_STRIPES_SHORT: the same for launches under 24 M samples
+    uint32_t work_stripes = 16;   // RBRT_WORK_STRIPES: chunks (of 64 work items) per stripe for a launch that has the GPU to itself; 0 = contiguous shards
+    uint32_t work_stripes_overlap = 0;  // RBRT_WORK_STRIPES_OVERLAP: the same for a launch issued while another is running
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
     // stats / timing
@@ -197,24 +197,27 @@ constexpr uint32_t kMaxPipeline = 8;
 constexpr uint32_t kLanesAtCreate = 4;  // lanes made by scene_create (deeper pipelines: rbrt_hip_scene_set_pipeline makes the rest)
 constexpr size_t kMaxTimedLaunches = 4096;  // timing events are recycled per set_timing, never more than this many launches
 
-// Launches under 24 M (pixel, sample) items -- a GPU's share of a sharded frame -- are "short": their fixed-cost
-// drain is the larger part of them.
-bool short_launch(uint64_t samples) { return samples < 24000000ull; }
+// Depth of the frame pipeline: what was set, or 3.
+uint32_t depth_for(const rbrt_hip_scene* s) { return s->pipeline != 0 ? s->pipeline : 3u; }
 
-// Depth of the frame pipeline: what was set, or, in automatic mode, 2 for long launches and 3 for short ones.
-uint32_t depth_for(const rbrt_hip_scene* s, uint64_t samples) {
-    if (s->pipeline != 0) return s->pipeline;
-    return short_launch(samples) ? 3u : 2u;
+// Is a trace launch of this scene still running on another lane? (What decides how the next one is issued.)
+bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane* mine) {
+    bool busy = false;
+    for (const auto& L : s->lanes)
+        if (&L != mine && L.in_use && L.ev_traced && hipEventQuery(L.ev_traced) == hipErrorNotReady) busy = true;
+    (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure: keep it out of the next launch check)
+    return busy;
 }
 
-// Waves of one trace launch. A launch that fills the GPU (all resident wave slots) is right for a long launch;
-// short ones are issued with HALF the slots, so that two consecutive launches are resident side by side (one's
-// drain always has the other's bulk to share the SIMDs with) and a third is queued behind them. Measured per
-// step on config 2, full grids 2 deep against half grids 3 deep: a half of the frame 2.88 vs 2.53 ms, a
-// quarter 1.78 vs 1.45, an eighth 1.18 vs 0.91 (half grids 2 or 4 deep: 1.14 / 1.17). A whole frame would gain
-// 2 % (4.94 vs 5.04 ms) at the price of launches of twice the duration; it keeps full grids.
-uint32_t grid_for(const rbrt_hip_scene* s, uint64_t samples, uint32_t depth) {
-    if (s->waves_fixed || depth < 2 || !short_launch(samples)) return s->n_waves;
+// Waves of one trace launch. A launch that finds the GPU idle (a blocking caller, the first frame of a stream)
+// takes all resident wave slots. One issued while another is still running -- consecutive frames or sample batches
+// queued back to back -- takes HALF, so that two launches are resident side by side (one's drain always has the
+// other's bulk to share the SIMDs with) and a third is queued behind them. Measured per step on config 2, full
+// grids 2 deep against half grids 3 deep: the whole frame 4.43 vs 4.25 ms, a half 2.88 vs 2.53, a quarter 1.78 vs
+// 1.45, an eighth 1.18 vs 0.91 (half grids 2 or 4 deep are worse; 12 of 16 slots is worse than either: the second
+// launch then gets the 4 that are left).
+uint32_t grid_for(const rbrt_hip_scene* s, bool overlapped) {
+    if (s->waves_fixed || !overlapped) return s->n_waves;
     const uint32_t half = s->n_cus * 8u;
     return half < s->n_waves ? half : s->n_waves;
 }
@@ -573,7 +576,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         }
         if (const char* e = std::getenv("RBRT_SHARE_BELOW")) s->share_below = std::strtoull(e, nullptr, 10);
         if (const char* e = std::getenv("RBRT_WORK_STRIPES")) s->work_stripes = uint32_t(std::max(0, std::atoi(e)));
-        if (const char* e = std::getenv("RBRT_WORK_STRIPES_SHORT")) s->work_stripes_short = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("RBRT_WORK_STRIPES_OVERLAP")) s->work_stripes_overlap = uint32_t(std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 11u;
         if (const char* e = std::getenv("RBRT_SHADE_ROUNDS")) {
             int v = std::atoi(e);
@@ -675,7 +678,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     if (batch < 1) batch = 1;
     if (batch > s_end - s_begin) batch = s_end - s_begin;
     const size_t need = batch * per_sample;
-    const uint32_t depth = depth_for(s, uint64_t(npix) * batch);
+    const uint32_t depth = depth_for(s);
     if (int rc = ensure_lanes(s, depth)) return rc;
     const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
         HIP_TRY(hipStreamSynchronize(stream));
@@ -770,7 +773,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.batch = nb;
         P.batch_magic = div_magic_of(nb);
         P.n_items = uint64_t(npix) * nb;
-        P.work_stripes = short_launch(P.n_items) ? uint32_t(s->work_stripes_short) : s->work_stripes;
+        const bool overlapped = piped && other_launch_in_flight(s, &L);
+        P.work_stripes = overlapped ? s->work_stripes_overlap : s->work_stripes;
         P.sample_buf = L.d_sample_buf;
         P.work_counter = L.d_work_counter;
         P.gseq = L.d_gseq;
@@ -779,7 +783,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
-        HIP_TRY(launch_trace_megakernel(P, stats ? s->n_waves : grid_for(s, P.n_items, depth), s->pool, stats,
+        HIP_TRY(launch_trace_megakernel(P, stats ? s->n_waves : grid_for(s, overlapped), s->pool, stats,
                                         s->share_idle != 0u && P.n_items < s->share_below, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
         if (piped) {
