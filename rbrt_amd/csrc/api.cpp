@@ -575,8 +575,13 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             if (v >= 0 && v <= 64) s->share_idle = uint32_t(v);
         }
         if (const char* e = std::getenv("RBRT_SHARE_BELOW")) s->share_below = std::strtoull(e, nullptr, 10);
-        if (const char* e = std::getenv("RBRT_WORK_STRIPES")) s->work_stripes = uint32_t(std::max(0, std::atoi(e)));
-        if (const char* e = std::getenv("RBRT_WORK_STRIPES_OVERLAP")) s->work_stripes_overlap = uint32_t(std::max(0, std::atoi(e)));
+        const auto pow2_below = [](int v) -> uint32_t {  // stripes are a power of two (the kernel shifts)
+            uint32_t p = 0;
+            for (uint32_t q = 1; v > 0 && q <= uint32_t(v) && q <= 65536u; q <<= 1) p = q;
+            return p;
+        };
+        if (const char* e = std::getenv("RBRT_WORK_STRIPES")) s->work_stripes = pow2_below(std::atoi(e));
+        if (const char* e = std::getenv("RBRT_WORK_STRIPES_OVERLAP")) s->work_stripes_overlap = pow2_below(std::atoi(e));
         if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 11u;
         if (const char* e = std::getenv("RBRT_SHADE_ROUNDS")) {
             int v = std::atoi(e);

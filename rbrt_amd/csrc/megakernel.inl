@@ -18,7 +18,9 @@
 // Which lane works on which path never affects the result: a path owns its RNG stream and its
 // sample slot, and resolve_kernel adds the samples of a pixel in sample order.
 
-#ifdef RBRT_MARKERS  // analysis build only (tools/static_cost.py): region markers in the instruction stream
+#if defined(RBRT_MARKERS) && RBRT_MARKERS == 2  // analysis build for PC sampling: a symbol at every region boundary
+#define RBRT_MARK(name) asm volatile("rbrt_mk_" name "_%=:" ::: "memory")
+#elif defined(RBRT_MARKERS)  // analysis build only (tools/static_cost.py): region markers in the instruction stream
 #define RBRT_MARK(name) asm volatile("; @@" name ::: "memory")
 #else
 #define RBRT_MARK(name)
@@ -143,13 +145,16 @@ struct WorkSource {
     __device__ __forceinline__ bool next_chunk(const TraceParams& P, uint32_t lane, uint32_t& lo, uint32_t& hi) {
         for (;;) {
             prefetch(P, lane);
-            const unsigned long long local = (unsigned long long)__shfl(int(uint32_t(pend_base)), 0) |
-                                             ((unsigned long long)__shfl(int(uint32_t(pend_base >> 32)), 0) << 32);
+            // (lane 0's result, through SGPRs: what follows is scalar arithmetic. next_chunk runs in wave-uniform
+            // control flow, so the first active lane IS lane 0.)
+            const unsigned long long local =
+                (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(pend_base)))) |
+                ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(pend_base >> 32)))) << 32);
             pending = false;
-            if (P.work_stripes) {
+            if (P.work_stripes) {  // (a power of two: api.cpp)
+                const uint32_t sh = 31u - uint32_t(__builtin_clz(P.work_stripes));
                 const unsigned long long l = local / kWorkChunk;  // chunk number inside the shard
-                const unsigned long long stripe = P.work_stripes;
-                const unsigned long long g = ((l / stripe) * kWorkShards + pend_shard) * stripe + l % stripe;
+                const unsigned long long g = (((l >> sh) * kWorkShards + pend_shard) << sh) + (l & (P.work_stripes - 1u));
                 if (g * kWorkChunk < P.n_items) {  // (n_items is a multiple of the chunk size: 64 pixel slots per tile)
                     lo = uint32_t(g * kWorkChunk);
                     hi = lo + kWorkChunk;
