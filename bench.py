@@ -223,6 +223,7 @@ def main():
     single = None
     if world == 1 and not emu and args.single_frames > 0:
         host_img = torch.empty((H, W, 3), dtype=torch.float32).pin_memory()
+        step()  # (untimed: the first blocking frame after a stream of frames is still issued as one of the stream)
         fence()
         ts = []
         for _ in range(args.single_frames):

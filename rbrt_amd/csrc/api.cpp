@@ -96,6 +96,7 @@ struct rbrt_hip_scene {
         bool in_use = false;  // ev_resolved has been recorded at least once
     };
     std::vector<Lane> lanes;
+    bool streaming_hint = false;  // the last trace launch was issued while another one was still running
     uint32_t pipeline = 0;   // RBRT_PIPELINE / rbrt_hip_scene_set_pipeline; 0 = automatic (depth_for)
     uint32_t scratch_waves = 0;
     uint32_t n_cus = 256;
@@ -778,7 +779,11 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.batch = nb;
         P.batch_magic = div_magic_of(nb);
         P.n_items = uint64_t(npix) * nb;
-        const bool overlapped = piped && other_launch_in_flight(s, &L);
+        // (a caller that streams launches keeps doing so: the first launch after a pause -- the GPU is idle, but the
+        // launch before it was issued into a busy one -- is still issued as one of a stream)
+        const bool busy = piped && other_launch_in_flight(s, &L);
+        const bool overlapped = busy || (piped && s->streaming_hint);
+        s->streaming_hint = busy;
         P.work_stripes = overlapped ? s->work_stripes_overlap : s->work_stripes;
         P.sample_buf = L.d_sample_buf;
         P.work_counter = L.d_work_counter;

@@ -397,20 +397,76 @@ struct Builder {
                 b.box.lo[k] = n.lo1[k], b.box.hi[k] = n.hi1[k];
             }
         };
+        // Slots still free when only leaves are left go to the two halves of the largest leaf of two or more
+        // triangles (the best of its two-way partitions by surface x count): two tighter boxes for the same node.
+        // The leaf's records are regrouped in place; each half keeps the ascending order of reference indices.
+        auto split_leaf = [&](const Cand& leaf, Cand& a, Cand& b) {
+            const uint32_t code = uint32_t(~leaf.ref), first = code >> kLeafBits, count = (code & uint32_t(kLeafMax - 1)) + 1u;
+            BvhTri t[kLeafMax];
+            Box tb[kLeafMax];
+            float te12[kLeafMax];
+            const float fmax = std::numeric_limits<float>::max();
+            for (uint32_t i = 0; i < count; ++i) {
+                t[i] = out.tris[first + i];
+                const float v0[3] = {t[i].v0[0], t[i].v0[1], t[i].v0[2]};
+                const float e1[3] = {t[i].e1x, t[i].e1yz[0], t[i].e1yz[1]}, e2[3] = {t[i].e2xy[0], t[i].e2xy[1], t[i].e2z};
+                float v1[3], v2[3];
+                for (int k = 0; k < 3; ++k) {
+                    v1[k] = std::min(std::max(v0[k] + e1[k], -fmax), fmax);
+                    v2[k] = std::min(std::max(v0[k] + e2[k], -fmax), fmax);
+                }
+                tb[i].reset();
+                tb[i].grow(v0), tb[i].grow(v1), tb[i].grow(v2);
+                te12[i] = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) *
+                          std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+            }
+            uint32_t best_mask = 1;
+            float best_cost = std::numeric_limits<float>::infinity();
+            for (uint32_t mask = 1; mask < (1u << count) - 1u; mask += 2) {  // triangle 0 always in the first half
+                Box ba, bb;
+                ba.reset(), bb.reset();
+                uint32_t na = 0;
+                for (uint32_t i = 0; i < count; ++i) (mask >> i & 1u) ? (ba.grow(tb[i]), ++na) : (bb.grow(tb[i]), 0u);
+                const float cost = ba.half_area() * float(na) + bb.half_area() * float(count - na);
+                if (cost < best_cost) best_cost = cost, best_mask = mask;
+            }
+            uint32_t pos = first, na = 0;
+            a.box.reset(), b.box.reset();
+            a.e12 = b.e12 = 0.0f;
+            for (int half = 1; half >= 0; --half)
+                for (uint32_t i = 0; i < count; ++i)
+                    if (int(best_mask >> i & 1u) == half) {
+                        out.tris[pos++] = t[i];
+                        Cand& dst = half ? a : b;
+                        dst.box.grow(tb[i]);
+                        dst.e12 = std::max(dst.e12, te12[i]);
+                        na += uint32_t(half);
+                    }
+            a.ref = ~int32_t((first << kLeafBits) | (na - 1u));
+            b.ref = ~int32_t(((first + na) << kLeafBits) | (count - na - 1u));
+            ++out.n_leaves;
+        };
         Cand c[4];
         int n = 2;
         children_of(n2, c[0], c[1]);
-        while (n < 4) {
-            int pick = -1;
-            float best = -1.0f;
-            for (int i = 0; i < n; ++i)
-                if (c[i].ref >= 0 && c[i].box.half_area() > best) best = c[i].box.half_area(), pick = i;
-            if (pick < 0) break;
-            Cand a, b;
-            children_of(c[pick].ref, a, b);
-            c[pick] = a;
-            c[n++] = b;
-        }
+        for (int pass = 0; pass < 2; ++pass)
+            while (n < 4) {
+                int pick = -1;
+                float best = -1.0f;
+                for (int i = 0; i < n; ++i) {
+                    const bool ok = pass == 0 ? c[i].ref >= 0
+                                              : c[i].ref < 0 && (uint32_t(~c[i].ref) & uint32_t(kLeafMax - 1)) != 0u;
+                    if (ok && c[i].box.half_area() > best) best = c[i].box.half_area(), pick = i;
+                }
+                if (pick < 0) break;
+                Cand a, b;
+                if (pass == 0)
+                    children_of(c[pick].ref, a, b);
+                else
+                    split_leaf(c[pick], a, b);
+                c[pick] = a;
+                c[n++] = b;
+            }
         const uint32_t me = uint32_t(out.nodes.size());
         out.nodes.emplace_back();
         out.max_depth = std::max(out.max_depth, depth);

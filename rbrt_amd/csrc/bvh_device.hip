@@ -318,21 +318,25 @@ __global__ __launch_bounds__(kTpb) void collapse_level(Work* w, Tree t, uint32_t
     uint32_t off[4] = {it.offset, it.offset + t.size[c[0]], 0u, 0u};
     int n = 2;
     auto expandable = [&](uint32_t id) { return t.size[id] > uint32_t(kLeafMax); };
-    while (n < 4) {  // open the expandable candidate with the largest surface (as bvh.cpp's collapse does)
-        int pick = -1;
-        float best = -1.0f;
-        for (int k = 0; k < n; ++k)
-            if (expandable(c[k])) {
-                const float a = t.nbox[size_t(c[k]) * 8u + 7u];
-                if (a > best) best = a, pick = k;
-            }
-        if (pick < 0) break;
-        const uint32_t open = c[pick], o0 = off[pick];
-        c[pick] = uint32_t(t.left[open]);
-        c[n] = uint32_t(t.right[open]);
-        off[n] = o0 + t.size[c[pick]];
-        ++n;
-    }
+    // open the expandable candidate with the largest surface (as bvh.cpp's collapse does); slots that are still free
+    // when only leaves are left go to the halves of the largest leaf of two or more triangles (two tighter boxes
+    // instead of one, for the same node)
+    for (int pass = 0; pass < 2; ++pass)
+        while (n < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int k = 0; k < n; ++k)
+                if (pass == 0 ? expandable(c[k]) : (t.size[c[k]] >= 2u && !expandable(c[k]))) {
+                    const float a = t.nbox[size_t(c[k]) * 8u + 7u];
+                    if (a > best) best = a, pick = k;
+                }
+            if (pick < 0) break;
+            const uint32_t open = c[pick], o0 = off[pick];
+            c[pick] = uint32_t(t.left[open]);
+            c[n] = uint32_t(t.right[open]);
+            off[n] = o0 + t.size[c[pick]];
+            ++n;
+        }
     BvhNode4 o;
     const float qnan = __uint_as_float(0x7fc00000u);
     for (int k = 0; k < 4; ++k) {
