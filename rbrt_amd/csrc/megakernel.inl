@@ -34,6 +34,9 @@
 #ifndef RBRT_PUSH_ORDER
 #define RBRT_PUSH_ORDER 0  // 0: children pushed far-to-near (sorted); 1: nearest next, the rest in slot order
 #endif
+#ifndef RBRT_SPHERE_BOUND
+#define RBRT_SPHERE_BOUND 1  // the triangle search of a ray that has hit a sphere starts at that hit's distance
+#endif
 #ifndef RBRT_MK_WAVES_PER_SIMD
 #define RBRT_MK_WAVES_PER_SIMD 4  // register budget: 512 / 4 = 128 VGPRs per lane
 #endif
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         closest = length(t_o - pc);
                     }
                 }
-                if (t_best > eps && t_best < 100000.0f) {  // triangle.rs:405
+                if (t_best > eps && t_best < 100000.0f && (!RBRT_SPHERE_BOUND || t_best_idx != 0xFFFFFFFFu)) {  // triangle.rs:405
                     const V3 p = t_o + t_best * t_d;
                     const float dist = length(t_o - p);
                     if (dist > P.min_dist && dist < P.max_dist) {
@@ -385,7 +388,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                              __uint_as_float(POOL(F_OZ, slot)));
                     t_d = mk(__uint_as_float(POOL(F_DX, slot)), __uint_as_float(POOL(F_DY, slot)),
                              __uint_as_float(POOL(F_DZ, slot)));
-                    const uint32_t t_mesh = (POOL(F_META, slot) >> 22) & 255u;
+                    const uint32_t r_meta = POOL(F_META, slot);
+                    const uint32_t t_mesh = (r_meta >> 22) & 255u;
                     t_ids = slot | (t_mesh << 8) | (lane << 16);
                     const uint32_t* md = sc.mesh + t_mesh * kMeshDw;
                     t_nodes = lds_ptr<BvhNode4>(md + MD_NODES);
@@ -393,8 +397,25 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                                      __uint_as_float(md[MD_RADIUS]), P.eps_frac);
                     t_best = 1000000.0f;  // triangle.rs:398
                     t_best_idx = 0;
+#if RBRT_SPHERE_BOUND
+                    // A ray that has hit a sphere already can only take a triangle that is CLOSER (scene.rs:37): the
+                    // search starts at that distance instead of 1e6. The mesh's distance is length(o - (o + t d))
+                    // with |d| = 1 to a few ulps, i.e. t up to rounding of the order 1e-7 (t + |o|); the bound is
+                    // relaxed by 1e-3 relative and 1e-3 (1 + max |o|) absolute, so a triangle beyond it is certain
+                    // to fail the exact `dist < closest` that the finalise step still applies to whatever is found.
+                    // Index 0xFFFFFFFF (no triangle has it) marks "nothing found below the bound".
+                    {
+                        const int32_t r_obj = int32_t((r_meta >> 14) & 255u) - 1;
+                        if (r_obj >= 0 && uint32_t(r_obj) < P.n_spheres) {
+                            const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t_o.x), __builtin_fabsf(t_o.y)),
+                                                               __builtin_fabsf(t_o.z));
+                            const float bound = __uint_as_float(POOL(F_TRI, slot)) * 1.001f + 0.001f * (1.0f + omax);
+                            if (bound < 100000.0f) t_best = bound, t_best_idx = 0xFFFFFFFFu;
+                        }
+                    }
+#endif
                     t_sp = 0;
-                    cell[lane] = kNoHitKey;
+                    cell[lane] = ((unsigned long long)__float_as_uint(t_best) << 32) | t_best_idx;
                     t_cur = 0;
                     t_pend = kNoChild;
                     t_pend2 = kNoChild;
