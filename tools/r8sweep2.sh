@@ -20,5 +20,5 @@ run RBRT_Y_LOW=20 --
 run RBRT_Y_LOW=36 --
 run RBRT_SHARE_IDLE=1 --
 run RBRT_SHARE_IDLE=8 --
-run RBRT_WORK_STRIPES_SHORT=16 --
+run RBRT_WORK_STRIPES_OVERLAP=16 --
 done
