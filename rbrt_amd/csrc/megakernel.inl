@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     uint32_t dg_steps = 0, dg_lane_steps = 0, dg_refills = 0, dg_census = 0;
     uint32_t dg_dr_rounds = 0, dg_dr_steps = 0, dg_dr_passes = 0, dg_dr_lane_steps = 0;  // after the work ran out
     unsigned long long dg_t_trav = 0, dg_t_shade = 0, dg_t0 = 0, dg_tk = 0;
-    uint32_t dg_share_rounds = 0, dg_share_given = 0;
+    uint32_t dg_share_rounds = 0, dg_share_given = 0, dg_root_only = 0;
     uint32_t dg_leaf_rounds = 0, dg_leaf_lanes = 0, dg_walk_rounds = 0, dg_walk_lanes = 0, dg_shade_rounds = 0;
     unsigned long long dg_rt0 = 0, dg_rt_workout = 0;
     if (STATS) {
@@ -614,6 +614,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     f32x4 links;
                     node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links, lds_root, t_cur == 0 && id_mesh() == 0u);
                     if (STATS) ++lc.nodes;
+                    if (STATS && t_cur == 0 && k[0] == kMissKey) ++dg_root_only;  // a traversal that ends at the root
 #if RBRT_PUSH_ORDER == 0
                     if (k[0] != kMissKey) {  // farthest first, so that the nearest is popped first
                         if (k[3] != kMissKey) push(link_of(links, k[3]));
@@ -957,6 +958,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         atomicAdd(&P.counters->tris_tested, (unsigned long long)lc.tris);
         atomicAdd(&P.counters->mesh_hits, (unsigned long long)lc.mesh_hits);
         atomicAdd(&P.counters->samples, (unsigned long long)n_samples_done);
+        atomicAdd(&P.counters->diag[61], (unsigned long long)dg_root_only);  // (per lane, like the counters above)
         if (lane == 0) {
             for (uint32_t k = 0; k < kNumStatus; ++k) {
                 atomicAdd(&P.counters->diag[k], (unsigned long long)dg_pass[k]);
