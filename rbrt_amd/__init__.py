@@ -129,7 +129,8 @@ class HipScene:
                                     trav_steps=(int(buf[50]) >> 16) & 0xFFFF, passes=int(buf[50]) & 0xFFFF),
                  drain_sum=dict(rounds=int(buf[51]), trav_steps=int(buf[52]), passes=int(buf[53]),
                                 lane_steps=int(buf[54])),
-                 shared_entries_given=int(buf[59]), share_rounds=int(buf[60]), traversals_ending_at_root=int(buf[61]))
+                 shared_entries_given=int(buf[59]), share_rounds=int(buf[60]), traversals_ending_at_root=int(buf[61]),
+                 sphere_tail_runs=int(buf[62]), sphere_tail_lanes=int(buf[63]))
         return d
 
     def trace_rays(self, rays, min_dist=0.001, max_dist=2000.0):

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     uint32_t dg_steps = 0, dg_lane_steps = 0, dg_refills = 0, dg_census = 0;
     uint32_t dg_dr_rounds = 0, dg_dr_steps = 0, dg_dr_passes = 0, dg_dr_lane_steps = 0;  // after the work ran out
     unsigned long long dg_t_trav = 0, dg_t_shade = 0, dg_t0 = 0, dg_tk = 0;
-    uint32_t dg_share_rounds = 0, dg_share_given = 0, dg_root_only = 0;
+    uint32_t dg_share_rounds = 0, dg_share_given = 0, dg_root_only = 0, dg_sph_tails = 0, dg_sph_pairs = 0;
     uint32_t dg_leaf_rounds = 0, dg_leaf_lanes = 0, dg_walk_rounds = 0, dg_walk_lanes = 0, dg_shade_rounds = 0;
     unsigned long long dg_rt0 = 0, dg_rt_workout = 0;
     if (STATS) {
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     t_best = 1000000.0f;  // triangle.rs:398
                     t_best_idx = 0;
 #if RBRT_SPHERE_BOUND
-                    // A ray that has hit a sphere already can only take a triangle that is CLOSER (scene.rs:37): the
+                    // A ray that has hit a sphere (or an earlier mesh) already can only take a triangle that is CLOSER (scene.rs:37): the
                     // search starts at that distance instead of 1e6. The mesh's distance is length(o - (o + t d))
                     // with |d| = 1 to a few ulps, i.e. t up to rounding of the order 1e-7 (t + |o|); the bound is
                     // relaxed by 1e-3 relative and 1e-3 (1 + max |o|) absolute, so a triangle beyond it is certain
@@ -406,10 +406,12 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     // Index 0xFFFFFFFF (no triangle has it) marks "nothing found below the bound".
                     {
                         const int32_t r_obj = int32_t((r_meta >> 14) & 255u) - 1;
-                        if (r_obj >= 0 && uint32_t(r_obj) < P.n_spheres) {
+                        if (r_obj >= 0) {  // (a sphere: F_TRI is its distance; an earlier mesh: F_T is its t, equal to
+                                           // its distance to the same few ulps)
                             const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t_o.x), __builtin_fabsf(t_o.y)),
                                                                __builtin_fabsf(t_o.z));
-                            const float bound = __uint_as_float(POOL(F_TRI, slot)) * 1.001f + 0.001f * (1.0f + omax);
+                            const float ref = __uint_as_float(uint32_t(r_obj) < P.n_spheres ? POOL(F_TRI, slot) : POOL(F_T, slot));
+                            const float bound = ref * 1.001f + 0.001f * (1.0f + omax);
                             if (bound < 100000.0f) t_best = bound, t_best_idx = 0xFFFFFFFFu;
                         }
                     }
@@ -904,6 +906,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 for (uint32_t i = 0; i < P.n_spheres; ++i) {
                     const float* sp = sc.sph + i * kSphDw;
                     float t, dist;
+                    if (STATS) {  // how often a wave runs the expensive part of sphere_hit, and for how many lanes
+                        const V3 l = o - mk(sp);
+                        const float bq = dot(d * 2.0f, l);
+                        const float sol = bq * bq - 4.0f * dot(d, d) * (dot(l, l) - sp[3] * sp[3]);
+                        const uint64_t m = wballot(sol >= 0.0f);
+                        if (m != 0ull) ++dg_sph_tails, dg_sph_pairs += uint32_t(__popcll(m));
+                    }
                     if (sphere_hit(mk(sp), sp[3], o, d, P.min_dist, P.max_dist, t, dist, P.counters)) {
                         if (dist < closest) {
                             closest = dist;
@@ -984,6 +993,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             atomicAdd(&P.counters->diag[18], (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
             atomicAdd(&P.counters->diag[59], (unsigned long long)dg_share_given);
             atomicAdd(&P.counters->diag[60], (unsigned long long)dg_share_rounds);
+            atomicAdd(&P.counters->diag[62], (unsigned long long)dg_sph_tails);
+            atomicAdd(&P.counters->diag[63], (unsigned long long)dg_sph_pairs);
             atomicAdd(&P.counters->diag[19], (unsigned long long)dg_leaf_rounds);
             atomicAdd(&P.counters->diag[20], (unsigned long long)dg_leaf_lanes);
             atomicAdd(&P.counters->diag[29], (unsigned long long)dg_shade_rounds);
