@@ -200,7 +200,10 @@ __device__ __forceinline__ bool bbox_gate(const float* lo, const float* hi, V3 o
 // tests -- t_max < 0, t_min > t_max -- come out the same whenever |t_max| > E and |t_min - t_max| > 2E. Otherwise
 // (a ray grazing an edge of the box within a few ulp, a zero / tiny / huge direction component, non-finite
 // quotients) the lane falls back to the IEEE form; the wave takes that branch only when one of its lanes needs it.
-__device__ __forceinline__ bool bbox_gate_fast(const float* lo, const float* hi, V3 o, V3 d) {
+// `beyond`: a ray parameter past which no triangle of this mesh could be accepted any more (the ray's closest hit so
+// far, relaxed as in the megakernel's refill; +inf when there is none). A box entered only past it is skipped: that is
+// not a decision of the reference's gate, it is the traversal's first culling step done here, before the ray is parked.
+__device__ __forceinline__ bool bbox_gate_fast(const float* lo, const float* hi, V3 o, V3 d, float beyond = __builtin_inff()) {
     const float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
     const float lx = (lo[0] - o.x) * rx, ux = (hi[0] - o.x) * rx;
     const float ly = (lo[1] - o.y) * ry, uy = (hi[1] - o.y) * ry;
@@ -216,7 +219,7 @@ __device__ __forceinline__ bool bbox_gate_fast(const float* lo, const float* hi,
     // every comparison below is false for a NaN operand: anything unusual lands in the exact branch
     const bool sure = (__builtin_fabsf(t_max) > E) && (__builtin_fabsf(t_min - t_max) > 2.0f * E) && (m < 1e30f) && (m > 1e-30f) &&
                       (dmin > 1e-30f) && (dmax < 1e30f) && (d.x == d.x) && (d.y == d.y) && (d.z == d.z);
-    bool res = !(t_max < 0.0f) && !(t_min > t_max);
+    bool res = !(t_max < 0.0f) && !(t_min > t_max) && !(t_min - E > beyond);
     if (!sure) res = bbox_gate(lo, hi, o, d);
     return res;
 }

@@ -91,13 +91,19 @@ __device__ __forceinline__ const T* lds_ptr(const uint32_t* p) {  // a 64-bit de
 }
 
 // First mesh with index >= m0 whose bbox gate (aabbox.rs:28-58) the ray passes, or n_meshes.
+// `closest`: the distance of the ray's closest hit so far (f32::MAX: none); a mesh whose box the ray enters only
+// beyond it (relaxed like the search bound of the refill) is passed over.
 template <bool STATS>
 __device__ __forceinline__ uint32_t next_gated_mesh(const SceneLds& sc, uint32_t n_meshes, uint32_t m0, V3 o, V3 d,
-                                                    LocalCounters& lc) {
+                                                    float closest, LocalCounters& lc) {
+    const float beyond = RBRT_SPHERE_BOUND
+                             ? closest * 1.001f + 0.001f * (1.0f + __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)),
+                                                                                  __builtin_fabsf(o.z)))
+                             : __builtin_inff();
     uint32_t m = m0;
     for (; m < n_meshes; ++m) {
         const float* md = reinterpret_cast<const float*>(sc.mesh + m * kMeshDw);
-        if (RBRT_FAST_GATE ? bbox_gate_fast(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d) : bbox_gate(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d)) {
+        if (RBRT_FAST_GATE ? bbox_gate_fast(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d, beyond) : bbox_gate(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d)) {
             if (STATS) ++lc.gate;
             break;
         }
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         }
                     }
                 }
-                const uint32_t m2 = next_gated_mesh<STATS>(sc, P.n_meshes, t_mesh + 1u, t_o, t_d, lc);
+                const uint32_t m2 = next_gated_mesh<STATS>(sc, P.n_meshes, t_mesh + 1u, t_o, t_d, closest, lc);
                 const uint32_t depth = meta & 127u;
                 POOL(F_META, slot) = pack_meta(depth, (meta >> 7) & 127u, obj, m2 < P.n_meshes ? m2 : 0u);
                 status[slot] = m2 < P.n_meshes ? ST_TRAV : classify(sc, obj, depth);
@@ -922,7 +928,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     }
                 }
                 RBRT_MARK("gate");
-                gated = next_gated_mesh<STATS>(sc, P.n_meshes, 0, o, d, lc);
+                gated = next_gated_mesh<STATS>(sc, P.n_meshes, 0, o, d, closest, lc);
                 next = gated < P.n_meshes ? uint32_t(ST_TRAV) : classify(sc, s_obj, depth);
             }
             // stay in registers? only sphere hits that need shading, while enough lanes do (or the wave
