@@ -58,7 +58,7 @@ uint32_t local_tiles_of(uint32_t n_tiles, uint32_t rank, uint32_t world) {
 }
 
 size_t workspace_cap_bytes() {
-    size_t mb = 2048;
+    size_t mb = 1024;
     if (const char* e = std::getenv("RBRT_HIP_WORKSPACE_MB")) {
         long v = std::atol(e);
         if (v > 0) mb = size_t(v);

@@ -41,6 +41,28 @@ def cost(N, c_tri=0.35):
     return c_inner, c_leaf, int(inner.sum()) + 1, int(leaf.sum()), float((n_tris * leaf).sum() / max(1, leaf.sum()))
 
 
+def cost_by_depth(N):
+    """Inner-node part of the cost per depth of the 4-wide tree (root = 0)."""
+    lo = N[:, 0:12].reshape(-1, 3, 4)
+    hi = N[:, 12:24].reshape(-1, 3, 4)
+    link = N[:, 24:28].view(np.int32)
+    ext = np.maximum(hi - lo, 0.0)
+    area = 2.0 * (ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0])
+    used = link != NO_CHILD
+    area = np.where(used, area, 0.0)
+    root_lo = np.where(used[0], lo[0], np.inf).min(1)
+    root_hi = np.where(used[0], hi[0], -np.inf).max(1)
+    e = root_hi - root_lo
+    root_area = 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0])
+    out = []
+    level = np.array([0])
+    while len(level):
+        inner = used[level] & (link[level] >= 0)
+        out.append(float((area[level] * inner).sum() / root_area))
+        level = link[level][inner]
+    return out
+
+
 def main():
     oracle.lib()
     for n in [int(a) for a in sys.argv[1:]] or [69451, 871414]:
@@ -59,6 +81,8 @@ def main():
             ci, cl, ni, nl, tpl = cost(N)
             print(f"  {name:16s} cost {ci + cl:8.2f} (nodes {ci:7.2f} + leaves {cl:6.2f})  inner {ni:7d} leaves {nl:7d} "
                   f"tris/leaf {tpl:.2f} depth {depth}")
+            if os.environ.get("RBRT_QUALITY_LEVELS"):
+                print("      by depth:", " ".join(f"{c:.2f}" for c in cost_by_depth(N)))
 
 
 if __name__ == "__main__":
