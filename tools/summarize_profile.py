@@ -21,6 +21,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = ROOT / "profiles"
 out_dir.mkdir(exist_ok=True)
 
+if not SRC.is_dir() or not any(SRC.iterdir()):
+    sys.exit(f"{SRC} is empty: run tools/profile.sh on the GPU box first (nothing written)")
 bench = None
 for leg in ("isolated", "default"):
     stats = sorted(glob.glob(str(SRC / f"stats_{leg}" / "*" / "*kernel_stats.csv")), key=lambda f: Path(f).stat().st_mtime)
