@@ -247,6 +247,31 @@ def test_shared_traversals_do_not_change_the_image(hip, oracle, monkeypatch, env
     assert (given > 0) == sharing, (env, given)
 
 
+def test_streamed_and_blocking_frames_interleaved(hip, oracle):
+    """The launch policy looks at what is in flight (api.cpp grid_for: half the wave slots for a launch issued while
+    another is running, all of them for one that finds the GPU idle, the first launch after a pause still issued as
+    one of a stream). Whatever it decides, every frame is the oracle's."""
+    import torch
+    cam = scenes.camera(oracle, 192, 128)
+    sc = scenes.example_scene(oracle, 2003)
+    exp = {seed: oracle.render(cam, sc, abi.default_opts(spp=4, seed=seed))[0] for seed in (1, 2)}
+    with hip.HipScene(sc) as hs:
+        imgs = [torch.full((128, 192, 3), float("nan"), dtype=torch.float32, device="cuda") for _ in range(9)]
+        seeds = [1, 2, 1, 2, 2, 1, 1, 2, 1]
+        for k in range(4):  # a stream of frames
+            hs.render_device(cam, abi.default_opts(spp=4, seed=seeds[k]), imgs[k].data_ptr(), None, None)
+        torch.cuda.synchronize()
+        for k in (4, 5):  # blocking frames: the first still issued as one of the stream, the second alone
+            hs.render_device(cam, abi.default_opts(spp=4, seed=seeds[k]), imgs[k].data_ptr(), None, None)
+            torch.cuda.synchronize()
+        for k in range(6, 9):  # and a stream again
+            hs.render_device(cam, abi.default_opts(spp=4, seed=seeds[k]), imgs[k].data_ptr(), None, None)
+        torch.cuda.synchronize()
+        hs.check()
+    for k, (img, seed) in enumerate(zip(imgs, seeds)):
+        assert_same_image(img.cpu().numpy(), exp[seed], f"frame {k} (seed {seed})")
+
+
 def test_stats_counters(hip, oracle):
     import torch
     cam = scenes.camera(oracle, 64, 48)
