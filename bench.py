@@ -104,6 +104,9 @@ def main():
         if args.rehearse_single_gpu:
             dist.init_process_group("gloo")
         else:
+            # the trace launches are persistent and hold every wave slot; the gather's copy kernels are short and
+            # on the critical path of every step: RCCL's stream gets high priority (the library's trace streams low)
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
             dist.init_process_group("nccl", device_id=dev)
 
     # ---- setup (untimed): stand-in asset, YAML through the C++ host, upload + BVH build ---------

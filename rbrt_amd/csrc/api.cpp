@@ -246,7 +246,13 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         // gets the error)
         s->lanes.push_back(L);
         rbrt_hip_scene::Lane& R = s->lanes.back();
-        hipError_t e = hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking);
+        // The lanes' streams carry the long trace launches and nothing else. They get the LOWEST priority: the short
+        // kernels that wait on them -- the resolve on the caller's stream, a collective's copy kernels, the unpack --
+        // then win the wave slots a finishing trace wave frees, ahead of the next trace launch's waves.
+        int prio_low = 0, prio_high = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: low >= high)
+        if (const char* pe = std::getenv("RBRT_LANE_PRIORITY")) prio_low = !std::strcmp(pe, "default") ? 0 : !std::strcmp(pe, "high") ? prio_high : prio_low;
+        hipError_t e = hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, prio_low);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_traced, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_resolved, hipEventDisableTiming);
         if (e != hipSuccess) {
