@@ -2,7 +2,7 @@
 """A/B harness for kernel tuning on the GPU box: runs bench.py once per environment variant (each in
 its own process, interleaved for several rounds) and prints the trace-kernel time per variant.
 
-    python tools/ab.py --rounds 2 "RBRT_POOL=128" "RBRT_POOL=192" "RBRT_POOL=256 RBRT_Y_LOW=32"
+    python tools/ab.py --rounds 2 "-" "RBRT_Y_LOW=32" "RBRT_SHARE_IDLE=0 RBRT_LEAF_ROUND=8"
 """
 import argparse
 import json
