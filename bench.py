@@ -138,10 +138,16 @@ def main():
     if world > 1:
         slot_pixels = rbrt_amd.packed_pixels(W, H, 0, world)  # rank 0 owns the most tiles: equal-size slots
         maxn = slot_pixels * 3
-        mine = torch.empty(maxn, dtype=torch.float32, device=dev)  # this rank's tiles (tail of the slot unused)
+        # Two sets of buffers and a side stream: the gather of frame k (and rank 0's unpack) runs beside the render of
+        # frame k + 1 instead of in front of it -- the render's resolve kernel, which frees a pipeline lane for its
+        # next launch, does not queue behind a collective that waits for the slowest rank.
+        mine = [torch.empty(maxn, dtype=torch.float32, device=dev) for _ in range(2)]  # this rank's tiles (tail of the slot unused)
         # rank 0 receives straight into one buffer of `world` equal slots; the unpack kernel strides over it
-        slots = torch.empty(world * maxn, dtype=torch.float32, device=dev) if rank == 0 else None
-        gathered = list(slots.chunk(world)) if rank == 0 else None
+        slots = [torch.empty(world * maxn, dtype=torch.float32, device=dev) for _ in range(2)] if rank == 0 else None
+        gathered = [list(sl.chunk(world)) for sl in slots] if rank == 0 else [None, None]
+        xs = torch.cuda.Stream(device=dev, priority=-1)  # (high priority: short kernels among persistent ones)
+        rendered = [torch.cuda.Event(), torch.cuda.Event()]
+        gathered_ev = [None, None]
 
     step_no = [0]
 
@@ -155,19 +161,29 @@ def main():
         if world == 1:
             scene.render_device(cam, opts, image.data_ptr(), None, stream)  # (emulation: packed tiles, fits)
             return
-        scene.render_device(cam, opts, mine.data_ptr(), None, stream)
-        if args.rehearse_single_gpu:  # gloo cannot gather device tensors: stage through the host
-            host = mine.cpu()
-            hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-            dist.gather(host, hg, dst=0)
+        b = step_no[0] & 1
+        main = torch.cuda.current_stream()
+        if gathered_ev[b] is not None:
+            main.wait_event(gathered_ev[b])  # the gather of two frames ago has read this buffer
+        scene.render_device(cam, opts, mine[b].data_ptr(), None, stream)
+        rendered[b].record(main)
+        xs.wait_event(rendered[b])
+        with torch.cuda.stream(xs):
+            if args.rehearse_single_gpu:  # gloo cannot gather device tensors: stage through the host
+                host = mine[b].cpu()
+                hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, hg, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        gathered[b][r].copy_(hg[r], non_blocking=False)
+            else:
+                dist.gather(mine[b], gathered[b], dst=0)  # RCCL over xGMI: every peer sends its tiles straight to rank 0
             if rank == 0:
-                for r in range(world):
-                    gathered[r].copy_(hg[r])
-        else:
-            dist.gather(mine, gathered, dst=0)  # RCCL over xGMI: every peer sends its tiles straight to rank 0
-        if rank == 0:
-            rbrt_amd.unpack_tiles(local_rank, slots.data_ptr(), W, H, world, image.data_ptr(), None, stream,
-                                  rank_stride_pixels=slot_pixels)
+                rbrt_amd.unpack_tiles(local_rank, slots[b].data_ptr(), W, H, world, image.data_ptr(), None, xs.cuda_stream,
+                                      rank_stride_pixels=slot_pixels)
+            ev = torch.cuda.Event()
+            ev.record(xs)
+            gathered_ev[b] = ev
 
     def fence():
         if world > 1:
