@@ -19,7 +19,7 @@ all: $(LIBDIR)/librbrt_hip.so host oracle
 
 $(LIBDIR)/librbrt_hip.so: $(CSRC)/kernels.hip $(CSRC)/megakernel.inl $(CSRC)/api.cpp $(CSRC)/bvh.cpp $(CSRC)/bvh.h \
                           $(CSRC)/bvh_device.hip $(CSRC)/bvh_device.h \
-                          $(CSRC)/device_types.h include/rbrt_hip.h
+                          $(CSRC)/device_types.h include/rbrt_hip.h include/rbrt_hip_debug.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/bvh_device.hip $(CSRC)/api.cpp $(CSRC)/bvh.cpp
 

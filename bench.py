@@ -43,6 +43,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 TRI_ALG_BYTES = 36     # the 9 fp32 SoA values Moller-Trumbore reads per triangle (triangle.rs:177-187)
 NORMAL_ALG_BYTES = 12  # normal fetch per accepted mesh hit (mesh.rs:253-257)
 PIXEL_ALG_BYTES = 12   # fp32 radiance store per pixel
+# VALU issue, measured on this chip (profiles/r03_valu_rate.txt): SIMD cycles per wave64 instruction of plain f32 / u32
+# VALU with >= 4 resident waves per SIMD, and what ONE wave alone sustains.
+VALU_CYCLES_PER_INST = 2.0
+VALU_CYCLES_ONE_WAVE = 4.0
+CLOCK_GHZ = 2.4
 
 
 def parse_args():
@@ -60,9 +65,10 @@ def parse_args():
     ap.add_argument("--vary-seed", type=int, default=0, help="1: every step renders a new frame (seed + step number)")
     ap.add_argument("--triangles", type=int, default=69451)
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
-    ap.add_argument("--cpu-col-stride", type=int, default=8,
+    ap.add_argument("--cpu-col-stride", type=int, default=-1,
                     help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline; 1 = the whole "
-                         "frame, ~2 min on 16 cores)")
+                         "frame: SURVEY 8(d) times config 2 in full, ~2 min on 256 cores; default: 1 on a host with 64 "
+                         "cores or more, else 8 -- a labelled sample)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = every core this process may use)")
     ap.add_argument("--isolated-steps", type=int, default=8,
                     help="steps of the second, unpipelined leg that times isolated trace launches for the roofline (N = 1 only; 0 = skip)")
@@ -216,6 +222,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     trace_ms, resolve_ms, n_launches = scene.kernel_ms()
+    mix_full, mix_half = scene.launch_mix()  # the grid of a launch depends on what was in flight when it was issued
     scene.set_timing(False)
     scene.check()  # a NaN sphere discriminant (sphere.rs:33 panics) or corrupt path state fails the run loudly
 
@@ -289,29 +296,47 @@ def main():
     if iso is not None:
         roofline["isolated_leg"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in iso.items()}
     # The two figures that describe the kernel as it really runs come from rocprofv3 PMC passes (their own runs of
-    # this same command, tools/profile.sh; committed under profiles/): a bench run cannot read counters itself.
-    prof = ROOT / "profiles" / "r02_pmc_summary.json"
-    if prof.exists() and world == 1:
-        try:
-            rec = json.loads(prof.read_text())
-            if rec.get("workload") == f"{W}x{H}x{spp}" and rec.get("triangles") == args.triangles:
-                roofline["traffic"] = rec.get("hbm_bytes_per_launch")
-                roofline["traffic_source"] = "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-                if rec.get("hbm_bytes_per_launch") and kernel_ms > 0:
-                    gbs = rec["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
-                    roofline["measured_hbm"] = {"bytes_per_launch": rec["hbm_bytes_per_launch"], "GBps": round(gbs, 1),
-                                                "frac": round(gbs / HBM_PEAK_GBS, 4)}
-                if rec.get("sq_insts_valu") and kernel_ms > 0:
-                    # one wave64 VALU instruction issues in 4 cycles of its SIMD (MI355X_MICROARCH.md, 'vector-instruction
-                    # ISSUE cost'); 256 CUs x 4 SIMDs; 2.4 GHz
-                    bound_ms = rec["sq_insts_valu"] * 4.0 / 1024.0 / 2.4e9 * 1e3
-                    roofline["valu_issue"] = {"sq_insts_valu": rec["sq_insts_valu"], "cycles_per_inst": 4, "simds": 1024,
-                                              "clock_ghz": 2.4, "bound_ms": round(bound_ms, 3),
-                                              "frac": round(bound_ms / kernel_ms, 4),
-                                              "valu_lane_utilisation": rec.get("valu_lane_utilisation"),
-                                              "source": "profiles/r02_pmc_summary.json"}
-        except Exception:
-            pass
+    # this same command, tools/profile.sh; committed under profiles/): a bench run cannot read counters itself. A
+    # summary is used only if it was measured on the kernel sources this run uses (rbrt_amd/srchash.py); otherwise the
+    # counter-derived figures are left out and the line says so.
+    if world == 1 and not emu:
+        from rbrt_amd.srchash import kernel_source_sha256
+        src_hash = kernel_source_sha256()
+        roofline["kernel_source_sha256_16"] = src_hash
+        cands = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"), reverse=True)
+        rec, prof = None, None
+        for cand in cands:
+            try:
+                r = json.loads(cand.read_text())
+            except Exception:
+                continue
+            if r.get("workload") == f"{W}x{H}x{spp}" and r.get("triangles") == args.triangles and r.get("kernel_source_sha256_16") == src_hash:
+                rec, prof = r, cand
+                break
+        if rec is None:
+            roofline["counters_stale"] = True
+            roofline["counters_note"] = ("no profiles/r*_pmc_summary.json was measured on these kernel sources "
+                                         f"(sha {src_hash}) and workload: traffic / measured_hbm / valu_issue omitted; run tools/profile.sh")
+        else:
+            src = f"profiles/{prof.name}"
+            roofline["counters_stale"] = False
+            roofline["traffic"] = rec.get("hbm_bytes_per_launch")
+            roofline["traffic_source"] = f"{src} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            if rec.get("hbm_bytes_per_launch") and kernel_ms > 0:
+                gbs = rec["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+                roofline["measured_hbm"] = {"bytes_per_launch": rec["hbm_bytes_per_launch"], "GBps": round(gbs, 1),
+                                            "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            if rec.get("sq_insts_valu") and kernel_ms > 0:
+                # SIMD cycles per wave64 VALU instruction: measured, tools/ubench/valu_rate.hip -> profiles/r03_valu_rate.txt
+                # (plain f32 / integer VALU at four or more resident waves per SIMD; one wave alone issues one per
+                # VALU_CYCLES_ONE_WAVE cycles -- the figure rounds 1 and 2 priced the kernel with, which is a LATENCY).
+                bound_ms = rec["sq_insts_valu"] * VALU_CYCLES_PER_INST / 1024.0 / CLOCK_GHZ / 1e9 * 1e3
+                roofline["valu_issue"] = {"sq_insts_valu": rec["sq_insts_valu"], "cycles_per_inst": VALU_CYCLES_PER_INST,
+                                          "cycles_per_inst_source": "profiles/r03_valu_rate.txt (tools/ubench/valu_rate.hip)",
+                                          "simds": 1024, "clock_ghz": CLOCK_GHZ, "bound_ms": round(bound_ms, 3),
+                                          "frac": round(bound_ms / kernel_ms, 4),
+                                          "one_wave_cycles_per_inst": VALU_CYCLES_ONE_WAVE,
+                                          "valu_lane_utilisation": rec.get("valu_lane_utilisation"), "source": src}
 
     out = {
         "metric": "Mray-samples/sec (WxHxspp/s) on bunny scene; achieved HBM GB/s vs peak",
@@ -324,6 +349,7 @@ def main():
                    "pipeline": (f"{args.pipeline or 'auto: 3'} trace launches in flight, half-size grids while they overlap (consecutive steps overlap)")
                    if args.pipeline != 1 else "1 (no overlap between steps)",
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
+                   "launch_mix_timed_region": {"full_grid": mix_full, "half_grid": mix_half},
                    "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,
                    **({"EMULATION_rank0_share_of_world": emu} if emu else {}),
                    # (with the pipeline on, the resolve waits on another stream: its event pair measures that wait)
@@ -336,6 +362,8 @@ def main():
                                "what": "one blocking frame: render + synchronise + copy of the fp32 radiance to pinned host memory"}
 
     # ---- CPU baseline (rank 0, N = 1 only): bounded sample of the same workload ---------------------
+    if args.cpu_col_stride < 0:
+        args.cpu_col_stride = 1 if len(os.sched_getaffinity(0)) >= 64 else 8
     if world == 1 and args.cpu_col_stride > 0:
         from oracle import pyoracle  # the checker, used here only as the timed CPU baseline
         n_threads = args.cpu_threads or len(os.sched_getaffinity(0))  # every core this process may use

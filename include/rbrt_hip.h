@@ -24,6 +24,11 @@
  *       rgb8    : uint8[H][W][3]  — (sqrt(c)*256) saturating cast (lib.rs:116-122)
  *   - there is NO CPU fallback: without a usable HIP device every render entry
  *     point fails with RBRT_ERR_NO_DEVICE.
+ *   - environment: the library reads two variables, both optional --
+ *       RBRT_HIP_WORKSPACE_MB   cap of one pipeline lane's sample workspace in MiB (default 1024)
+ *       RBRT_BVH_BUILDER        host | device: force one BVH builder (default: by mesh size)
+ *     Everything else that tunes the kernels' scheduling is a lab knob: ignored unless RBRT_HIP_LAB=1 is set, and
+ *     documented with the test / diagnostic entry points in rbrt_hip_debug.h, not here. No knob changes the image.
  */
 #ifndef RBRT_HIP_H
 #define RBRT_HIP_H
@@ -214,6 +219,18 @@ int rbrt_hip_unpack_tiles_strided(int device, void* stream, const float* d_gathe
                                   uint32_t height, uint32_t tile_world, size_t rank_stride_pixels,
                                   float* d_radiance, uint8_t* d_rgb8);
 
+/* What scene_create built (informational; the C++ host's --report prints it). */
+typedef struct rbrt_hip_scene_info {
+    uint32_t n_spheres, n_meshes;
+    uint32_t n_meshes_device_built; /* meshes whose BVH the GPU builder made (the host's SAH builder made the rest) */
+    uint32_t bvh_stack_need;        /* traversal stack entries the deepest tree can need */
+    uint64_t n_nodes;               /* 128-B BVH nodes, all meshes */
+    uint64_t n_triangles;           /* indexed triangle records, all meshes (what the reference's scan can return) */
+    uint32_t trace_waves;           /* resident single-wave workgroups of a full trace launch */
+    uint32_t lds_bytes_per_wave;    /* LDS each of them uses */
+} rbrt_hip_scene_info_t;
+int rbrt_hip_scene_info(rbrt_hip_scene_t* scene, rbrt_hip_scene_info_t* out);
+
 /* Error state of the resident path. rbrt_hip_render_device returns before the kernels have run, so what they
  * detect cannot come back through its return value: a NaN sphere discriminant (the reference panics with
  * "Encountered NAN", sphere.rs:33; here those rays miss that sphere and are counted) or a corrupt path slot
@@ -221,11 +238,6 @@ int rbrt_hip_unpack_tiles_strided(int device, void* stream, const float* d_gathe
  * any render on this scene since the previous check, and clears the flags. The one-shot rbrt_hip_render does the
  * same check itself. Call it where the reference's render_scene would have returned (lib.rs:124). */
 int rbrt_hip_scene_check(rbrt_hip_scene_t* scene);
-
-/* How the last rbrt_hip_render_device call on this scene split its samples: samples per batch (one trace launch
- * each, sized to the workspace cap $RBRT_HIP_WORKSPACE_MB and to the kernel's 32-bit work-item numbers) and the
- * number of batches. Diagnostic. */
-int rbrt_hip_scene_last_batching(rbrt_hip_scene_t* scene, uint32_t* samples_per_batch, uint32_t* n_batches);
 
 /* Counters of the last render on this scene that had RBRT_FLAG_COLLECT_STATS set. */
 int rbrt_hip_scene_stats(rbrt_hip_scene_t* scene, rbrt_hip_stats_t* out);
@@ -241,61 +253,12 @@ int rbrt_hip_scene_stats(rbrt_hip_scene_t* scene, rbrt_hip_stats_t* out);
  * is one blocking call, lib.rs:75-124); results are identical for every depth. */
 int rbrt_hip_scene_set_pipeline(rbrt_hip_scene_t* scene, uint32_t depth);
 
-/* Test / diagnostic hook for Scene::hit (scene.rs:19-43): closest hit of n rays against the
- * resident scene. Host arrays. rays = n x {ox,oy,oz,dx,dy,dz}. Outputs (each may be NULL):
- *   out_t[n]      ray parameter of the winning object (NaN on miss)
- *   out_obj[n]    -1 on miss, sphere index in [0,n_spheres), or n_spheres + mesh index
- *   out_tri[n]    winning triangle index (reference numbering) for mesh hits, else -1
- *   out_dist[n]   dist_from_ray_orig of the winner (lib.rs:35)                            */
-int rbrt_hip_trace_rays(rbrt_hip_scene_t* scene, const float* rays, size_t n, float min_dist,
-                        float max_dist, float* out_t, int32_t* out_obj, int32_t* out_tri,
-                        float* out_dist);
-
-/* Test hook for BoundingBox::hit (aabbox.rs:28-58): n rays against the box [lo, hi], decided by the division-free
- * form the megakernel uses (out_fast[n]) and by the verbatim form with six IEEE divisions (out_exact[n]); the two
- * must agree for every input. Host arrays. */
-int rbrt_hip_selftest_gate(const float lo[3], const float hi[3], const float* rays, size_t n, uint8_t* out_fast,
-                           uint8_t* out_exact);
-
-/* Test hook: the image needs correctly rounded sqrt and / (vec3.rs:111-126); the kernels use short forms of them when
- * every lane's operands are in the everyday range (kernels.hip "IEEE square root and division, the short way"). Runs n
- * pseudo-random operands through the short forms and the compiler's: counts[0] / counts[1] = differing sqrt results /
- * normalize components (must be 0), counts[2] = lanes that really took the short path. */
-int rbrt_hip_selftest_ieee(uint64_t seed, size_t n, uint64_t counts[3]);
-
-/* Diagnostic: pass statistics of the persistent megakernel from the last render with
- * RBRT_FLAG_COLLECT_STATS: out[0..5] passes per kind (empty, traverse, terminate, lambertian, metal,
- * dielectric), out[6..11] path slots handled per kind, out[12] traversal wave-steps, out[13] busy
- * lane-steps, out[14] refill rounds, out[15] scheduling rounds. */
-int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* scene, uint64_t* out, size_t n);
-
-/* Diagnostic: run the host-side BVH builder alone (needs no device). *nodes_out / *tris_out are
- * malloc'ed copies of the 128-B 4-wide node and 48-B triangle records (layout: rbrt_amd/csrc/device_types.h);
- * release them with rbrt_hip_free_host. */
-int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
-                            size_t* n_tris, uint32_t* max_depth, float* max_e12);
-void rbrt_hip_free_host(void* p);
-/* Diagnostic: the GPU-side BVH builder alone (rbrt_amd/csrc/bvh_device.hip; rbrt_hip_scene_create uses it for meshes of
- * 131,072 entries or more, $RBRT_BVH_BUILDER = host | device overrides). Same outputs as rbrt_hip_bvh_build_host;
- * *built = 0 when the builder declined the mesh (fewer than 8 entries, <= 4 indexed triangles, or a tree beyond the
- * traversal's depth budget), in which case scene_create falls back to the host builder. */
-int rbrt_hip_bvh_build_device(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
-                              size_t* n_tris, uint32_t* max_depth, float* max_e12, int* built);
-
 /* ---- misc ---------------------------------------------------------------------------------- */
 
 void rbrt_render_opts_default(rbrt_render_opts_t* opts); /* spp = 5 (src/main.rs:47), seed = 1 */
 int rbrt_hip_device_count(void);                         /* >= 0, or negative status */
 const char* rbrt_hip_last_error(void);
 int rbrt_hip_abi_version(void);
-/* Kernel timing with HIP events recorded on the launch stream around every trace-kernel launch
- * (and the resolve kernel after it). set_timing(scene, 1) starts / restarts the accumulation;
- * kernel_ms sums the durations of all launches since then (it synchronises on the last event) and
- * returns how many trace launches that was. */
-int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* scene, int enable);
-int rbrt_hip_scene_kernel_ms(rbrt_hip_scene_t* scene, float* trace_ms_total, float* resolve_ms_total,
-                             uint32_t* n_trace_launches);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,102 @@
+/*
+ * rbrt_hip_debug.h — test hooks, diagnostics and lab knobs of librbrt_hip.so.
+ *
+ * NOT part of the drop-in boundary (that is rbrt_hip.h, which a Rust host binds): nothing here is needed to
+ * replace rbrt_lib::render_scene (rbrt_lib/src/lib.rs:75-79). These entry points exist so that the parity tests
+ * can look inside the hot path (one Scene::hit, one scatter event, the BVH builders alone, the two forms of the
+ * mesh gate) and so that bench.py can time the trace kernel with events on the stream it really runs on.
+ *
+ * Lab knobs (environment, read by rbrt_hip_scene_create ONLY when RBRT_HIP_LAB=1; a value outside the stated range
+ * makes scene_create fail with RBRT_ERR_INVALID_ARG instead of being clamped; none of them changes the image):
+ *   RBRT_POOL=128|256            path slots per wave            RBRT_LDS_STACK=1..64       stack entries per lane in LDS
+ *   RBRT_Y_LOW / RBRT_Y_HIGH=1..64, RBRT_Y_HIGH_PARKED=1..256   refill water marks of the traversal lanes
+ *   RBRT_LEAF_ROUND=1..64, RBRT_LEAF_LEAVES=1..128              when a leaf round runs
+ *   RBRT_SHARE_IDLE=0..64, RBRT_SHARE_BELOW=<samples>           shared traversals in the drain
+ *   RBRT_DRAIN_MODE=<bits 0,1,3>  RBRT_WORK_STRIPES, RBRT_WORK_STRIPES_OVERLAP=<chunks, power of two>
+ *   RBRT_SHADE_ROUNDS=1..64, RBRT_SHADE_CONT_MIN=1..64          register-resident shading rounds
+ *   RBRT_WAVES_PER_CU=1..32      RBRT_PIPELINE=0..8             RBRT_LANE_PRIORITY=low|default|high
+ *   RBRT_BVH_DEVICE_MIN=<entries>, RBRT_BVH_DEVICE_ALGO=ploc|lbvh   RBRT_POISON_SAMPLES=1 (tests)
+ */
+#ifndef RBRT_HIP_DEBUG_H
+#define RBRT_HIP_DEBUG_H
+
+#include "rbrt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* How the last rbrt_hip_render_device call on this scene split its samples: samples per batch (one trace launch
+ * each, sized to the workspace cap $RBRT_HIP_WORKSPACE_MB and to the kernel's 32-bit work-item numbers) and the
+ * number of batches. Diagnostic. */
+int rbrt_hip_scene_last_batching(rbrt_hip_scene_t* scene, uint32_t* samples_per_batch, uint32_t* n_batches);
+
+/* Test / diagnostic hook for Scene::hit (scene.rs:19-43): closest hit of n rays against the
+ * resident scene. Host arrays. rays = n x {ox,oy,oz,dx,dy,dz}. Outputs (each may be NULL):
+ *   out_t[n]      ray parameter of the winning object (NaN on miss)
+ *   out_obj[n]    -1 on miss, sphere index in [0,n_spheres), or n_spheres + mesh index
+ *   out_tri[n]    winning triangle index (reference numbering) for mesh hits, else -1
+ *   out_dist[n]   dist_from_ray_orig of the winner (lib.rs:35)                            */
+int rbrt_hip_trace_rays(rbrt_hip_scene_t* scene, const float* rays, size_t n, float min_dist,
+                        float max_dist, float* out_t, int32_t* out_obj, int32_t* out_tri,
+                        float* out_dist);
+
+/* Test hook for BoundingBox::hit (aabbox.rs:28-58): n rays against the box [lo, hi], decided by the division-free
+ * form the megakernel uses (out_fast[n]) and by the verbatim form with six IEEE divisions (out_exact[n]); the two
+ * must agree for every input. Host arrays. */
+int rbrt_hip_selftest_gate(const float lo[3], const float hi[3], const float* rays, size_t n, uint8_t* out_fast,
+                           uint8_t* out_exact);
+
+/* Test hook: the image needs correctly rounded sqrt and / (vec3.rs:111-126); the kernels use short forms of them when
+ * every lane's operands are in the everyday range (kernels.hip "IEEE square root and division, the short way"). Runs n
+ * pseudo-random operands through the short forms and the compiler's: counts[0] / counts[1] = differing sqrt results /
+ * normalize components (must be 0), counts[2] = lanes that really took the short path. */
+int rbrt_hip_selftest_ieee(uint64_t seed, size_t n, uint64_t counts[3]);
+
+/* Diagnostic: pass statistics of the persistent megakernel from the last render with
+ * RBRT_FLAG_COLLECT_STATS: out[0..5] passes per kind (empty, traverse, terminate, lambertian, metal,
+ * dielectric), out[6..11] path slots handled per kind, out[12] traversal wave-steps, out[13] busy
+ * lane-steps, out[14] refill rounds, out[15] scheduling rounds. */
+int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* scene, uint64_t* out, size_t n);
+
+/* Diagnostic: run the host-side BVH builder alone (needs no device). *nodes_out / *tris_out are
+ * malloc'ed copies of the 128-B 4-wide node and 48-B triangle records (layout: rbrt_amd/csrc/device_types.h);
+ * release them with rbrt_hip_free_host. */
+int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
+                            size_t* n_tris, uint32_t* max_depth, float* max_e12);
+void rbrt_hip_free_host(void* p);
+/* Diagnostic: the GPU-side BVH builder alone (rbrt_amd/csrc/bvh_device.hip; rbrt_hip_scene_create uses it for meshes of
+ * 131,072 entries or more, $RBRT_BVH_BUILDER = host | device overrides). Same outputs as rbrt_hip_bvh_build_host;
+ * *built = 0 when the builder declined the mesh (fewer than 8 entries, <= 4 indexed triangles, or a tree beyond the
+ * traversal's depth budget), in which case scene_create falls back to the host builder. */
+int rbrt_hip_bvh_build_device(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
+                              size_t* n_tris, uint32_t* max_depth, float* max_e12, int* built);
+
+/* Test hook for RayScattering::scatter (materials.rs:4-12; lambertian.rs:11-24, metal.rs:12-25, dielectric.rs:11-85):
+ * n independent scatter events on the device code the megakernel shades with. Event i: incoming ray direction
+ * in_dir[i], hit point p[i], hit normal normal[i] (as the intersection routines hand it over: unnormalised for
+ * spheres), material mats[i], and the state of its random stream rng_state[i] = {s0, s1} (the xoroshiro64** words
+ * of DESIGN.md "RNG contract"; the draws are consumed in the reference's order). Outputs (each may be NULL):
+ *   out_dir[n][3]      direction of the scattered ray (its origin is p)
+ *   out_ok[n]          the reference's bool (metal.rs:25 can return false)
+ *   out_rng_state[n]   the stream's state afterwards (how many draws were consumed)
+ * Host arrays. So that an image mismatch can be localised to one material without bisecting images. */
+int rbrt_hip_debug_scatter(const rbrt_material_t* mats, const float* in_dir, const float* p, const float* normal,
+                           const uint32_t* rng_state, size_t n, float* out_dir, uint8_t* out_ok, uint32_t* out_rng_state);
+
+/* Kernel timing with HIP events recorded on the launch stream around every trace-kernel launch
+ * (and the resolve kernel after it). set_timing(scene, 1) starts / restarts the accumulation;
+ * kernel_ms sums the durations of all launches since then (it synchronises on the last event) and
+ * returns how many trace launches that was. */
+int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* scene, int enable);
+int rbrt_hip_scene_kernel_ms(rbrt_hip_scene_t* scene, float* trace_ms_total, float* resolve_ms_total,
+                             uint32_t* n_trace_launches);
+
+/* Trace launches since set_timing(scene, 1), by grid: a launch issued while another launch of the scene is still
+ * running takes half of the wave slots (rbrt_hip_scene_set_pipeline), so the mix depends on host timing. */
+int rbrt_hip_scene_launch_mix(rbrt_hip_scene_t* scene, uint32_t* n_full_grid, uint32_t* n_half_grid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBRT_HIP_DEBUG_H */

@@ -93,6 +93,17 @@ class HipScene:
         abi.check(self._lib.rbrt_hip_scene_kernel_ms(self._h, C.byref(t), C.byref(r), C.byref(n)))
         return t.value, r.value, n.value
 
+    def launch_mix(self):
+        """(full-grid, half-grid) trace launches since set_timing(True) (rbrt_hip_scene_launch_mix)."""
+        a, b = C.c_uint32(), C.c_uint32()
+        abi.check(self._lib.rbrt_hip_scene_launch_mix(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def info(self) -> dict:
+        i = abi.SceneInfo()
+        abi.check(self._lib.rbrt_hip_scene_info(self._h, C.byref(i)))
+        return {k: int(getattr(i, k)) for k, _ in abi.SceneInfo._fields_}
+
     def check(self):
         """Synchronise and raise RbrtError if a kernel flagged a NaN sphere discriminant (sphere.rs:33) or corrupt
         path state since the last check (rbrt_hip_scene_check)."""

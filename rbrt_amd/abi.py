@@ -111,7 +111,16 @@ class Stats(C.Structure):
     ]
 
 
-# every symbol include/rbrt_hip.h declares: name -> (restype, argtypes)
+class SceneInfo(C.Structure):
+    _fields_ = [
+        ("n_spheres", C.c_uint32), ("n_meshes", C.c_uint32),
+        ("n_meshes_device_built", C.c_uint32), ("bvh_stack_need", C.c_uint32),
+        ("n_nodes", C.c_uint64), ("n_triangles", C.c_uint64),
+        ("trace_waves", C.c_uint32), ("lds_bytes_per_wave", C.c_uint32),
+    ]
+
+
+# every symbol include/rbrt_hip.h (the drop-in boundary) declares: name -> (restype, argtypes)
 HIP_SYMBOLS = {
     "rbrt_hip_render": (C.c_int, [C.POINTER(Camera), C.POINTER(Scene), C.POINTER(RenderOpts), f32p, u8p]),
     "rbrt_hip_scene_create": (C.c_int, [C.POINTER(Scene), C.c_int, C.POINTER(C.c_void_p)]),
@@ -127,6 +136,15 @@ HIP_SYMBOLS = {
                                                 C.c_size_t, C.c_void_p, C.c_void_p]),
     "rbrt_hip_scene_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rbrt_hip_scene_check": (C.c_int, [C.c_void_p]),
+    "rbrt_render_opts_default": (None, [C.POINTER(RenderOpts)]),
+    "rbrt_hip_device_count": (C.c_int, []),
+    "rbrt_hip_last_error": (C.c_char_p, []),
+    "rbrt_hip_abi_version": (C.c_int, []),
+    "rbrt_hip_scene_set_pipeline": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rbrt_hip_scene_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
+}
+# ... and include/rbrt_hip_debug.h (test hooks and diagnostics, same library)
+DEBUG_SYMBOLS = {
     "rbrt_hip_scene_last_batching": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rbrt_hip_trace_rays": (C.c_int, [C.c_void_p, f32p, C.c_size_t, C.c_float, C.c_float, f32p, i32p, i32p, f32p]),
     "rbrt_hip_selftest_ieee": (C.c_int, [C.c_uint64, C.c_size_t, C.POINTER(C.c_uint64)]),
@@ -139,13 +157,11 @@ HIP_SYMBOLS = {
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
                                             f32p, C.POINTER(C.c_int)]),
     "rbrt_hip_scene_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]),
-    "rbrt_render_opts_default": (None, [C.POINTER(RenderOpts)]),
-    "rbrt_hip_device_count": (C.c_int, []),
-    "rbrt_hip_last_error": (C.c_char_p, []),
-    "rbrt_hip_abi_version": (C.c_int, []),
     "rbrt_hip_scene_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
-    "rbrt_hip_scene_set_pipeline": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rbrt_hip_scene_kernel_ms": (C.c_int, [C.c_void_p, f32p, f32p, C.POINTER(C.c_uint32)]),
+    "rbrt_hip_scene_launch_mix": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rbrt_hip_debug_scatter": (C.c_int, [C.POINTER(Material), f32p, f32p, f32p, C.POINTER(C.c_uint32), C.c_size_t, f32p, u8p,
+                                        C.POINTER(C.c_uint32)]),
 }
 
 
@@ -194,7 +210,7 @@ def load_hip() -> C.CDLL:
             "rbrt_amd has no CPU or pure-Python render path.")
     _preload_torch_hip_runtime()
     lib = C.CDLL(str(lib_path), mode=getattr(os, "RTLD_NOW", 2))
-    for name, (res, args) in HIP_SYMBOLS.items():
+    for name, (res, args) in {**HIP_SYMBOLS, **DEBUG_SYMBOLS}.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args

@@ -14,6 +14,7 @@
 #include "bvh.h"
 #include "bvh_device.h"
 #include "device_types.h"
+#include "../../include/rbrt_hip_debug.h"
 
 namespace rbrt {
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats, bool share,
@@ -28,6 +29,8 @@ hipError_t launch_trace_rays(const TraceParams& P, const float* rays, size_t n, 
                              int32_t* out_tri, float* out_dist, hipStream_t stream);
 hipError_t launch_gate_selftest(const float* d_box, const float* d_rays, size_t n, uint8_t* d_fast, uint8_t* d_exact);
 hipError_t launch_ieee_selftest(uint64_t seed, size_t n, unsigned long long* d_counts);
+hipError_t launch_scatter_debug(const DevMaterial* d_mats, const float* d_in_dir, const float* d_p, const float* d_normal,
+                                 const uint32_t* d_rng, size_t n, float* d_out_dir, uint8_t* d_out_ok, uint32_t* d_out_rng);
 uint64_t host_splitmix64(uint64_t x);
 }  // namespace rbrt
 
@@ -55,6 +58,28 @@ int fail(int code, const std::string& msg) {
 
 uint32_t local_tiles_of(uint32_t n_tiles, uint32_t rank, uint32_t world) {
     return rank < n_tiles ? (n_tiles - rank + world - 1u) / world : 0u;
+}
+
+// Lab knobs (include/rbrt_hip_debug.h): environment variables that tune the kernels' scheduling are read only when
+// RBRT_HIP_LAB=1, and a value outside its range is an error, not something to clamp silently.
+const char* lab_env(const char* name) {
+    const char* lab = std::getenv("RBRT_HIP_LAB");
+    return (lab && lab[0] == '1') ? std::getenv(name) : nullptr;
+}
+// dst = $name when set (lab mode); false + message when it is not an integer in [lo, hi] (or not in `allowed`, if given)
+bool lab_u32(const char* name, long long lo, long long hi, uint32_t& dst, std::string& err, std::initializer_list<long long> allowed = {}) {
+    const char* e = lab_env(name);
+    if (!e) return true;
+    char* end = nullptr;
+    const long long v = std::strtoll(e, &end, 10);
+    bool ok = end != e && *end == '\0' && v >= lo && v <= hi;
+    if (ok && allowed.size() != 0) ok = std::find(allowed.begin(), allowed.end(), v) != allowed.end();
+    if (!ok) {
+        err = std::string("lab knob ") + name + "=" + e + " is not valid (see include/rbrt_hip_debug.h)";
+        return false;
+    }
+    dst = uint32_t(v);
+    return true;
 }
 
 size_t workspace_cap_bytes() {
@@ -133,6 +158,7 @@ struct rbrt_hip_scene {
     size_t events_used = 0;
     bool timing_overflow = false;  // more than kMaxTimedLaunches launches since set_timing: the rest go untimed
     uint32_t last_batch = 0, last_n_batches = 0;  // sample batching of the last render (rbrt_hip_scene_last_batching)
+    uint32_t n_full_grid = 0, n_half_grid = 0;    // trace launches since set_timing(1), by grid size (rbrt_hip_scene_kernel_ms_ex)
     uint64_t total_nodes = 0, total_tris = 0;
     uint32_t n_device_built = 0;  // meshes whose BVH the GPU built
 };
@@ -178,7 +204,7 @@ hipError_t device_build_mesh(const rbrt_mesh_t& m, BvhTri* d_tris_out, uint32_t 
         const DeviceMeshSoa soa = {d_soa, d_soa + stride, d_soa + 2 * stride, d_soa + 3 * stride, d_soa + 4 * stride,
                                    d_soa + 5 * stride, d_soa + 6 * stride, d_soa + 7 * stride, d_soa + 8 * stride, d_pad};
         int algo = 0;
-        if (const char* a = std::getenv("RBRT_BVH_DEVICE_ALGO")) algo = !std::strcmp(a, "lbvh") ? 1 : 0;
+        if (const char* a = lab_env("RBRT_BVH_DEVICE_ALGO")) algo = !std::strcmp(a, "lbvh") ? 1 : 0;
         e = build_bvh_device(soa, m.n_total, d_tris_out, tri_base, r, nullptr, algo);
     }
     if (e == hipSuccess && r->ok && d_normals)
@@ -206,7 +232,9 @@ bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane*
     bool busy = false;
     for (const auto& L : s->lanes)
         if (&L != mine && L.in_use && L.ev_traced && hipEventQuery(L.ev_traced) == hipErrorNotReady) busy = true;
-    (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure: keep it out of the next launch check)
+    // (hipErrorNotReady is an answer, not a failure: keep it out of the next launch check -- and clear the error state
+    // only then, so that an unrelated sticky error still reaches whoever checks next)
+    if (busy) (void)hipGetLastError();
     return busy;
 }
 
@@ -251,7 +279,7 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         // then win the wave slots a finishing trace wave frees, ahead of the next trace launch's waves.
         int prio_low = 0, prio_high = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: low >= high)
-        if (const char* pe = std::getenv("RBRT_LANE_PRIORITY")) prio_low = !std::strcmp(pe, "default") ? 0 : !std::strcmp(pe, "high") ? prio_high : prio_low;
+        if (const char* pe = lab_env("RBRT_LANE_PRIORITY")) prio_low = !std::strcmp(pe, "default") ? 0 : !std::strcmp(pe, "high") ? prio_high : prio_low;
         hipError_t e = hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, prio_low);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_traced, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_resolved, hipEventDisableTiming);
@@ -455,7 +483,10 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
     int builder_mode = 0;  // 0 auto, 1 host, 2 device
     if (const char* e = std::getenv("RBRT_BVH_BUILDER")) builder_mode = !std::strcmp(e, "host") ? 1 : !std::strcmp(e, "device") ? 2 : 0;
     uint32_t device_min_tris = 131072;
-    if (const char* e = std::getenv("RBRT_BVH_DEVICE_MIN")) device_min_tris = uint32_t(std::max(0, std::atoi(e)));
+    {
+        std::string err;
+        if (!lab_u32("RBRT_BVH_DEVICE_MIN", 0, 1ll << 30, device_min_tris, err)) return bail(fail(RBRT_ERR_INVALID_ARG, err));
+    }
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         const rbrt_mesh_t& m = scene->meshes[i];
         put_mat(scene->n_spheres + i, m.mat);
@@ -538,74 +569,36 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(RBRT_ERR_HIP, "hipGetDeviceProperties failed"));
         int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (const char* e = std::getenv("RBRT_POOL")) {
-            int v = std::atoi(e);
-            if (v == 128 || v == 256) s->pool = uint32_t(v);
-        }
-        if (const char* e = std::getenv("RBRT_LDS_STACK")) {
-            int v = std::atoi(e);
-            if (v >= 1 && v <= kStackMax) s->stack_entries = uint32_t(v);
-        }
+        std::string err;
+        uint32_t waves_per_cu = 0, poison = 0, stripes = s->work_stripes, stripes_overlap = s->work_stripes_overlap;
+        const bool knobs_ok =
+            lab_u32("RBRT_POOL", 128, 256, s->pool, err, {128, 256}) && lab_u32("RBRT_LDS_STACK", 1, kStackMax, s->stack_entries, err) &&
+            lab_u32("RBRT_LEAF_ROUND", 1, 64, s->leaf_round, err) && lab_u32("RBRT_Y_HIGH", 1, 64, s->y_high_water, err) &&
+            lab_u32("RBRT_Y_HIGH_PARKED", 1, 256, s->y_high_min_parked, err) && lab_u32("RBRT_Y_LOW", 1, 64, s->y_low_water, err) &&
+            lab_u32("RBRT_WAVES_PER_CU", 1, 32, waves_per_cu, err) && lab_u32("RBRT_LEAF_LEAVES", 1, 128, s->leaf_leaves, err) &&
+            lab_u32("RBRT_SHARE_IDLE", 0, 64, s->share_idle, err) && lab_u32("RBRT_WORK_STRIPES", 0, 65536, stripes, err) &&
+            lab_u32("RBRT_WORK_STRIPES_OVERLAP", 0, 65536, stripes_overlap, err) && lab_u32("RBRT_DRAIN_MODE", 0, 11, s->drain_mode, err) &&
+            lab_u32("RBRT_SHADE_ROUNDS", 1, kMaxShadeRounds, s->shade_rounds, err) &&
+            lab_u32("RBRT_SHADE_CONT_MIN", 1, 64, s->shade_cont_min, err) && lab_u32("RBRT_PIPELINE", 0, kMaxPipeline, s->pipeline, err) &&
+            lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err);
+        if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
+        if ((stripes & (stripes - 1u)) != 0u || (stripes_overlap & (stripes_overlap - 1u)) != 0u)  // the kernel shifts
+            return bail(fail(RBRT_ERR_INVALID_ARG, "lab knob RBRT_WORK_STRIPES / RBRT_WORK_STRIPES_OVERLAP must be 0 or a power of two"));
+        s->work_stripes = stripes, s->work_stripes_overlap = stripes_overlap;
+        s->drain_mode &= 11u;
+        s->poison_samples = poison != 0;
+        if (const char* e = lab_env("RBRT_SHARE_BELOW")) s->share_below = std::strtoull(e, nullptr, 10);
         if (s->stack_entries > s->stack_need) s->stack_entries = s->stack_need;
-        if (const char* e = std::getenv("RBRT_LEAF_ROUND")) {
-            int v = std::atoi(e);
-            if (v >= 1 && v <= 64) s->leaf_round = uint32_t(v);
-        }
-        if (const char* e = std::getenv("RBRT_Y_HIGH")) {
-            int v = std::atoi(e);
-            if (v >= 1 && v <= 64) s->y_high_water = uint32_t(v);
-        }
-        if (const char* e = std::getenv("RBRT_Y_HIGH_PARKED")) {
-            int v = std::atoi(e);
-            if (v >= 1 && v <= 256) s->y_high_min_parked = uint32_t(v);
-        }
-        if (const char* e = std::getenv("RBRT_Y_LOW")) {
-            int v = std::atoi(e);
-            if (v >= 1 && v <= 64) s->y_low_water = uint32_t(v);
-        }
         // resident waves per CU: LDS-limited (160 KiB per CU), at most 5 per SIMD (VGPR budget)
         int per_cu = int((160u * 1024u) / megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes));
         if (per_cu > 20) per_cu = 20;
         if (per_cu < 1) per_cu = 1;
-        if (const char* e = std::getenv("RBRT_WAVES_PER_CU")) {
-            int v = std::atoi(e);
-            if (v > 0 && v <= 32) per_cu = v, s->waves_fixed = true;
-        }
+        if (waves_per_cu != 0) per_cu = int(waves_per_cu), s->waves_fixed = true;
         s->n_waves = uint32_t(cus * per_cu);
         s->n_cus = uint32_t(cus);
-        if (const char* e = std::getenv("RBRT_LEAF_LEAVES")) {
-            int v = std::atoi(e);
-            if (v >= 1 && v <= 128) s->leaf_leaves = uint32_t(v);
-        }
-        if (const char* e = std::getenv("RBRT_SHARE_IDLE")) {
-            int v = std::atoi(e);
-            if (v >= 0 && v <= 64) s->share_idle = uint32_t(v);
-        }
-        if (const char* e = std::getenv("RBRT_SHARE_BELOW")) s->share_below = std::strtoull(e, nullptr, 10);
-        const auto pow2_below = [](int v) -> uint32_t {  // stripes are a power of two (the kernel shifts)
-            uint32_t p = 0;
-            for (uint32_t q = 1; v > 0 && q <= uint32_t(v) && q <= 65536u; q <<= 1) p = q;
-            return p;
-        };
-        if (const char* e = std::getenv("RBRT_WORK_STRIPES")) s->work_stripes = pow2_below(std::atoi(e));
-        if (const char* e = std::getenv("RBRT_WORK_STRIPES_OVERLAP")) s->work_stripes_overlap = pow2_below(std::atoi(e));
-        if (const char* e = std::getenv("RBRT_DRAIN_MODE")) s->drain_mode = uint32_t(std::atoi(e)) & 11u;
-        if (const char* e = std::getenv("RBRT_SHADE_ROUNDS")) {
-            int v = std::atoi(e);
-            if (v >= 1 && v <= int(kMaxShadeRounds)) s->shade_rounds = uint32_t(v);
-        }
-        if (const char* e = std::getenv("RBRT_SHADE_CONT_MIN")) {
-            int v = std::atoi(e);
-            if (v >= 1 && v <= 64) s->shade_cont_min = uint32_t(v);
-        }
         s->scratch_waves = s->n_waves;  // per-wave scratch is indexed by workgroup (= wave); no grid is larger than n_waves
-        if (const char* e = std::getenv("RBRT_PIPELINE")) {
-            int v = std::atoi(e);
-            if (v >= 0 && v <= int(kMaxPipeline)) s->pipeline = uint32_t(v);
-        }
         // all lanes up front: rbrt_hip_render_device then never allocates lanes (which synchronises the device)
         if (int rc = ensure_lanes(s, std::max(kLanesAtCreate, s->pipeline))) return bail(rc);
-        if (const char* e = std::getenv("RBRT_POISON_SAMPLES")) s->poison_samples = e[0] == '1';
     }
     *out = s;
     return RBRT_OK;
@@ -633,6 +626,16 @@ int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* s, int enable) {
     s->timing = enable != 0;
     s->timing_overflow = false;
     s->events_used = 0;
+    s->n_full_grid = s->n_half_grid = 0;
+    return RBRT_OK;
+}
+
+// How the launches since set_timing(1) were issued: the grid of a launch depends on whether another one was still
+// running when it was issued (grid_for), i.e. on host timing; A/B sweeps read the mix beside the times.
+int rbrt_hip_scene_launch_mix(rbrt_hip_scene_t* s, uint32_t* n_full_grid, uint32_t* n_half_grid) {
+    if (!s) return fail(RBRT_ERR_INVALID_ARG, "null scene");
+    if (n_full_grid) *n_full_grid = s->n_full_grid;
+    if (n_half_grid) *n_half_grid = s->n_half_grid;
     return RBRT_OK;
 }
 
@@ -799,8 +802,9 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
-        HIP_TRY(launch_trace_megakernel(P, stats ? s->n_waves : grid_for(s, overlapped), s->pool, stats,
-                                        s->share_idle != 0u && P.n_items < s->share_below, ts));
+        const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped);
+        (grid < s->n_waves ? s->n_half_grid : s->n_full_grid) += 1;
+        HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, s->share_idle != 0u && P.n_items < s->share_below, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
         if (piped) {
             HIP_TRY(hipEventRecord(L.ev_traced, ts));
@@ -882,6 +886,18 @@ int rbrt_hip_scene_check(rbrt_hip_scene_t* s) {
     if (nan)
         return fail(RBRT_ERR_NAN, "a sphere discriminant was NaN " + std::to_string(nan) +
                                       " times (the reference panics: sphere.rs:33); those rays were treated as misses");
+    return RBRT_OK;
+}
+
+int rbrt_hip_scene_info(rbrt_hip_scene_t* s, rbrt_hip_scene_info_t* out) {
+    if (!s || !out) return fail(RBRT_ERR_INVALID_ARG, "scene_info: null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->n_spheres = s->n_spheres, out->n_meshes = s->n_meshes;
+    out->n_meshes_device_built = s->n_device_built;
+    out->bvh_stack_need = s->stack_need;
+    out->n_nodes = s->total_nodes, out->n_triangles = s->total_tris;
+    out->trace_waves = s->n_waves;
+    out->lds_bytes_per_wave = uint32_t(megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes));
     return RBRT_OK;
 }
 
@@ -1088,6 +1104,50 @@ int rbrt_hip_selftest_ieee(uint64_t seed, size_t n, uint64_t counts[3]) {
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RBRT_ERR_HIP, std::string("selftest_ieee: ") + hipGetErrorString(e));
     for (int k = 0; k < 3; ++k) counts[k] = h[k];
+    return RBRT_OK;
+}
+
+// Test hook: n scatter events (materials.rs:4-12) on the device functions the shading passes use. Host arrays.
+int rbrt_hip_debug_scatter(const rbrt_material_t* mats, const float* in_dir, const float* p, const float* normal,
+                           const uint32_t* rng_state, size_t n, float* out_dir, uint8_t* out_ok, uint32_t* out_rng_state) {
+    if (n == 0) return RBRT_OK;
+    if (!mats || !in_dir || !p || !normal || !rng_state) return fail(RBRT_ERR_INVALID_ARG, "debug_scatter: null argument");
+    std::vector<DevMaterial> hm(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (int rc = check_material(mats[i])) return rc;
+        for (int c = 0; c < 3; ++c) hm[i].albedo[c] = mats[i].albedo[c];
+        hm[i].param = mats[i].param, hm[i].kind = mats[i].kind;
+    }
+    if (int rc = ensure_device(0)) return rc;
+    DevMaterial* d_m = nullptr;
+    float *d_in = nullptr, *d_p = nullptr, *d_n = nullptr, *d_out = nullptr;
+    uint32_t *d_rng = nullptr, *d_rng_out = nullptr;
+    uint8_t* d_ok = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_m), (void)hipFree(d_in), (void)hipFree(d_p), (void)hipFree(d_n), (void)hipFree(d_out), (void)hipFree(d_rng),
+            (void)hipFree(d_rng_out), (void)hipFree(d_ok);
+    };
+    const size_t v3 = n * 3 * sizeof(float), st = n * 2 * sizeof(uint32_t);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_m), n * sizeof(DevMaterial));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_in), v3);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_p), v3);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_n), v3);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), v3);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rng), st);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rng_out), st);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ok), n);
+    if (e == hipSuccess) e = hipMemcpy(d_m, hm.data(), n * sizeof(DevMaterial), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in_dir, v3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_p, p, v3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_n, normal, v3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_rng, rng_state, st, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_scatter_debug(d_m, d_in, d_p, d_n, d_rng, n, d_out, d_ok, d_rng_out);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && out_dir) e = hipMemcpy(out_dir, d_out, v3, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_ok) e = hipMemcpy(out_ok, d_ok, n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_rng_state) e = hipMemcpy(out_rng_state, d_rng_out, st, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(RBRT_ERR_HIP, std::string("debug_scatter: ") + hipGetErrorString(e));
     return RBRT_OK;
 }
 

@@ -740,6 +740,22 @@ __global__ __launch_bounds__(kBlock) void gate_selftest_kernel(const float* __re
     out_exact[i] = bbox_gate(box, box + 3, o, d) ? 1 : 0;
 }
 
+// Test hook (rbrt_hip_debug_scatter): one RayScattering::scatter event per thread, through the same device functions
+// the megakernel's shading passes are built from (scatter / reflect / refract / schlick / random_point_in_unit_sphere).
+__global__ __launch_bounds__(kBlock) void scatter_debug_kernel(const DevMaterial* __restrict__ mats, const float* __restrict__ in_dir,
+                                                                const float* __restrict__ p, const float* __restrict__ normal,
+                                                                const uint32_t* __restrict__ rng_state, size_t n, float* out_dir,
+                                                                uint8_t* out_ok, uint32_t* out_rng_state) {
+    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Rng rng = {rng_state[2 * i], rng_state[2 * i + 1]};
+    V3 nd = mk(0.0f, 0.0f, 0.0f);
+    const bool ok = scatter(mats[i], mk(in_dir + 3 * i), mk(p + 3 * i), mk(normal + 3 * i), rng, nd);
+    if (out_dir) out_dir[3 * i] = nd.x, out_dir[3 * i + 1] = nd.y, out_dir[3 * i + 2] = nd.z;
+    if (out_ok) out_ok[i] = ok ? 1 : 0;
+    if (out_rng_state) out_rng_state[2 * i] = rng.s0, out_rng_state[2 * i + 1] = rng.s1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Launch wrappers (called from api.cpp, which is plain C++)
 // ---------------------------------------------------------------------------------------------
@@ -817,7 +833,13 @@ hipError_t launch_ieee_selftest(uint64_t seed, size_t n, unsigned long long* d_c
     hipLaunchKernelGGL(ieee_selftest_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, seed, n, d_counts);
     return hipGetLastError();
 }
-
+hipError_t launch_scatter_debug(const DevMaterial* d_mats, const float* d_in_dir, const float* d_p, const float* d_normal,
+                                 const uint32_t* d_rng, size_t n, float* d_out_dir, uint8_t* d_out_ok, uint32_t* d_out_rng) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_debug_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, d_mats, d_in_dir, d_p,
+                       d_normal, d_rng, n, d_out_dir, d_out_ok, d_out_rng);
+    return hipGetLastError();
+}
 
 uint64_t host_splitmix64(uint64_t x) { return splitmix64(x); }
 

@@ -163,6 +163,19 @@ struct ImageBuffer {
 };
 void write_png(const std::string& path, const uint8_t* rgb, uint32_t width, uint32_t height);
 
+// What render_scene measured (wall clock; with several GPUs the slowest rank's figure). The reference prints only
+// "Starting rendering..." and a progress line (lib.rs:80,105-110); a 4 ms render needs more than that to be understood.
+struct RenderReport {
+    double upload_build_s = 0;   // scene upload + BVH build (rbrt_hip_scene_create) + buffers
+    double render_s = 0;         // all passes, incl. checkpoint writes
+    double gather_s = 0;         // image to host memory (and the merge of the ranks' tiles)
+    uint32_t passes = 0, pass_spp = 0, checkpoints_written = 0, resumed_from_sample = 0;
+    int n_gpus = 1;
+    std::string gather = "none";    // none (one GPU) | host | rccl
+    std::string builder = "none";   // who built the BVHs: host | device | mixed | none (no mesh)
+    uint64_t bvh_nodes = 0, bvh_triangles = 0;
+};
+
 struct RenderConfig {  // additions that the reference hard-codes or lacks
     uint64_t seed = 1;
     int n_gpus = 1;
@@ -170,7 +183,11 @@ struct RenderConfig {  // additions that the reference hard-codes or lacks
     uint32_t pass_spp = 0;            // samples per pass (progress line / checkpoint granularity); 0 = automatic
     std::string checkpoint_path;      // non-empty: resume from / write per-pass checkpoints of the running sums here
     int checkpoint_every = 1;         // ... after every n-th pass
-    std::string gather = "rccl";      // multi-GPU: "rccl" (device-to-device over xGMI) or "host" (merge through host memory)
+    // multi-GPU: "host" (every rank copies its tiles over its own PCIe link, merged on the host: the image has to
+    // end up there anyway) or "rccl" (device-to-device over xGMI to GPU 0, then one copy; librccl is dlopen'ed)
+    std::string gather = "host";
+    bool oversubscribe = false;       // rank r runs on device r % n_devices (rehearsal of N ranks on fewer GPUs; host gather only)
+    RenderReport* report = nullptr;   // filled in when not null
 };
 // rbrt_lib::render_scene (lib.rs:75-79): blocks until the image is complete. Runs on the GPU(s)
 // through the C ABI; there is no CPU path.

@@ -7,13 +7,22 @@
 // progress line is printed (lib.rs:105-110 prints one per finished column; here a pass is the unit of progress) and,
 // if asked for, a checkpoint is written: the running sums of every rank plus the number of samples done. A later run
 // with the same scene, size, sample count, seed and GPU count resumes from it.
-// When all samples are in, the packed fp32 radiance of ranks 1..N-1 goes to rank 0's GPU with ONE grouped RCCL
-// send/recv (each peer over its own xGMI link: SURVEY 8(e)), rank 0 de-interleaves it with rbrt_hip_unpack_tiles and
-// quantises; only then does the image cross PCIe. `--gather host` keeps the staging-through-host merge as a fallback.
+// When all samples are in, the image has to reach HOST memory (the caller saves a file: src/main.rs:86). Default
+// (`--gather host`): every rank copies its own packed tiles over its own PCIe link and de-interleaves them on the host --
+// N parallel transfers of 1/N of the image each. `--gather rccl`: the packed fp32 radiance of ranks 1..N-1 goes to rank
+// 0's GPU with ONE grouped RCCL send/recv (each peer over its own xGMI link: SURVEY 8(e)), rank 0 de-interleaves it
+// with rbrt_hip_unpack_tiles and quantises, then the whole image crosses ONE PCIe link; that is the shape bench.py's
+// device-resident gather has, kept here for hosts that want the image on GPU 0. librccl is loaded with dlopen the first
+// time that path is asked for: a single-GPU run, or the host gather, does not depend on it.
+// RenderConfig::oversubscribe (CLI --oversubscribe) maps rank r to device r % n_devices, so that every line of the
+// N-rank path except the RCCL calls themselves (which need distinct devices) runs on a box with fewer GPUs.
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is not linked
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -78,6 +87,52 @@ struct CheckpointHeader {
     uint32_t samples_done, reserved;
 };
 
+// librccl, loaded on first use (`--gather rccl` with more than one GPU).
+struct RcclApi {
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    void* handle = nullptr;
+
+    static const RcclApi& get() {  // throws rbrt::Error when the library or a symbol is missing
+        static const RcclApi api = load();
+        return api;
+    }
+
+  private:
+    static RcclApi load() {
+        RcclApi a;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            a.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.handle) break;
+        }
+        if (!a.handle) throw Error(std::string("--gather rccl: cannot load librccl.so (") + dlerror() + "); use --gather host");
+        auto sym = [&](const char* n) {
+            void* p = dlsym(a.handle, n);
+            if (!p) throw Error(std::string("--gather rccl: librccl.so lacks ") + n);
+            return p;
+        };
+        a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(sym("ncclCommInitAll"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(sym("ncclCommAbort"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+        a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+        a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        return a;
+    }
+};
+
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 }  // namespace
 
 ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& scene, const RenderConfig& cfg) {
@@ -100,7 +155,12 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     const int n_dev = rbrt_hip_device_count();
     if (n_dev < 1) throw Error(std::string("no HIP device: ") + rbrt_hip_last_error());
     const int world = cfg.n_gpus < 1 ? 1 : cfg.n_gpus;
-    if (world > n_dev) throw Error("requested " + std::to_string(world) + " GPUs, " + std::to_string(n_dev) + " present");
+    if (world > n_dev && !cfg.oversubscribe)
+        throw Error("requested " + std::to_string(world) + " GPUs, " + std::to_string(n_dev) + " present");
+    const auto device_of = [&](int rank) { return cfg.oversubscribe ? rank % n_dev : rank; };
+    const bool use_rccl = world > 1 && cfg.gather == "rccl";
+    if (use_rccl && world > n_dev)
+        throw Error("--gather rccl needs one GPU per rank (RCCL cannot put two ranks on one device); use --gather host with --oversubscribe");
 
     // samples per pass: what was asked for, else passes of about 2^31 path samples each (a second or so of one GPU's
     // share), so that long renders report progress and can checkpoint; a short render is one pass
@@ -110,7 +170,6 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
         pass_spp = uint32_t(std::min<uint64_t>(num_samples, std::max<uint64_t>(1, (1ull << 31) / per_spp)));
     }
     const uint32_t ckpt_every = cfg.checkpoint_every < 1 ? 1u : uint32_t(cfg.checkpoint_every);
-    const bool use_rccl = world > 1 && cfg.gather != "host";
     // test hook: give up after this many passes of THIS run (as an interrupted run would), checkpoint left on disk
     int stop_after = 0;
     if (const char* e = std::getenv("RBRT_TEST_STOP_AFTER_PASS")) stop_after = std::atoi(e);
@@ -153,70 +212,94 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     }
 
     // ---- RCCL communicators (one process, one communicator per GPU) -----------------------------------------------
+    const RcclApi* rccl = use_rccl ? &RcclApi::get() : nullptr;
     std::vector<ncclComm_t> comms(world, nullptr);
     if (use_rccl) {
         std::vector<int> devs(world);
-        for (int r = 0; r < world; ++r) devs[r] = r;
-        const ncclResult_t rc = ncclCommInitAll(comms.data(), world, devs.data());
-        if (rc != ncclSuccess) throw Error(std::string("ncclCommInitAll: ") + ncclGetErrorString(rc));
+        for (int r = 0; r < world; ++r) devs[r] = device_of(r);
+        const ncclResult_t rc = rccl->CommInitAll(comms.data(), world, devs.data());
+        if (rc != ncclSuccess) throw Error(std::string("ncclCommInitAll: ") + rccl->GetErrorString(rc));
     }
 
+    // Errors: a rank records its first failure under the mutex and raises the counter. Ranks never have to agree on
+    // whether to go on rendering (a failed rank keeps meeting the barriers, idle); they DO have to agree on entering
+    // the RCCL group, and that decision is read between two barriers, when nobody can be failing.
+    std::mutex err_mutex;
     std::vector<std::string> errors(world);
+    std::atomic<int> n_failed{0};
     std::vector<std::vector<float>> ckpt_acc(world);  // host copies of the running sums for the checkpoint writer
     Barrier barrier(world);
-    std::vector<float*> d_slots(1, nullptr);  // rank 0: world equal-size slots of packed tiles
+    float* d_slots = nullptr;  // rank 0, RCCL gather: world equal-size slots of packed tiles
     const size_t slot_pixels = world > 1 ? rbrt_hip_packed_pixels(img.width, img.height, 0, uint32_t(world)) : 0;
-    auto any_error = [&]() {
-        for (const auto& e : errors)
-            if (!e.empty()) return true;
-        return false;
-    };
+    RenderReport rep;
+    rep.n_gpus = world;
+    rep.pass_spp = pass_spp;
+    rep.gather = world > 1 ? (use_rccl ? "rccl" : "host") : "none";
+    std::vector<double> t_setup(world, 0.0), t_render(world, 0.0), t_gather(world, 0.0);
 
     auto worker = [&](int rank) {
         rbrt_hip_scene_t* hs = nullptr;
         float *d_acc = nullptr, *d_rad = nullptr, *d_img = nullptr;
         uint8_t* d_rgb = nullptr;
         hipStream_t stream = nullptr;
+        bool failed = false;  // this rank's own view: it has recorded an error
         auto fail = [&](const std::string& m) {
-            if (errors[rank].empty()) errors[rank] = m.empty() ? "unknown error" : m;
+            if (failed) return;
+            failed = true;
+            {
+                std::lock_guard<std::mutex> lk(err_mutex);
+                errors[rank] = m.empty() ? "unknown error" : m;
+            }
+            n_failed.fetch_add(1);
         };
         auto hip_ok = [&](hipError_t e, const char* what) {
             if (e != hipSuccess) fail(std::string(what) + ": " + hipGetErrorString(e));
             return e == hipSuccess;
         };
+        const auto t_start = std::chrono::steady_clock::now();
         rbrt_render_opts_t o = opts;
         o.tile_rank = uint32_t(rank);
         o.tile_world = uint32_t(world);
+        const int dev = device_of(rank);
         const size_t npix = world > 1 ? rbrt_hip_packed_pixels(img.width, img.height, o.tile_rank, o.tile_world)
                                       : size_t(img.width) * img.height;
-        if (rbrt_hip_scene_create(&view.scene, rank, &hs) != RBRT_OK) fail(rbrt_hip_last_error());
+        if (rbrt_hip_scene_create(&view.scene, dev, &hs) != RBRT_OK) fail(rbrt_hip_last_error());
+        if (hs && rank == 0) {
+            rbrt_hip_scene_info_t info;
+            if (rbrt_hip_scene_info(hs, &info) == RBRT_OK) {
+                rep.bvh_nodes = info.n_nodes, rep.bvh_triangles = info.n_triangles;
+                rep.builder = info.n_meshes == 0 ? "none" : info.n_meshes_device_built == info.n_meshes ? "device" : info.n_meshes_device_built == 0 ? "host" : "mixed";
+            }
+        }
         if (hs && npix) {
-            hip_ok(hipSetDevice(rank), "hipSetDevice");
+            hip_ok(hipSetDevice(dev), "hipSetDevice");
             hip_ok(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
             hip_ok(hipMalloc(reinterpret_cast<void**>(&d_acc), npix * 3 * sizeof(float)), "hipMalloc(sums)");
             hip_ok(hipMalloc(reinterpret_cast<void**>(&d_rad), npix * 3 * sizeof(float)), "hipMalloc(radiance)");
             if (world == 1) hip_ok(hipMalloc(reinterpret_cast<void**>(&d_rgb), npix * 3), "hipMalloc(rgb8)");
-            if (rank == 0 && world > 1) {
-                hip_ok(hipMalloc(reinterpret_cast<void**>(&d_slots[0]), size_t(world) * slot_pixels * 3 * sizeof(float)), "hipMalloc(slots)");
+            if (rank == 0 && use_rccl) {
+                hip_ok(hipMalloc(reinterpret_cast<void**>(&d_slots), size_t(world) * slot_pixels * 3 * sizeof(float)), "hipMalloc(slots)");
                 hip_ok(hipMalloc(reinterpret_cast<void**>(&d_img), n * sizeof(float)), "hipMalloc(image)");
                 hip_ok(hipMalloc(reinterpret_cast<void**>(&d_rgb), n), "hipMalloc(rgb8)");
             }
-            if (errors[rank].empty() && start_sample != 0)
+            if (!failed && start_sample != 0)
                 hip_ok(hipMemcpy(d_acc, resume_acc[rank].data(), npix * 3 * sizeof(float), hipMemcpyHostToDevice), "upload of the checkpoint");
         }
-        // ---- passes ----
+        t_setup[rank] = seconds_since(t_start);
+        // ---- passes ---- (every rank meets every barrier, failed or not: the loop bounds are the same for all)
+        const auto t_passes = std::chrono::steady_clock::now();
         uint32_t pass_no = 0;
-        for (uint32_t b = start_sample; b < num_samples; b += pass_spp, ++pass_no) {
-            const uint32_t e = std::min(num_samples, b + pass_spp);
+        for (uint64_t b = start_sample; b < num_samples; b += pass_spp, ++pass_no) {
+            const uint32_t e = uint32_t(std::min<uint64_t>(num_samples, b + pass_spp));
             const bool last = e == num_samples;
-            if (errors[rank].empty() && npix) {
-                if (rbrt_hip_render_pass(hs, &c, &o, stream, b, e, d_acc, last ? d_rad : nullptr, last ? (world == 1 ? d_rgb : nullptr) : nullptr) != RBRT_OK)
+            if (!failed && npix) {
+                if (rbrt_hip_render_pass(hs, &c, &o, stream, uint32_t(b), e, d_acc, last ? d_rad : nullptr, last ? (world == 1 ? d_rgb : nullptr) : nullptr) != RBRT_OK)
                     fail(rbrt_hip_last_error());
                 else
                     hip_ok(hipStreamSynchronize(stream), "render pass");
             }
             const bool ckpt_now = !cfg.checkpoint_path.empty() && !last && (pass_no + 1) % ckpt_every == 0;
-            if (ckpt_now && errors[rank].empty() && npix) {
+            if (ckpt_now && !failed && npix) {
                 ckpt_acc[rank].resize(npix * 3);
                 hip_ok(hipMemcpy(ckpt_acc[rank].data(), d_acc, npix * 3 * sizeof(float), hipMemcpyDeviceToHost), "download of the running sums");
             }
@@ -226,7 +309,8 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
                     std::printf("\rRendering %.1f%% complete!", double(e) / double(num_samples) * 100.0);
                     std::fflush(stdout);
                 }
-                if (ckpt_now && !any_error()) {
+                // (between the two barriers of a checkpointing pass no other rank is running: the counter is stable)
+                if (ckpt_now && n_failed.load() == 0) {
                     const std::string tmp = cfg.checkpoint_path + ".tmp";
                     std::ofstream out(tmp, std::ios::binary | std::ios::trunc);
                     CheckpointHeader h = want;
@@ -239,57 +323,82 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
                     }
                     out.close();
                     if (!out || std::rename(tmp.c_str(), cfg.checkpoint_path.c_str()) != 0) fail("cannot write checkpoint " + cfg.checkpoint_path);
+                    if (!failed) ++rep.checkpoints_written;
                 }
             }
             if (world > 1 && ckpt_now) barrier.wait();  // the sums may change again only after they are on disk
             if (stop_after > 0 && int(pass_no) + 1 == stop_after && !last) fail("stopped after pass " + std::to_string(stop_after) + " (RBRT_TEST_STOP_AFTER_PASS)");
         }
+        if (rank == 0) rep.passes = pass_no;
         // ---- the reference would have panicked on a NaN discriminant (sphere.rs:33): surface it ----
-        if (hs && errors[rank].empty() && rbrt_hip_scene_check(hs) != RBRT_OK) fail(rbrt_hip_last_error());
+        if (hs && !failed && rbrt_hip_scene_check(hs) != RBRT_OK) fail(rbrt_hip_last_error());
+        t_render[rank] = seconds_since(t_passes);
         // ---- gather ----
+        const auto t_g = std::chrono::steady_clock::now();
         if (world == 1) {
-            if (errors[rank].empty() && npix) {
+            if (!failed && npix) {
                 hip_ok(hipMemcpy(img.radiance.data(), d_rad, n * sizeof(float), hipMemcpyDeviceToHost), "download");
                 hip_ok(hipMemcpy(img.rgb.data(), d_rgb, n, hipMemcpyDeviceToHost), "download");
             }
         } else if (use_rccl) {
-            barrier.wait();  // every rank knows whether any rank failed: either all enter the group call or none
-            if (!any_error()) {
+            // The decision to enter the group is taken ONCE, between two barriers: before the first every rank has
+            // recorded what it had to record, and until the second nobody runs code that can fail. All enter or none.
+            barrier.wait();
+            const bool go = n_failed.load() == 0;
+            barrier.wait();
+            if (go) {
                 // one grouped exchange: rank r > 0 sends its packed tiles, rank 0 receives each into that rank's slot
-                ncclResult_t rc = ncclGroupStart();
+                bool copied = true;
+                if (rank == 0) copied = hip_ok(hipMemcpyAsync(d_slots, d_rad, npix * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream), "own tiles");
+                ncclResult_t rc = rccl->GroupStart();
                 if (rank == 0) {
-                    hip_ok(hipMemcpyAsync(d_slots[0], d_rad, npix * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream), "own tiles");
                     for (int r = 1; r < world && rc == ncclSuccess; ++r) {
                         const size_t cnt = rbrt_hip_packed_pixels(img.width, img.height, uint32_t(r), uint32_t(world)) * 3;
-                        if (cnt) rc = ncclRecv(d_slots[0] + size_t(r) * slot_pixels * 3, cnt, ncclFloat, r, comms[0], stream);
+                        if (cnt) rc = rccl->Recv(d_slots + size_t(r) * slot_pixels * 3, cnt, ncclFloat, r, comms[0], stream);
                     }
                 } else if (npix && rc == ncclSuccess) {
-                    rc = ncclSend(d_rad, npix * 3, ncclFloat, 0, comms[rank], stream);
+                    rc = rccl->Send(d_rad, npix * 3, ncclFloat, 0, comms[rank], stream);
                 }
-                const ncclResult_t rc2 = ncclGroupEnd();
-                if (rc != ncclSuccess || rc2 != ncclSuccess) fail(std::string("RCCL gather: ") + ncclGetErrorString(rc != ncclSuccess ? rc : rc2));
-                if (rank == 0 && errors[0].empty()) {
-                    if (rbrt_hip_unpack_tiles_strided(0, stream, d_slots[0], img.width, img.height, uint32_t(world), slot_pixels, d_img, d_rgb) != RBRT_OK)
+                const ncclResult_t rc2 = rccl->GroupEnd();
+                if (rc != ncclSuccess || rc2 != ncclSuccess) fail(std::string("RCCL gather: ") + rccl->GetErrorString(rc != ncclSuccess ? rc : rc2));
+                if (rank == 0 && !failed && copied) {
+                    if (rbrt_hip_unpack_tiles_strided(dev, stream, d_slots, img.width, img.height, uint32_t(world), slot_pixels, d_img, d_rgb) != RBRT_OK)
                         fail(rbrt_hip_last_error());
                 }
-                hip_ok(hipStreamSynchronize(stream), "gather");
-                if (rank == 0 && errors[0].empty()) {
+                // Wait for the exchange, but not for ever: if a peer failed inside the group (its send or receive was
+                // never enqueued) this rank's side can not complete; it then aborts its communicator instead of hanging.
+                for (;;) {
+                    const hipError_t q = hipStreamQuery(stream);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) {
+                        hip_ok(q, "gather");
+                        break;
+                    }
+                    if (n_failed.load() != 0) {
+                        fail("RCCL gather abandoned: another rank failed");
+                        (void)rccl->CommAbort(comms[rank]);
+                        comms[rank] = nullptr;
+                        break;
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+                if (rank == 0 && !failed) {
                     hip_ok(hipMemcpy(img.radiance.data(), d_img, n * sizeof(float), hipMemcpyDeviceToHost), "download");
                     hip_ok(hipMemcpy(img.rgb.data(), d_rgb, n, hipMemcpyDeviceToHost), "download");
                 }
             }
-        } else if (errors[rank].empty() && npix) {  // --gather host: every rank's tiles through host memory
+        } else if (!failed && npix) {  // --gather host: every rank's tiles over its own PCIe link, merged on the host
             std::vector<float> hr(npix * 3);
             if (hip_ok(hipMemcpy(hr.data(), d_rad, hr.size() * sizeof(float), hipMemcpyDeviceToHost), "download")) {
                 const uint32_t tiles_x = (img.width + RBRT_TILE - 1) / RBRT_TILE;
-                for (size_t tl = 0; tl < npix / 64; ++tl) {
+                for (size_t tl = 0; tl < npix / 64; ++tl) {  // (ranks write disjoint pixels of the shared image)
                     const uint32_t tile = uint32_t(tl) * uint32_t(world) + uint32_t(rank);
                     const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
                     for (uint32_t p = 0; p < 64; ++p) {
                         const uint32_t row = ty * RBRT_TILE + p / 8, col = tx * RBRT_TILE + p % 8;
                         if (row >= img.height || col >= img.width) continue;
                         const size_t src = (tl * 64 + p) * 3, dst = (size_t(row) * img.width + col) * 3;
-                        for (int k = 0; k < 3; ++k) {  // lib.rs:116-122 on the host for this fallback
+                        for (int k = 0; k < 3; ++k) {  // lib.rs:116-122 on the host for this path
                             const float v = hr[src + k];
                             img.radiance[dst + k] = v;
                             const float q = std::sqrt(v) * 256.0f;
@@ -299,11 +408,12 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
                 }
             }
         }
+        t_gather[rank] = seconds_since(t_g);
         if (d_acc) (void)hipFree(d_acc);
         if (d_rad) (void)hipFree(d_rad);
         if (d_rgb) (void)hipFree(d_rgb);
         if (d_img) (void)hipFree(d_img);
-        if (rank == 0 && d_slots[0]) (void)hipFree(d_slots[0]);
+        if (rank == 0 && d_slots) (void)hipFree(d_slots);
         if (stream) (void)hipStreamDestroy(stream);
         rbrt_hip_scene_destroy(hs);
     };
@@ -312,11 +422,16 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     worker(0);
     for (auto& t : threads) t.join();
     for (ncclComm_t cm : comms)
-        if (cm) (void)ncclCommDestroy(cm);
+        if (cm) (void)rccl->CommDestroy(cm);
     for (int r = 0; r < world; ++r)
-        if (!errors[r].empty()) throw Error("GPU " + std::to_string(r) + ": " + errors[r]);
+        if (!errors[r].empty()) throw Error("GPU " + std::to_string(device_of(r)) + (cfg.oversubscribe ? " (rank " + std::to_string(r) + ")" : "") + ": " + errors[r]);
     if (!cfg.checkpoint_path.empty()) std::remove(cfg.checkpoint_path.c_str());  // (only reached when the render is complete)
     if (!cfg.quiet) std::printf("\rRendering 100%% complete!\n");
+    rep.resumed_from_sample = start_sample;
+    rep.upload_build_s = *std::max_element(t_setup.begin(), t_setup.end());
+    rep.render_s = *std::max_element(t_render.begin(), t_render.end());
+    rep.gather_s = *std::max_element(t_gather.begin(), t_gather.end());
+    if (cfg.report) *cfg.report = rep;
     return img;
 }
 

@@ -6,6 +6,9 @@ import pytest
 
 # GPU tests: fill the sample buffer with NaN bit patterns before every trace launch, so that a (pixel, sample)
 # the kernel fails to write cannot hide behind a previous render's value or a zero-initialised allocation.
+# (RBRT_POISON_SAMPLES and the scheduling knobs some tests set are lab knobs: the library reads them only with
+# RBRT_HIP_LAB=1, include/rbrt_hip_debug.h)
+os.environ.setdefault("RBRT_HIP_LAB", "1")
 os.environ.setdefault("RBRT_POISON_SAMPLES", "1")
 
 ROOT = Path(__file__).resolve().parent.parent

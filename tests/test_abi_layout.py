@@ -12,18 +12,30 @@ from rbrt_amd import abi, tiles
 ROOT = Path(__file__).resolve().parent.parent
 STRUCTS = {"rbrt_material_t": abi.Material, "rbrt_sphere_t": abi.Sphere, "rbrt_mesh_t": abi.Mesh,
            "rbrt_scene_t": abi.Scene, "rbrt_camera_t": abi.Camera, "rbrt_render_opts_t": abi.RenderOpts,
-           "rbrt_hip_stats_t": abi.Stats}
+           "rbrt_hip_stats_t": abi.Stats, "rbrt_hip_scene_info_t": abi.SceneInfo}
+
+
+def _declared(header_name):
+    header = (ROOT / "include" / header_name).read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)  # prose in comments may mention calls
+    return set(re.findall(r"\b(rbrt_(?:hip_)?[a-z_0-9]+)\s*\(", header)) - {"rbrt_hip_scene"}  # (the opaque struct tag)
 
 
 def test_library_exports_every_declared_symbol():
-    header = (ROOT / "include" / "rbrt_hip.h").read_text()
-    declared = set(re.findall(r"\b(rbrt_(?:hip_)?[a-z_0-9]+)\s*\(", header))
-    declared -= {"rbrt_hip_scene"}  # the opaque struct tag
+    """Both headers: the drop-in boundary (rbrt_hip.h) and the test hooks / diagnostics (rbrt_hip_debug.h)."""
     lib = abi.load_hip()
-    for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} is declared in rbrt_hip.h but not exported"
-    assert declared == set(abi.HIP_SYMBOLS), declared ^ set(abi.HIP_SYMBOLS)
+    for header_name, table in (("rbrt_hip.h", abi.HIP_SYMBOLS), ("rbrt_hip_debug.h", abi.DEBUG_SYMBOLS)):
+        declared = _declared(header_name)
+        for name in sorted(declared):
+            assert hasattr(lib, name), f"{name} is declared in {header_name} but not exported"
+        assert declared == set(table), (header_name, declared ^ set(table))
     assert lib.rbrt_hip_abi_version() == 1
+
+
+def test_drop_in_header_has_no_test_hooks():
+    """What a Rust host binds is the render path only: hooks and diagnostics live in rbrt_hip_debug.h."""
+    declared = _declared("rbrt_hip.h")
+    assert not [n for n in declared if "selftest" in n or "debug" in n or "trace_rays" in n or "bvh_build" in n or "timing" in n]
 
 
 def test_struct_layout_matches_the_c_header(tmp_path):

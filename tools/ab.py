@@ -24,7 +24,7 @@ def main():
     res = {v: [] for v in args.variants}
     for r in range(args.rounds):
         for v in args.variants:
-            env = dict(os.environ)
+            env = dict(os.environ, RBRT_HIP_LAB="1")
             if v != "-":
                 for kv in v.split():
                     k, val = kv.split("=", 1)

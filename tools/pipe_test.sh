@@ -1,4 +1,5 @@
 # usage: bash tools/pipe_test.sh WORLD -- per-step time of rank 0's share for (waves per CU, pipeline depth) pairs
+export RBRT_HIP_LAB=1  # the scheduling knobs below are lab knobs (include/rbrt_hip_debug.h)
 w=${1:-8}
 for cfg in "16 2" "16 3" "12 3" "10 3" "8 2" "8 3" "8 4" "6 3" "6 4" "5 3" "5 4" "4 4"; do
 set -- $cfg

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RBRT_HIP_LAB=1  # the scheduling knobs below are lab knobs (include/rbrt_hip_debug.h)
 # SQ / TCP counters of the trace megakernel for one library build: tools/pmc_ab.sh <tag> [ENV=VALUE ...]
 # (two rocprofv3 --pmc passes over a short unpipelined bench run; prints per-dispatch averages)
 set -o pipefail

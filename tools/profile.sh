@@ -9,6 +9,8 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profile
 rm -rf "$OUT" && mkdir -p "$OUT"
+# what is being profiled: the hash bench.py later checks the counters' freshness against (rbrt_amd/srchash.py)
+python3 -c "from rbrt_amd.srchash import kernel_source_sha256 as h; print(h())" > "$OUT/kernel_source_sha256.txt" || exit 1
 COMMON="--cpu-col-stride 0 --single-frames 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_isolated" -- python3 bench.py --steps 10 --warmup 2 --pipeline 1 $COMMON \
     > "$OUT/bench_stats_isolated.json" 2> "$OUT/bench_stats_isolated.err" || exit 1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RBRT_HIP_LAB=1  # the scheduling knobs below are lab knobs (include/rbrt_hip_debug.h)
 # An eighth of the frame (rank 0 of 8) under scheduling variants: grid size x pipeline depth, drain mode, watermarks
 mkdir -p gpurun_out
 run() { # env... -- extra bench args

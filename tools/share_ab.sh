@@ -1,4 +1,5 @@
 #!/bin/bash
+export RBRT_HIP_LAB=1  # the scheduling knobs below are lab knobs (include/rbrt_hip_debug.h)
 # A/B of the two kernel builds (with / without shared traversals in the drain) on the frame and on its 1/2, 1/4, 1/8
 set -o pipefail
 OUT=gpurun_out/share; mkdir -p $OUT

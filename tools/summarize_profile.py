@@ -16,6 +16,9 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from rbrt_amd.srchash import kernel_source_sha256  # noqa: E402
+
 SRC = ROOT / "gpurun_out" / "profile"
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = ROOT / "profiles"
@@ -71,6 +74,9 @@ for k, d in res.items():
         corrected = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
         cfg = bench["config"]["workload"]
         rec = {"kernel": k, "workload": "1024x768x50", "triangles": 69451, "bench_workload": cfg,
+               # (recorded by tools/profile.sh on the GPU box, from the tree the counters were measured on)
+               "kernel_source_sha256_16": ((SRC / "kernel_source_sha256.txt").read_text().strip()
+                                           if (SRC / "kernel_source_sha256.txt").exists() else kernel_source_sha256()),
                "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"], "hbm_bytes_per_launch_raw": raw,
                "hbm_bytes_per_launch": corrected,
                "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 "
@@ -83,6 +89,10 @@ for k, d in res.items():
             rec["sq_insts_valu"] = c["SQ_INSTS_VALU"]
             rec["sq_insts_salu"] = c.get("SQ_INSTS_SALU")
             rec["sq_lds_bank_conflict"] = c.get("SQ_LDS_BANK_CONFLICT")
+            for name in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                         "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAVES", "GRBM_GUI_ACTIVE"):
+                if name in c:
+                    rec[name.lower()] = c[name]
             rec["valu_lane_utilisation"] = d["derived"].get("valu_lane_utilisation")
             rec["l2_hit_rate"] = d["derived"].get("l2_hit_rate")
             rec["l1_hit_rate"] = d["derived"].get("l1_hit_rate")
