@@ -23,6 +23,11 @@ $(LIBDIR)/librbrt_hip.so: $(CSRC)/kernels.hip $(CSRC)/megakernel.inl $(CSRC)/api
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/bvh_device.hip $(CSRC)/api.cpp $(CSRC)/bvh.cpp
 
+# Analysis build (not the product): every region marker of the megakernel stamps s_memtime; tools/region_profile.py reads it.
+timers: $(LIBDIR)/librbrt_hip_timers.so
+$(LIBDIR)/librbrt_hip_timers.so: $(LIBDIR)/librbrt_hip.so
+	$(HIPCC) $(HIPFLAGS) -DRBRT_REGION_TIMERS=1 -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/bvh_device.hip $(CSRC)/api.cpp $(CSRC)/bvh.cpp
+
 host:
 	@if [ -f rbrt_amd/host/Makefile ]; then $(MAKE) -C rbrt_amd/host; fi
 
@@ -37,4 +42,4 @@ clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all host oracle clean asan tsan
+.PHONY: all host oracle clean asan tsan timers

@@ -64,6 +64,9 @@ def parse_args():
                          "on this many internal streams; 0 = the library's automatic choice (3)")
     ap.add_argument("--vary-seed", type=int, default=0, help="1: every step renders a new frame (seed + step number)")
     ap.add_argument("--triangles", type=int, default=69451)
+    ap.add_argument("--mesh", choices=("smooth", "rough"), default="smooth",
+                    help="which stand-in takes bunny.obj's place: the smooth blob (headline) or the rough one (uneven triangle "
+                         "sizes, concavities, thin parts; rbrt_amd/standin.py) -- brackets the headline's sensitivity to geometry")
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
     ap.add_argument("--cpu-col-stride", type=int, default=-1,
                     help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline; 1 = the whole "
@@ -117,8 +120,8 @@ def main():
 
     # ---- setup (untimed): stand-in asset, YAML through the C++ host, upload + BVH build ---------
     work = Path(tempfile.mkdtemp(prefix=f"rbrt_bench_r{rank}_"))
-    real_asset = Path("bunny.obj").exists() and args.triangles == standin.BUNNY_TRIANGLES
-    obj = Path("bunny.obj").resolve() if real_asset else standin.ensure_obj(work / "bunny.obj", args.triangles)
+    real_asset = Path("bunny.obj").exists() and args.triangles == standin.BUNNY_TRIANGLES and args.mesh == "smooth"
+    obj = Path("bunny.obj").resolve() if real_asset else standin.ensure_obj(work / "bunny.obj", args.triangles, args.mesh)
     yaml_text = Path(args.scene).read_text().replace("obj_filepath: bunny.obj", f"obj_filepath: {obj}")
     (work / "scene.yaml").write_text(yaml_text)
     devnull = os.open(os.devnull, os.O_WRONLY)  # the host prints the reference's progress lines
@@ -310,7 +313,8 @@ def main():
                 r = json.loads(cand.read_text())
             except Exception:
                 continue
-            if r.get("workload") == f"{W}x{H}x{spp}" and r.get("triangles") == args.triangles and r.get("kernel_source_sha256_16") == src_hash:
+            if (r.get("workload") == f"{W}x{H}x{spp}" and r.get("triangles") == args.triangles and args.mesh == "smooth" and
+                    r.get("kernel_source_sha256_16") == src_hash):
                 rec, prof = r, cand
                 break
         if rec is None:
@@ -344,7 +348,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"example_scene.yaml, {args.triangles}-triangle "
-                               f"{'bunny.obj' if real_asset else 'stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
+                               f"{'bunny.obj' if real_asset else 'stand-in mesh' if args.mesh == 'smooth' else 'ROUGH stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
                    "pipeline": (f"{args.pipeline or 'auto: 3'} trace launches in flight, half-size grids while they overlap (consecutive steps overlap)")
                    if args.pipeline != 1 else "1 (no overlap between steps)",

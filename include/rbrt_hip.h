@@ -228,6 +228,8 @@ typedef struct rbrt_hip_scene_info {
     uint64_t n_triangles;           /* indexed triangle records, all meshes (what the reference's scan can return) */
     uint32_t trace_waves;           /* resident single-wave workgroups of a full trace launch */
     uint32_t lds_bytes_per_wave;    /* LDS each of them uses */
+    uint32_t occupancy_api_waves_per_cu; /* hipOccupancyMaxActiveBlocksPerMultiprocessor for that kernel and LDS size */
+    uint32_t n_cus;
 } rbrt_hip_scene_info_t;
 int rbrt_hip_scene_info(rbrt_hip_scene_t* scene, rbrt_hip_scene_info_t* out);
 

@@ -59,6 +59,10 @@ int rbrt_hip_selftest_ieee(uint64_t seed, size_t n, uint64_t counts[3]);
  * lane-steps, out[14] refill rounds, out[15] scheduling rounds. */
 int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* scene, uint64_t* out, size_t n);
 
+/* Diagnostic: preset slot `index` (< 64) of the counters rbrt_hip_scene_debug_counters reads (analysis builds keep
+ * minima there, which must start at all-ones). Synchronises the device. */
+int rbrt_hip_scene_debug_set_counter(rbrt_hip_scene_t* scene, size_t index, uint64_t value);
+
 /* Diagnostic: run the host-side BVH builder alone (needs no device). *nodes_out / *tris_out are
  * malloc'ed copies of the 128-B 4-wide node and 48-B triangle records (layout: rbrt_amd/csrc/device_types.h);
  * release them with rbrt_hip_free_host. */

@@ -738,6 +738,24 @@ int rbrt_oracle_kat_scatter(const rbrt_material_t* m, const float ray[6], const 
     out_ray[3] = o.direction.x, out_ray[4] = o.direction.y, out_ray[5] = o.direction.z;
     return ok;
 }
+// The same event, also reporting the stream's state before and after it ({s0, s1} each): what the HIP hook
+// rbrt_hip_debug_scatter takes and returns, so that a fixture can check the draw COUNT of an event as well.
+int rbrt_oracle_kat_scatter_state(const rbrt_material_t* m, const float ray[6], const float point[3],
+                                  const float normal[3], uint64_t seed, uint32_t pixel, uint32_t sample,
+                                  float att[3], float out_ray[6], uint32_t state_before[2], uint32_t state_after[2]) {
+    Rng rng(seed, pixel, sample);
+    state_before[0] = rng.s0, state_before[1] = rng.s1;
+    Ray in{v3(ray), v3(ray + 3)};
+    Hit h{v3(point), v3(normal), m, 0.0f};
+    V3 a = v3(0, 0, 0);
+    Ray o{v3(0, 0, 0), v3(0, 0, 0)};
+    bool ok = scatter(*m, in, h, a, o, rng);
+    att[0] = a.x, att[1] = a.y, att[2] = a.z;
+    out_ray[0] = o.origin.x, out_ray[1] = o.origin.y, out_ray[2] = o.origin.z;
+    out_ray[3] = o.direction.x, out_ray[4] = o.direction.y, out_ray[5] = o.direction.z;
+    state_after[0] = rng.s0, state_after[1] = rng.s1;
+    return ok;
+}
 uint8_t rbrt_oracle_kat_quantise(float c) { return quantise(c); }
 
 }  // extern "C"

@@ -120,6 +120,14 @@ class HipScene:
         abi.check(self._lib.rbrt_hip_scene_stats(self._h, C.byref(st)))
         return {k: int(getattr(st, k)) for k, _ in abi.Stats._fields_}
 
+    def set_debug_counter(self, index: int, value: int):
+        abi.check(self._lib.rbrt_hip_scene_debug_set_counter(self._h, int(index), int(value)))
+
+    def raw_debug_counters(self) -> list:
+        buf = (C.c_uint64 * 64)()
+        abi.check(self._lib.rbrt_hip_scene_debug_counters(self._h, buf, 64))
+        return [int(x) for x in buf]
+
     def debug_counters(self) -> dict:
         """Pass statistics of the megakernel from the last counting render (diagnostic)."""
         buf = (C.c_uint64 * 64)()
@@ -155,6 +163,24 @@ class HipScene:
                                                 t.ctypes.data_as(abi.f32p), obj.ctypes.data_as(abi.i32p),
                                                 tri.ctypes.data_as(abi.i32p), dist.ctypes.data_as(abi.f32p)))
         return t, obj, tri, dist
+
+
+def debug_scatter(kind, albedo, param, in_dir, point, normal, rng_state):
+    """n scatter events through the device functions the shading passes use (rbrt_hip_debug_scatter; test hook).
+    Arrays of length n: kind int32, albedo (n,3), param, in_dir (n,3), point (n,3), normal (n,3), rng_state (n,2) uint32.
+    Returns (out_dir (n,3) float32, ok (n,) uint8, state_after (n,2) uint32)."""
+    n = len(kind)
+    mats = (abi.Material * n)()
+    for i in range(n):
+        mats[i] = abi.material(int(kind[i]), tuple(float(x) for x in albedo[i]), float(param[i]))
+    f = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
+    in_dir, point, normal = f(in_dir), f(point), f(normal)
+    st = np.ascontiguousarray(rng_state, np.uint32)
+    out_dir, ok, st_out = np.zeros((n, 3), np.float32), np.zeros(n, np.uint8), np.zeros((n, 2), np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    abi.check(load_hip().rbrt_hip_debug_scatter(mats, abi.fptr(in_dir), abi.fptr(point), abi.fptr(normal), st.ctypes.data_as(u32p), n,
+                                                 abi.fptr(out_dir), ok.ctypes.data_as(abi.u8p), st_out.ctypes.data_as(u32p)))
+    return out_dir, ok, st_out
 
 
 def packed_pixels(width: int, height: int, rank: int, world: int) -> int:

@@ -117,6 +117,7 @@ class SceneInfo(C.Structure):
         ("n_meshes_device_built", C.c_uint32), ("bvh_stack_need", C.c_uint32),
         ("n_nodes", C.c_uint64), ("n_triangles", C.c_uint64),
         ("trace_waves", C.c_uint32), ("lds_bytes_per_wave", C.c_uint32),
+        ("occupancy_api_waves_per_cu", C.c_uint32), ("n_cus", C.c_uint32),
     ]
 
 
@@ -159,6 +160,7 @@ DEBUG_SYMBOLS = {
     "rbrt_hip_scene_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]),
     "rbrt_hip_scene_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "rbrt_hip_scene_kernel_ms": (C.c_int, [C.c_void_p, f32p, f32p, C.POINTER(C.c_uint32)]),
+    "rbrt_hip_scene_debug_set_counter": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),
     "rbrt_hip_scene_launch_mix": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rbrt_hip_debug_scatter": (C.c_int, [C.POINTER(Material), f32p, f32p, f32p, C.POINTER(C.c_uint32), C.c_size_t, f32p, u8p,
                                         C.POINTER(C.c_uint32)]),

@@ -22,6 +22,7 @@ hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint3
 size_t megakernel_gseq_bytes(uint32_t n_waves);
 size_t megakernel_gstack_bytes(uint32_t n_waves);
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
+int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
                          size_t rank_stride_pixels, float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
@@ -101,7 +102,6 @@ struct rbrt_hip_scene {
     DevMaterial* d_materials = nullptr;
     DevMesh* d_meshes = nullptr;
     BvhTri* d_tris = nullptr;  // all meshes' triangle records
-    const BvhNode4* d_root0 = nullptr;  // mesh 0's nodes
     DevCounters* d_counters = nullptr;
     // workspace, grown on demand
     // Frame pipeline: consecutive trace launches (the batches of one render, or successive renders) alternate
@@ -318,7 +318,6 @@ int fill_trace_params(const rbrt_hip_scene* s, const rbrt_camera_t* cam, const r
     P.materials = s->d_materials;
     P.meshes = s->d_meshes;
     P.tris = s->d_tris;
-    P.root0 = s->d_root0;
     P.counters = s->d_counters;
     return RBRT_OK;
 }
@@ -544,7 +543,6 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             s->total_tris += bvh.tris.size();
         }
         dm.tris = s->d_tris, dm.normals = d_normals;
-        if (i == 0) s->d_root0 = dm.nodes;
         float diag2 = 0.0f;
         for (int c = 0; c < 3; ++c) {
             dm.bbox_lo[c] = m.bbox_lo[c];
@@ -898,6 +896,9 @@ int rbrt_hip_scene_info(rbrt_hip_scene_t* s, rbrt_hip_scene_info_t* out) {
     out->n_nodes = s->total_nodes, out->n_triangles = s->total_tris;
     out->trace_waves = s->n_waves;
     out->lds_bytes_per_wave = uint32_t(megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes));
+    (void)hipSetDevice(s->device);
+    out->occupancy_api_waves_per_cu = uint32_t(megakernel_occupancy_per_cu(s->pool, out->lds_bytes_per_wave));
+    out->n_cus = s->n_cus;
     return RBRT_OK;
 }
 
@@ -1011,6 +1012,16 @@ int rbrt_hip_scene_debug_counters(rbrt_hip_scene_t* s, uint64_t* out, size_t n) 
     DevCounters c;
     HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n && i < 64; ++i) out[i] = c.diag[i];
+    return RBRT_OK;
+}
+
+// Diagnostic: preset one diag slot (the analysis builds keep minima there, which have to start at all-ones).
+int rbrt_hip_scene_debug_set_counter(rbrt_hip_scene_t* s, size_t index, uint64_t value) {
+    if (!s || index >= 64) return fail(RBRT_ERR_INVALID_ARG, "debug_set_counter: bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const unsigned long long v = value;
+    HIP_TRY(hipMemcpy(&s->d_counters->diag[index], &v, sizeof(v), hipMemcpyHostToDevice));
     return RBRT_OK;
 }
 

@@ -105,7 +105,6 @@ struct TraceParams {
     const DevSphere* spheres;
     const DevMaterial* materials;  // [object id]: spheres first, then meshes
     const DevMesh* meshes;
-    const BvhNode4* root0;  // mesh 0's node array (experiment RBRT_ROOT_LDS reads its root from an LDS copy)
     const BvhTri* tris;  // the triangle records of ALL meshes, one array; leaf links hold absolute positions in it
     // work decomposition
     uint32_t tiles_x, tiles_y, n_tiles;

@@ -327,27 +327,16 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {
 
 // Fetch one 128-B node (8 x dwordx4 by this lane) and test its four children; k[] comes back sorted by
 // entry distance (misses last) -- or, with SORTED = false, in slot order --, links = the four child links.
-// `lds_root` (experiment RBRT_ROOT_LDS, DESIGN.md "top of the tree in LDS"): when not null and this lane is at the
-// root, the eight 16-byte pieces come from a copy of node 0 in LDS instead of global memory / L1.
 template <bool SORTED = true>
 __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull& rc, float eps, float best_t,
-                                            uint32_t k[4], f32x4& links, const char* lds_root = nullptr, bool at_root = false) {
+                                            uint32_t k[4], f32x4& links) {
     const char* nb = reinterpret_cast<const char*>(node);
     f32x4 nx, ny, nz, fx, fy, fz, me;
-    if (lds_root != nullptr && at_root) {
-        typedef const __attribute__((address_space(3))) f32x4 lds_f32x4;
-        const char* lb = lds_root;
-        nx = *(lds_f32x4*)(lb + rc.near_x), ny = *(lds_f32x4*)(lb + rc.near_y), nz = *(lds_f32x4*)(lb + rc.near_z);
-        fx = *(lds_f32x4*)(lb + (rc.near_x ^ 48u)), fy = *(lds_f32x4*)(lb + (rc.near_y ^ 80u)), fz = *(lds_f32x4*)(lb + (rc.near_z ^ 112u));
-        me = *(lds_f32x4*)(lb + 112);
-        links = *(lds_f32x4*)(lb + 96);
-    } else {
-        nx = *RBRT_AS1(f32x4, nb + rc.near_x), ny = *RBRT_AS1(f32x4, nb + rc.near_y), nz = *RBRT_AS1(f32x4, nb + rc.near_z);
-        fx = *RBRT_AS1(f32x4, nb + (rc.near_x ^ 48u)), fy = *RBRT_AS1(f32x4, nb + (rc.near_y ^ 80u));
-        fz = *RBRT_AS1(f32x4, nb + (rc.near_z ^ 112u));
-        me = *RBRT_AS1(f32x4, nb + 112);
-        links = *RBRT_AS1(f32x4, nb + 96);
-    }
+    nx = *RBRT_AS1(f32x4, nb + rc.near_x), ny = *RBRT_AS1(f32x4, nb + rc.near_y), nz = *RBRT_AS1(f32x4, nb + rc.near_z);
+    fx = *RBRT_AS1(f32x4, nb + (rc.near_x ^ 48u)), fy = *RBRT_AS1(f32x4, nb + (rc.near_y ^ 80u));
+    fz = *RBRT_AS1(f32x4, nb + (rc.near_z ^ 112u));
+    me = *RBRT_AS1(f32x4, nb + 112);
+    links = *RBRT_AS1(f32x4, nb + 96);
     // one pad for the node: the largest of its children's error terms (siblings have similar triangles)
     const float pad = __builtin_fmaf(rc.pad_k, __builtin_fmaxf(__builtin_fmaxf(me.x, me.y), __builtin_fmaxf(me.z, me.w)),
                                      rc.pad_base);
@@ -567,6 +556,7 @@ __device__ __forceinline__ bool scatter(const DevMaterial& m, V3 in_d, V3 p, V3 
     }
 }
 
+__host__ __device__ inline uint32_t megakernel_lds_dwords(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
 #include "megakernel.inl"
 
 // lib.rs:116-122: (sqrt(c) * 256) as u8 — Rust's float->int cast saturates and maps NaN to 0.
@@ -762,11 +752,23 @@ __global__ __launch_bounds__(kBlock) void scatter_debug_kernel(const DevMaterial
 size_t megakernel_gseq_bytes(uint32_t n_waves) { return size_t(n_waves) * kPoolMax * kSeqWords * sizeof(uint32_t); }
 size_t megakernel_gstack_bytes(uint32_t n_waves) { return size_t(n_waves) * kStackMax * 64u * sizeof(uint32_t); }
 
+__host__ __device__ inline uint32_t megakernel_lds_dwords(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
+    const uint32_t scene = n_spheres * kSphDw + (n_spheres + n_meshes) * kMatDw + n_meshes * kMeshDw + kGenDw;
+    const uint32_t pool_pad = (pool + 63u) & ~63u;  // status + list: one byte per (padded) slot each
+    uint32_t dw = uint32_t(kFields) * pool + kCellDw + kTqDw + kHelpDw + pool_pad / 2u + stack_entries * 64u + scene;
+    if (RBRT_REGION_TIMERS) dw = ((dw + 1u) & ~1u) + 2u * uint32_t(kNumRegions);  // analysis build: u64 accumulators per region
+    return dw;
+}
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
-    const size_t scene = size_t(n_spheres) * kSphDw + size_t(n_spheres + n_meshes) * kMatDw + size_t(n_meshes) * kMeshDw + kGenDw +
-                         (RBRT_ROOT_LDS ? 32u + 3u : 0u);  // experiment: mesh 0's root node, 16-byte aligned
-    const size_t pool_pad = (size_t(pool) + 63u) & ~size_t(63);  // status + list: one byte per (padded) slot each
-    return (size_t(kFields) * pool + kCellDw + kTqDw + kHelpDw + pool_pad / 2u + size_t(stack_entries) * 64u + scene) * sizeof(uint32_t);
+    return size_t(megakernel_lds_dwords(pool, stack_entries, n_spheres, n_meshes)) * sizeof(uint32_t);
+}
+
+// What the HIP runtime says fits: resident single-wave workgroups of the trace kernel per CU at this much LDS (0 on error).
+int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes) {
+    int n = 0;
+    hipError_t e = pool == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_megakernel<256, false, true>, 64, lds_bytes)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_megakernel<128, false, true>, 64, lds_bytes);
+    return e == hipSuccess ? n : 0;
 }
 
 // n_waves single-wave workgroups; each loops until the global work counter (zeroed by the caller on

@@ -18,18 +18,27 @@
 // Which lane works on which path never affects the result: a path owns its RNG stream and its
 // sample slot, and resolve_kernel adds the samples of a pixel in sample order.
 
-#if defined(RBRT_MARKERS) && RBRT_MARKERS == 2  // analysis build for PC sampling: a symbol at every region boundary
-#define RBRT_MARK(name) asm volatile("rbrt_mk_" name "_%=:" ::: "memory")
-#elif defined(RBRT_MARKERS)  // analysis build only (tools/static_cost.py): region markers in the instruction stream
-#define RBRT_MARK(name) asm volatile("; @@" name ::: "memory")
+// Region markers. Three analysis builds, none of them the product:
+//   -DRBRT_MARKERS=1          asm comments at region boundaries (tools/static_cost.py counts instructions between them)
+//   -DRBRT_REGION_TIMERS=1    every marker stamps s_memtime and adds the cycles since the previous marker to the region
+//                             that just ended (per-wave accumulators in LDS, summed into DevCounters::diag[0..kNumRegions)
+//                             at the end): where a wave's LIFETIME goes, waits included (tools/region_profile.py)
+#define RBRT_REGIONS(X) X(init) X(finalise) X(census) X(refill) X(choose) X(burst_top) X(leaf_round) X(leaf_chunk) X(walk) \
+    X(burst_end) X(pass_lists) X(term) X(gen) X(scatter_load) X(round_top) X(scatter_kind) X(spheres_gate) X(gate) X(park)
+#define RBRT_REGION_ENUM(name) R_##name,
+enum { RBRT_REGIONS(RBRT_REGION_ENUM) kNumRegions };
+#ifndef RBRT_REGION_TIMERS
+#define RBRT_REGION_TIMERS 0
+#endif
+#if RBRT_REGION_TIMERS
+#define RBRT_MARK(name) rt_tick(R_##name)
+#elif defined(RBRT_MARKERS)
+#define RBRT_MARK(name) asm volatile("; @@" #name ::: "memory")
 #else
 #define RBRT_MARK(name)
 #endif
 #ifndef RBRT_FAST_GATE
 #define RBRT_FAST_GATE 1  // mesh bbox gate through bbox_gate_fast (same decisions, no IEEE divisions on the common path)
-#endif
-#ifndef RBRT_ROOT_LDS
-#define RBRT_ROOT_LDS 0  // experiment: the root node of mesh 0 is read from a copy in LDS (measured: no gain)
 #endif
 #ifndef RBRT_PUSH_ORDER
 #define RBRT_PUSH_ORDER 0  // 0: children pushed far-to-near (sorted); 1: nearest next, the rest in slot order
@@ -208,6 +217,22 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     const uint32_t lane = threadIdx.x;
     uint32_t* const stack_base = helpers + kHelpDw + kPoolPad / 2u;                     // 2 * kPoolPad bytes of byte arrays
     uint32_t* const stack = stack_base + lane;
+#if RBRT_REGION_TIMERS
+    // (the accumulators sit at the very end of the workgroup's LDS: megakernel_lds_bytes adds room for them)
+    unsigned long long* const rt_acc = reinterpret_cast<unsigned long long*>(
+        lds + (megakernel_lds_dwords(POOLN, P.stack_entries, P.n_spheres, P.n_meshes) - 2u * kNumRegions));
+    if (lane < uint32_t(kNumRegions)) rt_acc[lane] = 0ull;
+    unsigned long long rt_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt_wall0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same clock on every CU
+    unsigned long long rt_wall_workout = 0;
+    uint32_t rt_cur = R_init;
+    auto rt_tick = [&](uint32_t next) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (lane == 0) rt_acc[rt_cur] += now - rt_prev;
+        rt_prev = now;
+        rt_cur = next;
+    };
+#endif
     uint32_t* const gseq = P.gseq + size_t(blockIdx.x) * kPoolMax * kSeqWords;
 #define POOL(f, s) pool[(f) * POOLN + (s)]
 
@@ -247,13 +272,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         }
     }
     const uint32_t* const gp = sc_base + P.n_spheres * kSphDw + n_obj * kMatDw + P.n_meshes * kMeshDw;
-    const char* lds_root = nullptr;
-    if (RBRT_ROOT_LDS && P.n_meshes != 0) {  // a copy of mesh 0's root node behind the generation parameters
-        uint32_t* rp = const_cast<uint32_t*>(gp) + kGenDw;
-        rp += (4u - ((rp - lds) & 3u)) & 3u;  // 16-byte alignment for ds_read_b128
-        if (lane < 32u) rp[lane] = reinterpret_cast<const uint32_t*>(P.root0)[lane];
-        lds_root = reinterpret_cast<const char*>(rp);
-    }
     const float* const gpf = reinterpret_cast<const float*>(gp);
     const SceneLds sc = {reinterpret_cast<const float*>(sc_base), sc_base + P.n_spheres * kSphDw,
                          sc_base + P.n_spheres * kSphDw + n_obj * kMatDw};
@@ -320,7 +338,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     auto id_given = [&]() { return t_ids >> 22; };
 
     for (;;) {
-        RBRT_MARK("finalise");
+        RBRT_MARK(finalise);
         // ---- finalise finished traversals in a batch (mesh.rs:245-266, scene.rs:33-41) ----
         if (wany(t_has_result != 0u)) {
             if (t_has_result) {
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             }
         }
         __syncthreads();
-        RBRT_MARK("census");
+        RBRT_MARK(census);
         // ---- census: how many slots wait for each kind of work ---------------------------------
         uint32_t cnt[kNumStatus] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (STATS) ++dg_census, dg_dr_rounds += more_work ? 0u : 1u;
         uint32_t n_active = uint32_t(__popcll(wballot(t_active != 0u)));
 
-        RBRT_MARK("refill");
+        RBRT_MARK(refill);
         // ---- idle lanes take parked rays (in batches: only when enough lanes are idle) ----
         // with plenty of parked rays the lanes are topped up sooner (y_high_water) than when few wait
         const uint32_t y_refill = cnt[ST_TRAV] >= P.y_high_min_parked ? P.y_high_water : P.y_low_water;
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             n_active += taken;
         }
 
-        RBRT_MARK("choose");
+        RBRT_MARK(choose);
         // ---- pick the shading kind with the most waiting slots ----
         // A TERM pass also starts new paths in empty slots while work is left.
         const uint32_t n_gen_slots = more_work ? cnt[ST_EMPTY] : 0u;
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             // (two copies of the loop: the bulk of a frame runs the one without any of the sharing code)
             auto burst = [&](auto share_tag) {
             constexpr bool SHARE = decltype(share_tag)::value;
-        RBRT_MARK("burst_top");
+        RBRT_MARK(burst_top);
             do {
                 if (STATS) {
                     ++dg_steps;
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     dg_walk_lanes += uint32_t(__popcll(walk_mask));
                 }
                 if (n_pend_leaves >= P.leaf_leaves || (n_pend_leaves != 0 && (n_stalled >= P.leaf_round || walk_mask == 0ull))) {
-        RBRT_MARK("leaf_round");
+        RBRT_MARK(leaf_round);
                     // ---- leaf round: the pending triangles are dealt out to ALL lanes, one triangle each ----
                     // (a leaf holds 1..4 triangles and only some lanes hold a leaf: testing them where they are
                     // pending ran at a third of the lanes.) The list is every lane's first pending leaf, then every
@@ -582,7 +600,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         ++dg_leaf_rounds;
                         dg_leaf_lanes += n_pend_tris;
                     }
-        RBRT_MARK("leaf_chunk");
+        RBRT_MARK(leaf_chunk);
                     for (uint32_t B = 0; B < n_pend_tris; B += 64u) {
 #pragma unroll
                         for (uint32_t i = 0; i < uint32_t(kLeafMax); ++i) {
@@ -616,11 +634,11 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         t_pend2 = kNoChild;
                     }
                 }
-        RBRT_MARK("walk");
+        RBRT_MARK(walk);
                 if (can_walk) {
                     uint32_t k[4];
                     f32x4 links;
-                    node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links, lds_root, t_cur == 0 && id_mesh() == 0u);
+                    node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links);
                     if (STATS) ++lc.nodes;
                     if (STATS && t_cur == 0 && k[0] == kMissKey) ++dg_root_only;  // a traversal that ends at the root
 #if RBRT_PUSH_ORDER == 0
@@ -663,7 +681,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         t_has_result = 1;
                     }
                 }
-        RBRT_MARK("burst_end");
+        RBRT_MARK(burst_end);
             } while (uint32_t(__popcll(wballot(t_active != 0u))) >= keep);
             };
             if (share)
@@ -674,7 +692,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             continue;
         }
 
-        RBRT_MARK("pass_lists");
+        RBRT_MARK(pass_lists);
         // ============================ shading pass of one kind ===============================
         if (STATS) {
             ++dg_pass[kind];
@@ -711,7 +729,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         uint32_t item = 0, depth = 0, nrec = 0, word = 0;
         bool have_ray = false;
 
-        RBRT_MARK("term");
+        RBRT_MARK(term);
         if (kind == ST_TERM) {
             bool need_new = is_gen;
             if (is_main) {
@@ -756,7 +774,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 if (STATS) ++n_samples_done;
                 need_new = true;
             }
-        RBRT_MARK("gen");
+        RBRT_MARK(gen);
             // ---- new paths (cam.rs:64-82); work items come from the sharded global counters ----
             const uint64_t want = wballot(need_new && more_work);
             if (want) {
@@ -769,6 +787,9 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     // other launches on its SIMD: the drain is a chain of dependent rounds, the bulk fills the gaps
                     if (!more_work && (P.drain_mode & 8u)) __builtin_amdgcn_s_setprio(2);
                     if (STATS && !more_work) dg_rt_workout = __builtin_amdgcn_s_memrealtime();
+#if RBRT_REGION_TIMERS
+                    if (!more_work) rt_wall_workout = __builtin_amdgcn_s_memrealtime();
+#endif
                 }
                 if (need_new) {
                     const uint32_t rk = lane_rank(want);
@@ -816,7 +837,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 if (more_work && work.res_end - work.res_next < 64u) work.prefetch(P, lane);
             }
         }
-        RBRT_MARK("scatter_load");
+        RBRT_MARK(scatter_load);
         // ---- RayScattering::scatter, then the closest sphere + mesh gate for the new ray ----
         // In the first round every lane shades the pass's kind (wave-uniform branches). A lane whose new
         // ray passes no mesh gate already knows its next hit; when that needs shading again it may stay
@@ -844,7 +865,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             s_ht = __uint_as_float(POOL(F_T, slot));
             s_tri = POOL(F_TRI, slot);
         }
-        RBRT_MARK("round_top");
+        RBRT_MARK(round_top);
         for (uint32_t round = 1;; ++round) {
             if (scat) {
                 const V3 p = o + s_ht * d;  // same expression as inside the intersection routines
@@ -865,7 +886,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 }
                 V3 nd;
                 bool ok;
-                RBRT_MARK("scatter_kind");
+                RBRT_MARK(scatter_kind);
                 if (lk == ST_LAMB) {  // lambertian.rs:11-24
                     const V3 target = (p + normalize(n)) + random_point_in_unit_sphere(rng);
                     nd = normalize(target - p);
@@ -904,7 +925,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             // closest sphere + mesh gate for the new ray (scene.rs:19-43 up to the meshes)
             uint32_t gated = 0, next = ST_TERM;
             float closest = 3.40282347e+38f;
-        RBRT_MARK("spheres_gate");
+        RBRT_MARK(spheres_gate);
             if (have_ray) {
                 if (STATS) ++lc.rays;
                 s_obj = -1;
@@ -927,13 +948,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         }
                     }
                 }
-                RBRT_MARK("gate");
+                RBRT_MARK(gate);
                 gated = next_gated_mesh<STATS>(sc, P.n_meshes, 0, o, d, closest, lc);
                 next = gated < P.n_meshes ? uint32_t(ST_TRAV) : classify(sc, s_obj, depth);
             }
             // stay in registers? only sphere hits that need shading, while enough lanes do (or the wave
             // has no other work left), and for a bounded number of rounds
-            RBRT_MARK("park");
+            RBRT_MARK(park);
             const bool cand = have_ray && next >= ST_LAMB;
             const uint32_t n_cand = uint32_t(__popcll(wballot(cand)));
             const bool go = n_cand != 0 && round < kMaxShadeRounds &&
@@ -966,6 +987,27 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (STATS) dg_t_shade += __builtin_amdgcn_s_memtime() - dg_tk;
     }
 #undef POOL
+#if RBRT_REGION_TIMERS
+    rt_tick(R_init);
+    if (lane < uint32_t(kNumRegions)) atomicAdd(&P.counters->diag[lane], rt_acc[lane]);
+    if (lane == 0) {  // the launch's phases on the wall clock: ramp-up, bulk, drain
+        const unsigned long long rt_wall1 = __builtin_amdgcn_s_memrealtime();
+        if (rt_wall_workout == 0) rt_wall_workout = rt_wall1;
+        atomicAdd(&P.counters->diag[kNumRegions], 1ull);                            // waves
+        atomicMin(&P.counters->diag[kNumRegions + 1], rt_wall0);                     // first wave start (slot preset to ~0 by the host tool)
+        atomicMax(&P.counters->diag[kNumRegions + 2], rt_wall0);                     // last wave start
+        atomicMin(&P.counters->diag[kNumRegions + 3], rt_wall_workout);              // first wave out of work items
+        atomicMax(&P.counters->diag[kNumRegions + 4], rt_wall_workout);              // last wave out of work items
+        atomicMax(&P.counters->diag[kNumRegions + 5], rt_wall1);                     // last wave end
+        atomicAdd(&P.counters->diag[kNumRegions + 6], rt_wall1 - rt_wall_workout);   // summed drain time of the waves
+        atomicAdd(&P.counters->diag[kNumRegions + 7], rt_wall1 - rt_wall0);          // summed lifetime of the waves
+        // when did this wave START, in 100-us buckets after the epoch the host tool put in diag[kNumRegions + 8] (the end of
+        // the previous launch): waves that start late were not resident from the beginning (the grid exceeds what fits)
+        const unsigned long long epoch = P.counters->diag[kNumRegions + 8];
+        const unsigned long long b = rt_wall0 > epoch ? (rt_wall0 - epoch) / 10000ull : 0ull;
+        atomicAdd(&P.counters->diag[32 + (b < 31ull ? b : 31ull)], 1ull);
+    }
+#endif
     if (STATS) {
         atomicAdd(&P.counters->rays, (unsigned long long)lc.rays);
         atomicAdd(&P.counters->mesh_gate_pass, (unsigned long long)lc.gate);

@@ -72,5 +72,50 @@ def main():
     print("rays", int((obj >= 4).sum()), "mesh hits,", int((obj >= 0).sum()), "hits of 600")
 
 
+# (material kind, parameter): lambertian, a polished and a rough metal, the glass sphere's index and the example mesh's
+SCATTER_MATERIALS = [(0, 0.0), (1, 0.005), (1, 0.6), (2, 1.8), (2, 0.2)]
+
+
+def make_scatter_events():
+    """SURVEY 8(c) fixture 4, second half: single scatter events (materials.rs:4-12) -> attenuation, next ray, bool,
+    with explicit random streams: 300 per material. A future image mismatch can be localised to M3 / M4 / M5 by
+    replaying these through rbrt_hip_debug_scatter instead of bisecting images."""
+    import ctypes as C
+    rng = np.random.default_rng(2024)
+    n_per = 300
+    n = n_per * len(SCATTER_MATERIALS)
+    kind, param = np.zeros(n, np.int32), np.zeros(n, np.float32)
+    albedo = np.zeros((n, 3), np.float32)
+    in_ray, point, normal = np.zeros((n, 6), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    att, out_ray, ok = np.zeros((n, 3), np.float32), np.zeros((n, 6), np.float32), np.zeros(n, np.uint8)
+    before, after = np.zeros((n, 2), np.uint32), np.zeros((n, 2), np.uint32)
+    key = np.zeros((n, 3), np.uint64)
+    u32p = C.POINTER(C.c_uint32)
+    for i in range(n):
+        k, prm = SCATTER_MATERIALS[i // n_per]
+        kind[i], param[i] = k, prm
+        albedo[i] = rng.uniform(0.05, 0.95, 3)
+        d = rng.uniform(-1, 1, 3) * rng.uniform(0.3, 2)
+        in_ray[i] = np.concatenate([rng.uniform(-10, 10, 3), d])
+        point[i] = rng.uniform(-10, 10, 3)
+        # sphere normals come unnormalised (sphere.rs:56: up to the ground sphere's radius 1000), mesh normals unit
+        nrm = rng.uniform(-1, 1, 3)
+        normal[i] = nrm / np.linalg.norm(nrm) if i % 3 == 0 else nrm * rng.uniform(0.3, 1000)
+        if i % 7 == 0:  # a normal on the ray's side / against it, exactly aligned: the sign tests' edge
+            normal[i] = (d if i % 14 == 0 else -d).astype(np.float32)
+        key[i] = (int(rng.integers(1 << 40)), int(rng.integers(1 << 20)), int(rng.integers(4096)))
+        mat = abi.material(int(k), tuple(float(x) for x in albedo[i]), float(prm))
+        ok[i] = pyoracle.lib().rbrt_oracle_kat_scatter_state(
+            C.byref(mat), pyoracle._p(in_ray[i]), pyoracle._p(point[i]), pyoracle._p(normal[i]), int(key[i, 0]), int(key[i, 1]),
+            int(key[i, 2]), pyoracle._p(att[i]), pyoracle._p(out_ray[i]), before[i].ctypes.data_as(u32p), after[i].ctypes.data_as(u32p))
+    np.savez_compressed(HERE / "scatter_events.npz", kind=kind, param=param, albedo=albedo, in_ray=in_ray, point=point, normal=normal,
+                        stream_key=key, state_before=before, attenuation=att, out_ray=out_ray, ok=ok, state_after=after)
+    print("scatter events", n, "false:", int((ok == 0).sum()))
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["scatter"]:
+        make_scatter_events()
+    else:
+        main()
+        make_scatter_events()

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Golden fixtures for the FULL-SIZE BASELINE configurations 2, 3, 4 and 5, from the CPU oracle.
 
-    python tests/golden/make_golden_big.py [cfg2] [cfg3] [cfg4] [cfg5]      (default: all; ~10 min on 8 cores)
+    python tests/golden/make_golden_big.py [cfg2] [cfg2rough] [cfg3] [cfg4] [cfg5]      (default: all; ~10 min on 8 cores)
 
 The brute-force oracle cannot render these configurations whole inside a test run (config 5 is 68.7 G
 samples), so this script is run once in the build container and its outputs are committed:
 
   cfg2_full_1024x768x50_seed1.npz   SHA-256 of the WHOLE fp32 radiance and RGB8 image of config 2 (every one of the
                                     1024 columns through the oracle) + an 8x8 sub-sampled copy for diagnosis
+  cfg2rough_cols_1024x768x50_seed1.npz every 32nd column of config 2 with the ROUGH stand-in (uneven triangle sizes,
+                                    concavities, fins and spikes: rbrt_amd/standin.py make_rough_mesh) in the bunny's place
   cfg3_cols_1920x1080x512_seed1.npz every 64th column of config 3 (30 columns x 1080 rows x 512 spp)
   cfg4_windows_1024x768x50_seed1.npz config 4 (871,414-triangle stand-in): a window at the example scene's scale 45
                                     (where the reference's |a| < 1e-3 test makes every triangle invisible) and a window
@@ -37,6 +39,7 @@ from rbrt_amd import abi, standin  # noqa: E402
 
 SEED = 1
 CFG3_STRIDE = 64
+CFG2ROUGH_STRIDE = 32
 # (what the tile centre's primary ray sees, tile_y, tile_x) in units of 8x8 tiles of the 4096x4096 frame
 CFG5_TILES = [("sky", 103, 221), ("ground", 410, 253), ("sphere1", 308, 53), ("sphere2", 334, 341),
               ("sphere3", 264, 165), ("sphere4", 219, 429), ("sphere5", 339, 205), ("sphere6", 311, 453),
@@ -66,6 +69,16 @@ def make_cfg2():
                         radiance_sub=rad[::8, ::8].copy(), rgb8_sub=rgb[::8, ::8].copy(), rays=np.int64(rays),
                         mean=rad.mean(axis=(0, 1)), triangles=np.int64(standin.BUNNY_TRIANGLES))
     print(f"cfg2 {sha(rad)[:16]} rays {rays} ({time.time() - t0:.0f} s)", flush=True)
+
+
+def make_cfg2rough():
+    cam = scenes.camera(pyoracle, 1024, 768)
+    sc = scenes.example_scene(pyoracle, kind="rough")
+    t0 = time.time()
+    rad, _, rays = pyoracle.render(cam, sc, abi.default_opts(spp=50, seed=SEED), want_rgb8=False, col_stride=CFG2ROUGH_STRIDE)
+    cols = np.arange(0, 1024, CFG2ROUGH_STRIDE)
+    np.savez_compressed(HERE / "cfg2rough_cols_1024x768x50_seed1.npz", cols=cols, radiance=rad[:, cols].copy(), rays=np.int64(rays))
+    print(f"cfg2rough {len(cols)} columns, rays {rays} ({time.time() - t0:.0f} s)", flush=True)
 
 
 def make_cfg3():
@@ -110,6 +123,6 @@ def make_cfg5():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg5", "cfg4", "cfg3", "cfg2"]
+    which = sys.argv[1:] or ["cfg5", "cfg4", "cfg3", "cfg2rough", "cfg2"]
     for w in which:
-        {"cfg2": make_cfg2, "cfg3": make_cfg3, "cfg4": make_cfg4, "cfg5": make_cfg5}[w]()
+        {"cfg2": make_cfg2, "cfg2rough": make_cfg2rough, "cfg3": make_cfg3, "cfg4": make_cfg4, "cfg5": make_cfg5}[w]()

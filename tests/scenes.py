@@ -50,15 +50,15 @@ def spheres_scene(spheres=EXAMPLE_SPHERES):
     return abi.SceneData(spheres=spheres)
 
 
-def standin_mesh(oracle, n_triangles, scale, translation, rotation, mat):
-    return oracle.mesh_prep(standin.triangles(n_triangles), scale, rotation, translation, mat)
+def standin_mesh(oracle, n_triangles, scale, translation, rotation, mat, kind="smooth"):
+    return oracle.mesh_prep(standin.triangles(n_triangles, kind), scale, rotation, translation, mat)
 
 
-def example_scene(oracle, n_triangles=standin.BUNNY_TRIANGLES, mesh_over=None, spheres=EXAMPLE_SPHERES):
-    """scenes/example_scene.yaml with the stand-in mesh (n_triangles of it)."""
+def example_scene(oracle, n_triangles=standin.BUNNY_TRIANGLES, mesh_over=None, spheres=EXAMPLE_SPHERES, kind="smooth"):
+    """scenes/example_scene.yaml with the stand-in mesh (n_triangles of it; kind: the smooth blob or the rough one)."""
     m = dict(EXAMPLE_MESH)
     m.update(mesh_over or {})
-    return abi.SceneData(spheres=spheres, meshes=[standin_mesh(oracle, n_triangles, **m)])
+    return abi.SceneData(spheres=spheres, meshes=[standin_mesh(oracle, n_triangles, kind=kind, **m)])
 
 
 def header_scene(oracle, n_triangles=standin.BUNNY_TRIANGLES):
