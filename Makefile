@@ -9,7 +9,10 @@ ARCH ?= gfx950
 
 # -ffp-contract=off is load-bearing: hipcc's default (fast-honor-pragmas) would fuse mul+add into FMA
 # and the radiance would no longer match the reference's unfused f32 arithmetic (vec3_avx.rs:18-21).
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+# -fno-slp-vectorize: left on, the SLP vectoriser packs pairs of scalar f32 mul/add into v_pk_mul_f32 / v_pk_add_f32, which
+# issue at half the rate of the plain forms on gfx950 and need register shuffles around them (profiles/r03_valu_rate.txt;
+# measured on the frame: -1 % isolated launch, -1.9 % per pipelined step, same image).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -Wall -Wextra -Wno-unused-parameter
 CSRC := rbrt_amd/csrc
 LIBDIR := rbrt_amd/lib

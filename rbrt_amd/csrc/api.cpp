@@ -23,6 +23,7 @@ size_t megakernel_gseq_bytes(uint32_t n_waves);
 size_t megakernel_gstack_bytes(uint32_t n_waves);
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
 int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes);
+int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
                          size_t rank_stride_pixels, float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
@@ -896,6 +897,9 @@ int rbrt_hip_scene_info(rbrt_hip_scene_t* s, rbrt_hip_scene_info_t* out) {
     out->n_nodes = s->total_nodes, out->n_triangles = s->total_tris;
     out->trace_waves = s->n_waves;
     out->lds_bytes_per_wave = uint32_t(megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes));
+    (void)hipSetDevice(s->device);
+    out->occupancy_api_waves_per_cu = uint32_t(megakernel_occupancy_per_cu(s->pool, out->lds_bytes_per_wave));
+    out->n_cus = s->n_cus;
     (void)hipSetDevice(s->device);
     out->occupancy_api_waves_per_cu = uint32_t(megakernel_occupancy_per_cu(s->pool, out->lds_bytes_per_wave));
     out->n_cus = s->n_cus;

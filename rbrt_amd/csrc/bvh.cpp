@@ -473,12 +473,14 @@ struct Builder {
         int32_t refs[4];
         for (int i = 0; i < n; ++i) refs[i] = c[i].ref >= 0 ? int32_t(collapse(c[i].ref, depth + 1)) : c[i].ref;
         BvhNode4& o = out.nodes[me];
-        const float qnan = std::numeric_limits<float>::quiet_NaN();
+        // (an unused slot holds the EMPTY box, lo = +inf / hi = -inf: every ray's entry parameter to it is +inf and its
+        // exit parameter -inf, so the traversal's single compare max(tn, eps) <= min(tf, best) fails: kernels.hip child_key)
+        const float pinf = std::numeric_limits<float>::infinity(), ninf = -pinf;
         for (int i = 0; i < 4; ++i) {
             const bool used = i < n;
-            o.lo_x[i] = used ? c[i].box.lo[0] : qnan, o.lo_y[i] = used ? c[i].box.lo[1] : qnan;
-            o.lo_z[i] = used ? c[i].box.lo[2] : qnan, o.hi_x[i] = used ? c[i].box.hi[0] : qnan;
-            o.hi_y[i] = used ? c[i].box.hi[1] : qnan, o.hi_z[i] = used ? c[i].box.hi[2] : qnan;
+            o.lo_x[i] = used ? c[i].box.lo[0] : pinf, o.lo_y[i] = used ? c[i].box.lo[1] : pinf;
+            o.lo_z[i] = used ? c[i].box.lo[2] : pinf, o.hi_x[i] = used ? c[i].box.hi[0] : ninf;
+            o.hi_y[i] = used ? c[i].box.hi[1] : ninf, o.hi_z[i] = used ? c[i].box.hi[2] : ninf;
             o.child[i] = used ? refs[i] : kNoChild;
             o.max_e12[i] = used ? c[i].e12 : 0.0f;
         }

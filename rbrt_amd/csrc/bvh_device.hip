@@ -17,7 +17,7 @@
 //                merge, order-preserving compaction; (B, fallback / RBRT_BVH_DEVICE_ALGO=lbvh) binary radix tree
 //                (Karras 2012, ties broken by position) + bottom-up fit (second arrival merges its children's boxes)
 //   collapse     level by level from the root: a binary subtree of <= kLeafMax triangles becomes a leaf, larger
-//                ones are opened (largest surface first) until a node has four children; unused slots get NaN boxes
+//                ones are opened (largest surface first) until a node has four children; unused slots get the empty box (lo = +inf, hi = -inf)
 //   emit_tris    48-byte records in leaf order, links absolute in the scene's triangle array
 #include <hip/hip_runtime.h>
 
@@ -338,10 +338,11 @@ __global__ __launch_bounds__(kTpb) void collapse_level(Work* w, Tree t, uint32_t
             ++n;
         }
     BvhNode4 o;
-    const float qnan = __uint_as_float(0x7fc00000u);
+    const float pinf = __uint_as_float(0x7f800000u), ninf = __uint_as_float(0xff800000u);
     for (int k = 0; k < 4; ++k) {
-        if (k >= n) {
-            o.lo_x[k] = o.lo_y[k] = o.lo_z[k] = o.hi_x[k] = o.hi_y[k] = o.hi_z[k] = qnan;
+        if (k >= n) {  // (the empty box: bvh.cpp)
+            o.lo_x[k] = o.lo_y[k] = o.lo_z[k] = pinf;
+            o.hi_x[k] = o.hi_y[k] = o.hi_z[k] = ninf;
             o.child[k] = kNoChild;
             o.max_e12[k] = 0.0f;
             continue;

@@ -28,7 +28,7 @@ constexpr int kLdsStack = 8;         // per-lane traversal stack entries kept in
 // as SoA (so the four slab tests are the same code on four registers), four child links and, per
 // child, max |e1|*|e2| of its subtree (the error-bound term of the culling pad).
 // child >= 0 : index of an inner node; child < 0 : leaf, ~child = (first_tri << kLeafBits) | (count - 1);
-// kNoChild marks an unused slot, whose box is NaN so that every slab compare fails.
+// kNoChild marks an unused slot, whose box is EMPTY (lo = +inf, hi = -inf) so that the slab test fails for every ray.
 constexpr int32_t kNoChild = INT32_MIN;
 struct alignas(128) BvhNode4 {
     float lo_x[4], lo_y[4], lo_z[4];

@@ -302,9 +302,14 @@ constexpr uint32_t kMissKey = 0xFFFFFFFFu;
 // with it; in the ray-parameter domain that is a constant per axis, folded into the FMA's addend by the
 // caller (nodn = nod - pad|1/d|, nodf = nod + pad|1/d|), so one FMA per plane gives the padded plane's
 // parameter. Returns the sort key of the child: kMissKey when the ray misses it, else its entry distance
-// (>= 0, two low mantissa bits replaced by the child slot). An unused slot has NaN planes: every compare
-// fails, it misses. A zero direction component gives inf/NaN parameters on that axis; fmax/fmin ignore a
-// NaN, so the axis can only make the test MORE permissive, which culling tolerates.
+// (two low mantissa bits replaced by the child slot).
+// The three conditions of a hit -- tn <= tf, tf >= eps, tn <= best_t -- are ONE compare: with best_t >= eps (every
+// search bound is: triangle.rs:398's 1e6, a sphere's distance relaxed upwards, an accepted t > eps) they are
+// equivalent to max(tn, eps) <= min(tf, best_t). fmax / fmin ignore a NaN operand, so a NaN plane parameter (a
+// zero direction component) can only make the test MORE permissive, which culling tolerates; an UNUSED slot has the
+// empty box (lo = +inf, hi = -inf: its entry parameter is +inf or NaN on every axis, its exit parameter -inf or
+// NaN) and misses unless all six are NaN, i.e. unless the ray itself is degenerate -- those rays never get here
+// (ray_is_traversable below).
 __device__ __forceinline__ uint32_t child_key(float nx, float ny, float nz, float fx, float fy, float fz, V3 inv, V3 nodn,
                                               V3 nodf, float eps, float best_t, uint32_t slot) {
     const float tnx = __builtin_fmaf(nx, inv.x, nodn.x);
@@ -313,10 +318,16 @@ __device__ __forceinline__ uint32_t child_key(float nx, float ny, float nz, floa
     const float tfx = __builtin_fmaf(fx, inv.x, nodf.x);
     const float tfy = __builtin_fmaf(fy, inv.y, nodf.y);
     const float tfz = __builtin_fmaf(fz, inv.z, nodf.z);
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
-    const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
-    const bool hit = (tn <= tf) && (tf >= eps) && (tn <= best_t);
-    return hit ? ((__float_as_uint(__builtin_fmaxf(tn, 0.0f)) & ~3u) | slot) : kMissKey;
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), eps);
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), best_t);
+    return tn <= tf ? ((__float_as_uint(tn) & ~3u) | slot) : kMissKey;
+}
+// A ray the slab arithmetic above can be trusted with: finite origin, finite non-zero direction. Anything else gets
+// no mesh hit at all, which is what the reference's ordered compares give it (triangle.rs:190-241: every NaN compare
+// is false) -- callers start such a ray's search at a bound below eps, so that every node test fails.
+__device__ __forceinline__ bool ray_is_traversable(V3 o, V3 d) {
+    const float dd = dot(d, d), oo = dot(o, o);
+    return dd > 0.0f && dd < __builtin_inff() && oo < __builtin_inff();  // (false for NaN)
 }
 
 __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {
@@ -397,8 +408,8 @@ __device__ __forceinline__ void mesh_closest(const DevMesh& M, V3 o, V3 d, float
     float best_t = 1000000.0f;  // triangle.rs:398
     uint32_t best_idx = 0;
     int sp = 0;
-    int32_t cur = 0;  // root
-    for (;;) {
+    int32_t cur = ray_is_traversable(o, d) ? 0 : kNoChild;  // root
+    while (cur != kNoChild) {
         bool pop = true;
         if (cur >= 0) {
             uint32_t k[4];
@@ -756,7 +767,7 @@ __host__ __device__ inline uint32_t megakernel_lds_dwords(uint32_t pool, uint32_
     const uint32_t scene = n_spheres * kSphDw + (n_spheres + n_meshes) * kMatDw + n_meshes * kMeshDw + kGenDw;
     const uint32_t pool_pad = (pool + 63u) & ~63u;  // status + list: one byte per (padded) slot each
     uint32_t dw = uint32_t(kFields) * pool + kCellDw + kTqDw + kHelpDw + pool_pad / 2u + stack_entries * 64u + scene;
-    if (RBRT_REGION_TIMERS) dw = ((dw + 1u) & ~1u) + 2u * uint32_t(kNumRegions);  // analysis build: u64 accumulators per region
+    if (RBRT_REGION_TIMERS) dw += uint32_t(kNumRegions);  // analysis build: a u32 cycle accumulator per region
     return dw;
 }
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {

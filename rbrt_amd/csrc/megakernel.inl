@@ -41,7 +41,8 @@ enum { RBRT_REGIONS(RBRT_REGION_ENUM) kNumRegions };
 #define RBRT_FAST_GATE 1  // mesh bbox gate through bbox_gate_fast (same decisions, no IEEE divisions on the common path)
 #endif
 #ifndef RBRT_PUSH_ORDER
-#define RBRT_PUSH_ORDER 0  // 0: children pushed far-to-near (sorted); 1: nearest next, the rest in slot order
+#define RBRT_PUSH_ORDER 0  // 0: children pushed far-to-near (sorted); 1: nearest next, the rest in slot order;
+                           // 2: like 1 without branches (stores of children that are not pushed go to a sink word in LDS)
 #endif
 #ifndef RBRT_SPHERE_BOUND
 #define RBRT_SPHERE_BOUND 1  // the triangle search of a ray that has hit a sphere starts at that hit's distance
@@ -219,16 +220,18 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     uint32_t* const stack = stack_base + lane;
 #if RBRT_REGION_TIMERS
     // (the accumulators sit at the very end of the workgroup's LDS: megakernel_lds_bytes adds room for them)
-    unsigned long long* const rt_acc = reinterpret_cast<unsigned long long*>(
-        lds + (megakernel_lds_dwords(POOLN, P.stack_entries, P.n_spheres, P.n_meshes) - 2u * kNumRegions));
-    if (lane < uint32_t(kNumRegions)) rt_acc[lane] = 0ull;
+    // (u32: a wave spends at most a few million cycles in a region per launch; 76 bytes fit the slack of the product's
+    // allocation granule, so this build keeps the product's 16 workgroups per CU)
+    uint32_t* const rt_acc = lds + (megakernel_lds_dwords(POOLN, P.stack_entries, P.n_spheres, P.n_meshes) - uint32_t(kNumRegions));
+    if (lane < uint32_t(kNumRegions)) rt_acc[lane] = 0u;
     unsigned long long rt_prev = __builtin_amdgcn_s_memtime();
     const unsigned long long rt_wall0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same clock on every CU
     unsigned long long rt_wall_workout = 0;
+    uint32_t rt_dr_rounds = 0, rt_dr_passes = 0, rt_dr_steps = 0, rt_dr_live = 0, rt_dr_maxb = 0;  // this wave's drain
     uint32_t rt_cur = R_init;
     auto rt_tick = [&](uint32_t next) {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
-        if (lane == 0) rt_acc[rt_cur] += now - rt_prev;
+        if (lane == 0) rt_acc[rt_cur] += uint32_t(now - rt_prev);
         rt_prev = now;
         rt_cur = next;
     };
@@ -385,6 +388,12 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             for (uint32_t k = 0; k < kNumStatus; ++k) cnt[k] += uint32_t(__popcll(wballot(st == k)));
         }
         if (STATS) ++dg_census, dg_dr_rounds += more_work ? 0u : 1u;
+#if RBRT_REGION_TIMERS
+        if (!more_work) {
+            if (rt_dr_rounds == 0) rt_dr_live = uint32_t(POOLN) - cnt[ST_EMPTY];  // paths in hand when the work ran out
+            ++rt_dr_rounds;
+        }
+#endif
         uint32_t n_active = uint32_t(__popcll(wballot(t_active != 0u)));
 
         RBRT_MARK(refill);
@@ -440,9 +449,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         }
                     }
 #endif
+                    // (a degenerate ray -- NaN / inf / zero direction -- takes no mesh hit, like the reference's ordered
+                    // compares give it none: its walk does not start, and the bound below eps fails the accept test)
+                    const bool r_ok = ray_is_traversable(t_o, t_d);
+                    if (!r_ok) t_best = -1.0f, t_best_idx = 0xFFFFFFFFu;
                     t_sp = 0;
                     cell[lane] = ((unsigned long long)__float_as_uint(t_best) << 32) | t_best_idx;
-                    t_cur = 0;
+                    t_cur = r_ok ? 0 : kNoChild;
                     t_pend = kNoChild;
                     t_pend2 = kNoChild;
                     t_active = 1;
@@ -493,6 +506,9 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             constexpr bool SHARE = decltype(share_tag)::value;
         RBRT_MARK(burst_top);
             do {
+#if RBRT_REGION_TIMERS
+                if (!more_work) ++rt_dr_steps;
+#endif
                 if (STATS) {
                     ++dg_steps;
                     if (!more_work) ++dg_dr_steps, dg_dr_lane_steps += uint32_t(__popcll(wballot(t_active != 0u)));
@@ -635,13 +651,59 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     }
                 }
         RBRT_MARK(walk);
+#ifdef RBRT_DUMMY_WALK  // calibration experiment: N extra full-rate VALU instructions per traversal step (the result is unused)
+                {
+                    float dummy = __uint_as_float(t_sp);
+#pragma unroll
+                    for (int i = 0; i < RBRT_DUMMY_WALK; ++i) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
+                    asm volatile("" ::"v"(dummy));
+                }
+#endif
                 if (can_walk) {
                     uint32_t k[4];
                     f32x4 links;
                     node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links);
                     if (STATS) ++lc.nodes;
                     if (STATS && t_cur == 0 && k[0] == kMissKey) ++dg_root_only;  // a traversal that ends at the root
-#if RBRT_PUSH_ORDER == 0
+#if RBRT_PUSH_ORDER == 2
+                    // The nearest child next, the other hit children onto the stack in slot order -- without a branch
+                    // per child: every child's link is stored, to the top of the stack if the child is to be pushed
+                    // and to a sink word otherwise (tq[lane]: the leaf rounds' queue, idle during a walk). Keys are
+                    // distinct (the slot is in their low bits), so "hit and not the nearest" is ONE unsigned compare:
+                    // k - kmin - 1 < miss - kmin - 1. A lane whose stack could leave its LDS part in this step takes the
+                    // general code below (the wave, that is: the test is a vote).
+                    const uint32_t kmin = min(min(k[0], k[1]), min(k[2], k[3]));
+                    if (!wany(t_sp + 4u > n_lds_stack)) {
+                        const uint32_t c1 = ~kmin, lim = kMissKey + c1;
+                        const uint32_t stack_off = uint32_t(uintptr_t((lds_u32*)stack)), sink_off = uint32_t(uintptr_t((lds_u32*)(tq + lane)));
+                        const int32_t lk4[4] = {__float_as_int(links.x), __float_as_int(links.y), __float_as_int(links.z), __float_as_int(links.w)};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool v = (k[j] + c1) < lim;
+                            const uint32_t addr = v ? stack_off + t_sp * 256u : sink_off;
+                            asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(lk4[j]) : "memory");
+                            t_sp += v ? 1u : 0u;
+                        }
+                        if (kmin != kMissKey) {
+                            t_cur = link_of(links, kmin);
+                        } else if (t_sp != 0) {
+                            --t_sp;
+                            int32_t popped;
+                            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(popped) : "v"(stack_off + t_sp * 256u) : "memory");
+                            t_cur = popped;
+                        } else {
+                            t_cur = kNoChild;
+                        }
+                    } else if (kmin != kMissKey) {
+                        if (k[0] != kMissKey && k[0] != kmin) push(__float_as_int(links.x));
+                        if (k[1] != kMissKey && k[1] != kmin) push(__float_as_int(links.y));
+                        if (k[2] != kMissKey && k[2] != kmin) push(__float_as_int(links.z));
+                        if (k[3] != kMissKey && k[3] != kmin) push(__float_as_int(links.w));
+                        t_cur = link_of(links, kmin);
+                    } else {
+                        t_cur = t_sp != 0 ? pop() : kNoChild;
+                    }
+#elif RBRT_PUSH_ORDER == 0
                     if (k[0] != kMissKey) {  // farthest first, so that the nearest is popped first
                         if (k[3] != kMissKey) push(link_of(links, k[3]));
                         if (k[2] != kMissKey) push(link_of(links, k[2]));
@@ -694,6 +756,9 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 
         RBRT_MARK(pass_lists);
         // ============================ shading pass of one kind ===============================
+#if RBRT_REGION_TIMERS
+        if (!more_work) ++rt_dr_passes;
+#endif
         if (STATS) {
             ++dg_pass[kind];
             if (!more_work) ++dg_dr_passes;
@@ -751,6 +816,14 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     }
                 }
                 item = POOL(F_ITEM, slot);  // index of this path's sample in the sample buffer
+#if RBRT_REGION_TIMERS
+                if (!more_work) {  // the longest path this wave finishes in its drain
+                    const uint32_t bounces = P.max_depth - (meta & 127u);
+                    uint32_t mb = bounces;
+                    for (int sh = 32; sh >= 1; sh >>= 1) mb = max(mb, uint32_t(__shfl_xor(int(mb), sh, 64)));
+                    rt_dr_maxb = max(rt_dr_maxb, uint32_t(__builtin_amdgcn_readfirstlane(int(mb))));
+                }
+#endif
                 if (STATS) {  // path-length histogram; bounces = scatter events, recorded or not
                     const uint32_t bounces = P.max_depth - (meta & 127u);
                     atomicAdd(&P.counters->diag[32 + (31 - __clz(int(bounces + 1u)))], 1ull);
@@ -989,7 +1062,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 #undef POOL
 #if RBRT_REGION_TIMERS
     rt_tick(R_init);
-    if (lane < uint32_t(kNumRegions)) atomicAdd(&P.counters->diag[lane], rt_acc[lane]);
+    if (lane < uint32_t(kNumRegions)) atomicAdd(&P.counters->diag[lane], (unsigned long long)rt_acc[lane]);
     if (lane == 0) {  // the launch's phases on the wall clock: ramp-up, bulk, drain
         const unsigned long long rt_wall1 = __builtin_amdgcn_s_memrealtime();
         if (rt_wall_workout == 0) rt_wall_workout = rt_wall1;
@@ -1006,6 +1079,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         const unsigned long long epoch = P.counters->diag[kNumRegions + 8];
         const unsigned long long b = rt_wall0 > epoch ? (rt_wall0 - epoch) / 10000ull : 0ull;
         atomicAdd(&P.counters->diag[32 + (b < 31ull ? b : 31ull)], 1ull);
+        // the wave with the longest drain: [drain in 10-ns ticks : 24 | rounds : 10 | passes : 10 | steps : 12 | paths in hand : 8]
+        // and, keyed the same way, the longest path it finished there
+        const unsigned long long ticks = (rt_wall1 - rt_wall_workout) & 0xFFFFFFull;
+        atomicMax(&P.counters->diag[kNumRegions + 9], (ticks << 40) | ((unsigned long long)(rt_dr_rounds & 1023u) << 30) |
+                                                          ((unsigned long long)(rt_dr_passes & 1023u) << 20) |
+                                                          ((unsigned long long)(rt_dr_steps & 4095u) << 8) | (rt_dr_live & 255u));
+        atomicMax(&P.counters->diag[kNumRegions + 10], (ticks << 40) | rt_dr_maxb);
     }
 #endif
     if (STATS) {

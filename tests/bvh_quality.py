@@ -28,7 +28,7 @@ def cost(N, c_tri=0.35):
     ext = np.maximum(hi - lo, 0.0)
     area = 2.0 * (ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0])  # [n, 4] child areas
     used = link != NO_CHILD
-    area = np.where(used, area, 0.0)  # (unused slots have NaN planes)
+    area = np.where(used, area, 0.0)  # (unused slots hold the empty box: lo = +inf, hi = -inf)
     root_lo = np.where(used[0], lo[0], np.inf).min(1)
     root_hi = np.where(used[0], hi[0], -np.inf).max(1)
     e = root_hi - root_lo

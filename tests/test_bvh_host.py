@@ -65,7 +65,7 @@ def check_invariants(md, N, T, depth, max_e12):
         for k in range(4):
             c = child[node, k]
             if c == NO_CHILD:
-                assert np.isnan(N[node, [k, 4 + k, 8 + k, 12 + k, 16 + k, 20 + k]]).all()
+                assert (N[node, [k, 4 + k, 8 + k]] == np.inf).all() and (N[node, [12 + k, 16 + k, 20 + k]] == -np.inf).all()  # the empty box
                 continue
             blo = N[node, [k, 4 + k, 8 + k]]
             bhi = N[node, [12 + k, 16 + k, 20 + k]]

@@ -56,17 +56,20 @@ def main():
     nr = len(REGIONS)
     before = scene.raw_debug_counters()
     scene.set_timing(True)
-    phases = []
+    phases, slowest = [], []
     for _ in range(args.frames):
         for k in (1, 3):
             scene.set_debug_counter(nr + k, 2**64 - 1)   # minima
         scene.set_debug_counter(nr + 8, scene.raw_debug_counters()[nr + 5])  # epoch of the start histogram: the previous launch's end
-        for k in (2, 4, 5):
+        for k in (2, 4, 5, 9, 10):
             scene.set_debug_counter(nr + k, 0)            # maxima
         scene.render_device(hs.camera, opts, img.data_ptr(), None, stream)
         torch.cuda.synchronize()
         c = scene.raw_debug_counters()
         first_start, last_start, first_out, last_out, last_end = (c[nr + k] for k in (1, 2, 3, 4, 5))
+        slow, slow_b = c[nr + 9], c[nr + 10]
+        slowest.append(dict(drain_us=(slow >> 40) / 100.0, rounds=(slow >> 30) & 1023, passes=(slow >> 20) & 1023, trav_steps=(slow >> 8) & 4095,
+                            paths_in_hand=slow & 255, longest_path_bounces=slow_b & 0xFFFF))
         phases.append(((last_start - first_start) / 100.0, (first_out - first_start) / 100.0, (last_out - first_start) / 100.0,
                        (last_end - first_start) / 100.0))
     ms, _, n = scene.kernel_ms()
@@ -87,6 +90,7 @@ def main():
           f"{sum(p[2] for p in phases) / len(phases):.1f}, last wave ended {sum(p[3] for p in phases) / len(phases):.1f}")
     print(f"# summed drain time of the waves / summed lifetime: {d[nr + 6] / max(1, d[nr + 7]) * 100:.1f} %  ({d[nr + 6] / max(1, waves) / 100:.1f} us of "
           f"{d[nr + 7] / max(1, waves) / 100:.1f} us per wave)")
+    print("# the wave with the longest drain, per launch:", slowest)
     hist = [x // max(1, n) for x in d[32:64]]
     print("# waves by start time, 100-us buckets after the previous launch's end (per launch):", hist)
     print("# grouped")

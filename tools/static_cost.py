@@ -14,7 +14,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 flags = sys.argv[1:]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-DRBRT_MARKERS=1",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-DRBRT_MARKERS=1",
        *flags, "-S", "--cuda-device-only", "-o", "/tmp/static_cost.s", str(ROOT / "rbrt_amd/csrc/kernels.hip")]
 subprocess.run(cmd, check=True, capture_output=True, cwd="/tmp")
 text = Path("/tmp/static_cost.s").read_text().splitlines()
