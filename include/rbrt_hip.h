@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RBRT_ABI_VERSION 1
+#define RBRT_ABI_VERSION 2 /* 2: rbrt_scene_t grew n_triangles / triangles / element_order (appended: the v1 prefix is unchanged) */
 
 typedef enum rbrt_status {
     RBRT_OK = 0,
@@ -101,12 +101,30 @@ typedef struct rbrt_mesh {
     rbrt_material_t mat;       /* one material per mesh (mesh.rs:24) */
 } rbrt_mesh_t;
 
+/* triangle.rs:9-34: BasicTriangle, the reference's second `Intersectable` (lib.rs:38-41) besides Sphere -- a single
+ * triangle as a scene element, corners counter-clockwise. The YAML factory never creates one (blueprints.rs:132-158
+ * builds spheres and meshes only), but Scene::elements is a Vec<Box<dyn Intersectable>> and admits it; a host that
+ * fills it with triangles gets them rendered. Intersection: triangle.rs:92-130 (scalar Moller-Trumbore, |a| < min_dist
+ * rejects, 0 <= u <= 1, v >= 0, u + v <= 1, t > min_dist, then the distance window) and :412-441; the hit normal is
+ * normalize((c1 - c0) x (c2 - c0)) (triangle.rs:30-34), computed by the library, never flipped towards the ray. */
+typedef struct rbrt_triangle {
+    float corners[3][3];
+    rbrt_material_t mat;
+} rbrt_triangle_t;
+
 /* scene.rs:12-16 (lights are always empty in the reference: blueprints.rs:151) */
 typedef struct rbrt_scene {
     uint32_t n_spheres;
-    const rbrt_sphere_t* spheres; /* Scene::elements, YAML order (scene.rs:23-31) */
+    const rbrt_sphere_t* spheres; /* the spheres of Scene::elements, YAML order (scene.rs:23-31) */
     uint32_t n_meshes;
     const rbrt_mesh_t* meshes;    /* Scene::triangle_meshes, YAML order (scene.rs:33-41) */
+    uint32_t n_triangles;
+    const rbrt_triangle_t* triangles; /* the BasicTriangles of Scene::elements */
+    /* Order of Scene::elements (scene.rs:23-31 tests them in that order and the EARLIER element wins a tie in distance):
+     * NULL = all spheres, then all triangles; else n_spheres + n_triangles entries, entry k = the k-th element:
+     * bit 31 clear -> spheres[entry], bit 31 set -> triangles[entry & 0x7fffffff]; every object exactly once.
+     * Object ids (rbrt_hip_trace_rays) follow this order: element k has id k, mesh m has id n_spheres + n_triangles + m. */
+    const uint32_t* element_order;
 } rbrt_scene_t;
 
 /* The 8 of Camera's 14 fields (cam.rs:4-19) that get_ray_through_pixel (cam.rs:64-82) reads. */

@@ -21,8 +21,14 @@ pub struct RbrtMesh {
     pub bbox_lo: [f32; 3], pub bbox_hi: [f32; 3],
     pub mat: RbrtMaterial,
 }
+#[repr(C)] #[derive(Copy, Clone)]
+pub struct RbrtTriangle { pub corners: [[f32; 3]; 3], pub mat: RbrtMaterial }       // BasicTriangle, triangle.rs:9-34
 #[repr(C)]
-pub struct RbrtScene { pub n_spheres: u32, pub spheres: *const RbrtSphere, pub n_meshes: u32, pub meshes: *const RbrtMesh }
+pub struct RbrtScene {
+    pub n_spheres: u32, pub spheres: *const RbrtSphere, pub n_meshes: u32, pub meshes: *const RbrtMesh,
+    pub n_triangles: u32, pub triangles: *const RbrtTriangle,
+    pub element_order: *const u32,   // null, or Scene::elements order: index, bit 31 set for a triangle (ABI version 2)
+}
 #[repr(C)]
 pub struct RbrtCamera {
     pub position: [f32; 3], pub right: [f32; 3], pub up: [f32; 3], pub img_center_point: [f32; 3],

@@ -3,18 +3,30 @@
 // (rbrt_amd/host/render.cpp) and by the ctypes mirror (rbrt_amd/abi.py, checked against the header's layout).
 //
 // Replacement body of `render_scene` in rbrt_lib/src/lib.rs (reference lib.rs:75-124). It reads the scene exactly
-// as the reference stores it (scene.rs:12-16): spheres come out of `scene.elements` through
-// `Intersectable::as_sphere` (trait_additions.rs), meshes out of `scene.triangle_meshes`.
+// as the reference stores it (scene.rs:12-16): spheres and BasicTriangles come out of `scene.elements` through
+// `Intersectable::as_sphere` / `as_basic_triangle` (trait_additions.rs), meshes out of `scene.triangle_meshes`.
 
 pub fn render_scene(cam: Camera, num_samples: u32, scene: Scene) -> image::ImageBuffer<Rgb<u8>, Vec<u8>> {
     use crate::hip_ffi::*;
     println!("Starting rendering...");
     let v3 = |v: Vec3| [v.x, v.y, v.z];
     // Scene::hit tests `elements` in order, then `triangle_meshes` in order (scene.rs:23-41): keep both orders.
-    let spheres: Vec<RbrtSphere> = scene.elements.iter().map(|e| {
-        let s = e.as_sphere().expect("the GPU path supports Sphere elements only (blueprints.rs:144-149 creates no others)");
-        RbrtSphere { center: v3(s.center), radius: s.radius, mat: s.material.as_ffi() }
-    }).collect();
+    // `elements` holds Spheres and (never from the YAML factory, but the type admits them) BasicTriangles: both go over,
+    // with the order they are tested in (an earlier element keeps a tie in distance).
+    let mut spheres: Vec<RbrtSphere> = Vec::new();
+    let mut triangles: Vec<RbrtTriangle> = Vec::new();
+    let mut order: Vec<u32> = Vec::new();
+    for e in scene.elements.iter() {
+        if let Some(s) = e.as_sphere() {
+            order.push(spheres.len() as u32);
+            spheres.push(RbrtSphere { center: v3(s.center), radius: s.radius, mat: s.material.as_ffi() });
+        } else if let Some(t) = e.as_basic_triangle() {
+            order.push(0x8000_0000u32 | triangles.len() as u32);
+            triangles.push(RbrtTriangle { corners: [v3(t.corners[0]), v3(t.corners[1]), v3(t.corners[2])], mat: t.material.as_ffi() });
+        } else {
+            panic!("the GPU path knows Sphere and BasicTriangle elements (the only Intersectable types in rbrt_lib)");
+        }
+    }
     let meshes: Vec<RbrtMesh> = scene.triangle_meshes.iter().map(|m| RbrtMesh {
         n_total: m.is_padding_triangle.len() as u32,
         n_real: m.is_padding_triangle.iter().filter(|p| !**p).count() as u32,
@@ -27,7 +39,9 @@ pub fn render_scene(cam: Camera, num_samples: u32, scene: Scene) -> image::Image
         mat: m.material.as_ffi(),
     }).collect();
     let ffi_scene = RbrtScene { n_spheres: spheres.len() as u32, spheres: spheres.as_ptr(),
-                                n_meshes: meshes.len() as u32, meshes: meshes.as_ptr() };
+                                n_meshes: meshes.len() as u32, meshes: meshes.as_ptr(),
+                                n_triangles: triangles.len() as u32, triangles: triangles.as_ptr(),
+                                element_order: order.as_ptr() };
     let ffi_cam = RbrtCamera { position: v3(cam.position), right: v3(cam.right), up: v3(cam.up),
         img_center_point: v3(cam.img_center_point), mm_per_pix_hor: cam.mm_per_pix_hor,
         mm_per_pix_vert: cam.mm_per_pix_vert, img_width_pix: cam.img_width_pix, img_height_pix: cam.img_height_pix };

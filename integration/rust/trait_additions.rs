@@ -8,13 +8,16 @@
 // ---- rbrt_lib/src/lib.rs:38-41, trait Intersectable: one defaulted method --------------------------------------
 pub trait Intersectable: Sync {
     fn intersect_with_ray(&self, ray: &Ray, min_dist: f32, max_dist: f32) -> Option<HitInformation>;
-    /// The GPU path handles spheres natively; every other element type returns None and is reported
-    /// by render_scene as unsupported (the scene builder, blueprints.rs:144-149, only ever creates spheres here).
+    /// The GPU path takes the concrete parameters of the two Intersectable types rbrt_lib has (the scene builder,
+    /// blueprints.rs:144-149, only ever creates spheres; a BasicTriangle reaches `elements` only from code).
     fn as_sphere(&self) -> Option<&crate::sphere::Sphere> { None }
+    fn as_basic_triangle(&self) -> Option<&crate::triangle::BasicTriangle> { None }
 }
 
 // ---- rbrt_lib/src/sphere.rs:12, inside `impl Intersectable for Sphere` ---------------------------------------------
 //     fn as_sphere(&self) -> Option<&Sphere> { Some(self) }
+// ---- rbrt_lib/src/triangle.rs:412, inside `impl Intersectable for BasicTriangle` ---------------------------------
+//     fn as_basic_triangle(&self) -> Option<&BasicTriangle> { Some(self) }
 
 // ---- rbrt_lib/src/materials.rs:4-12, trait RayScattering: one required method ------------------------------------
 pub trait RayScattering {

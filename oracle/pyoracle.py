@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
     L.rbrt_oracle_kat_scatter_state.restype = C.c_int
     L.rbrt_oracle_kat_scatter_state.argtypes = [C.POINTER(abi.Material), f32p, f32p, f32p, C.c_uint64, C.c_uint32,
                                                 C.c_uint32, f32p, f32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.rbrt_oracle_kat_basic_triangle.restype = C.c_int
+    L.rbrt_oracle_kat_basic_triangle.argtypes = [C.POINTER(abi.Triangle), f32p, C.c_float, C.c_float, f32p, f32p, f32p]
     L.rbrt_oracle_kat_quantise.restype = C.c_uint8
     L.rbrt_oracle_kat_quantise.argtypes = [C.c_float]
     _lib = L

@@ -387,20 +387,61 @@ struct HitIds {
     int32_t obj, tri;
 };
 
-// scene.rs:19-43 — spheres first, then meshes; strictly smaller distance wins.
+// triangle.rs:30-34
+inline V3 get_triangle_normal(const float c[3][3]) {
+    V3 edge1 = v3(c[1]) - v3(c[0]);
+    V3 edge2 = v3(c[2]) - v3(c[0]);
+    return normalize(cross(edge1, edge2));
+}
+
+// triangle.rs:92-130 basic_triangle_intersect_w_ray + triangle.rs:412-441 (Intersectable for BasicTriangle).
+// edges = [c1 - c0, c2 - c0] (triangle.rs:25); `(0.0..=1.0).contains(&u)` is false for a NaN u.
+inline bool basic_triangle_hit(const rbrt_triangle_t& tri, const Ray& ray, float min_dist, float max_dist, Hit& out, float* t_out) {
+    const float eps = min_dist;
+    const V3 v0 = v3(tri.corners[0]);
+    const V3 e0 = v3(tri.corners[1]) - v0, e1 = v3(tri.corners[2]) - v0;
+    const V3 h = cross(ray.direction, e1);
+    const float a = dot(e0, h);
+    if (-eps < a && a < eps) return false;
+    const float f = 1.0f / a;
+    const V3 s = ray.origin - v0;
+    const float u = f * dot(s, h);
+    if (!(0.0f <= u && u <= 1.0f)) return false;
+    const V3 q = cross(s, e0);
+    const float v = f * dot(ray.direction, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = f * dot(e1, q);
+    if (!(t > eps)) return false;
+    const V3 p = ray.point_at(t);
+    const float dist = length(ray.origin - p);
+    if (dist < min_dist || dist > max_dist) return false;  // (checked twice in the reference: :122 and :427)
+    out.point = p;
+    out.normal = get_triangle_normal(tri.corners);  // BasicTriangle::new stores it (triangle.rs:23); never flipped
+    out.mat = &tri.mat;
+    out.dist = dist;
+    if (t_out) *t_out = t;
+    return true;
+}
+
+// scene.rs:19-43 — Scene::elements in their order (spheres and BasicTriangles; rbrt_scene_t::element_order), then the
+// meshes; strictly smaller distance wins, so the earlier object keeps a tie.
 inline bool scene_hit(const rbrt_scene_t& sc, const Ray& ray, float min_dist, float max_dist,
                       Hit& best, HitIds* ids = nullptr) {
     bool any = false;
     float closest = std::numeric_limits<float>::max();
-    for (uint32_t i = 0; i < sc.n_spheres; ++i) {
+    const uint32_t n_elem = sc.n_spheres + sc.n_triangles;
+    for (uint32_t e = 0; e < n_elem; ++e) {
+        const uint32_t desc = sc.element_order ? sc.element_order[e] : (e < sc.n_spheres ? e : (0x80000000u | (e - sc.n_spheres)));
         Hit h;
         float t;
-        if (sphere_hit(sc.spheres[i], ray, min_dist, max_dist, h, &t)) {
+        const bool hit = (desc >> 31) ? basic_triangle_hit(sc.triangles[desc & 0x7FFFFFFFu], ray, min_dist, max_dist, h, &t)
+                                      : sphere_hit(sc.spheres[desc], ray, min_dist, max_dist, h, &t);
+        if (hit) {
             if (h.dist < closest) {
                 closest = h.dist;
                 best = h;
                 any = true;
-                if (ids) *ids = HitIds{t, int32_t(i), -1};
+                if (ids) *ids = HitIds{t, int32_t(e), -1};
             }
         }
     }
@@ -413,7 +454,7 @@ inline bool scene_hit(const rbrt_scene_t& sc, const Ray& ray, float min_dist, fl
                 closest = h.dist;
                 best = h;
                 any = true;
-                if (ids) *ids = HitIds{t, int32_t(sc.n_spheres + i), int32_t(idx)};
+                if (ids) *ids = HitIds{t, int32_t(n_elem + i), int32_t(idx)};
             }
         }
     }
@@ -755,6 +796,17 @@ int rbrt_oracle_kat_scatter_state(const rbrt_material_t* m, const float ray[6], 
     out_ray[3] = o.direction.x, out_ray[4] = o.direction.y, out_ray[5] = o.direction.z;
     state_after[0] = rng.s0, state_after[1] = rng.s1;
     return ok;
+}
+// BasicTriangle::intersect_with_ray alone (triangle.rs:412-441): returns hit, t, distance, normal.
+int rbrt_oracle_kat_basic_triangle(const rbrt_triangle_t* tri, const float ray[6], float min_dist, float max_dist, float* t,
+                                   float* dist, float normal[3]) {
+    Hit h;
+    float tt = 0.0f;
+    Ray r{v3(ray), v3(ray + 3)};
+    if (!basic_triangle_hit(*tri, r, min_dist, max_dist, h, &tt)) return 0;
+    *t = tt, *dist = h.dist;
+    normal[0] = h.normal.x, normal[1] = h.normal.y, normal[2] = h.normal.z;
+    return 1;
 }
 uint8_t rbrt_oracle_kat_quantise(float c) { return quantise(c); }
 

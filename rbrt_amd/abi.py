@@ -60,12 +60,19 @@ class Mesh(C.Structure):
     ]
 
 
+class Triangle(C.Structure):
+    _fields_ = [("corners", (C.c_float * 3) * 3), ("mat", Material)]
+
+
 class Scene(C.Structure):
     _fields_ = [
         ("n_spheres", C.c_uint32),
         ("spheres", C.POINTER(Sphere)),
         ("n_meshes", C.c_uint32),
         ("meshes", C.POINTER(Mesh)),
+        ("n_triangles", C.c_uint32),
+        ("triangles", C.POINTER(Triangle)),
+        ("element_order", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -245,17 +252,28 @@ def fptr(a: np.ndarray):
 class SceneData:
     """Owns the numpy arrays and ctypes arrays a `Scene` struct points into."""
 
-    def __init__(self, spheres=(), meshes=()):
-        # spheres: iterable of (center, radius, Material); meshes: iterable of MeshData
+    def __init__(self, spheres=(), meshes=(), triangles=(), element_order=None):
+        # spheres: iterable of (center, radius, Material); meshes: iterable of MeshData; triangles: iterable of
+        # (corners (3,3), Material); element_order: None or entries as in rbrt_scene_t.element_order
         self.spheres = list(spheres)
         self.meshes = list(meshes)
+        self.triangles = list(triangles)
+        self.element_order = None if element_order is None else [int(x) for x in element_order]
         self._sph = (Sphere * max(1, len(self.spheres)))()
         for i, (c, r, m) in enumerate(self.spheres):
             self._sph[i] = Sphere(_f3(c), float(r), m)
         self._msh = (Mesh * max(1, len(self.meshes)))()
         for i, md in enumerate(self.meshes):
             self._msh[i] = md.struct
-        self.struct = Scene(len(self.spheres), self._sph, len(self.meshes), self._msh)
+        self._tri = (Triangle * max(1, len(self.triangles)))()
+        for i, (corners, m) in enumerate(self.triangles):
+            for a in range(3):
+                for b in range(3):
+                    self._tri[i].corners[a][b] = float(corners[a][b])
+            self._tri[i].mat = m
+        self._order = None if self.element_order is None else (C.c_uint32 * len(self.element_order))(*self.element_order)
+        self.struct = Scene(len(self.spheres), self._sph, len(self.meshes), self._msh, len(self.triangles), self._tri,
+                            self._order if self._order is not None else C.POINTER(C.c_uint32)())
 
     def ptr(self):
         return C.byref(self.struct)

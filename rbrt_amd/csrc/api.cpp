@@ -21,7 +21,7 @@ hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint3
                                    hipStream_t stream);
 size_t megakernel_gseq_bytes(uint32_t n_waves);
 size_t megakernel_gstack_bytes(uint32_t n_waves);
-size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
+size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes, uint32_t n_elem_tris);
 int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes);
 int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
@@ -97,9 +97,11 @@ size_t workspace_cap_bytes() {
 
 struct rbrt_hip_scene {
     int device = 0;
-    uint32_t n_spheres = 0, n_meshes = 0;
+    uint32_t n_spheres = 0, n_meshes = 0, n_elem_tris = 0;
     std::vector<void*> allocs;  // everything hipMalloc'ed for the scene itself
     DevSphere* d_spheres = nullptr;
+    DevTriangle* d_elem_tris = nullptr;  // BasicTriangle elements (triangle.rs:9-34)
+    uint32_t* d_elems = nullptr;         // Scene::elements order (null: no triangles, element e = sphere e)
     DevMaterial* d_materials = nullptr;
     DevMesh* d_meshes = nullptr;
     BvhTri* d_tris = nullptr;  // all meshes' triangle records
@@ -315,7 +317,10 @@ int fill_trace_params(const rbrt_hip_scene* s, const rbrt_camera_t* cam, const r
     P.seed_key = host_splitmix64(o->seed);
     P.n_spheres = s->n_spheres;
     P.n_meshes = s->n_meshes;
+    P.n_elem_tris = s->n_elem_tris;
     P.spheres = s->d_spheres;
+    P.elem_tris = s->d_elem_tris;
+    P.elems = s->d_elems;
     P.materials = s->d_materials;
     P.meshes = s->d_meshes;
     P.tris = s->d_tris;
@@ -402,10 +407,27 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
     *out = nullptr;
     if (scene->n_spheres && !scene->spheres) return fail(RBRT_ERR_INVALID_ARG, "spheres is null");
     if (scene->n_meshes && !scene->meshes) return fail(RBRT_ERR_INVALID_ARG, "meshes is null");
-    if (uint64_t(scene->n_spheres) + scene->n_meshes > uint64_t(kMaxObjects))
-        return fail(RBRT_ERR_UNSUPPORTED, "more than 255 objects (spheres + meshes) in one scene");
+    if (scene->n_triangles && !scene->triangles) return fail(RBRT_ERR_INVALID_ARG, "triangles is null");
+    if (uint64_t(scene->n_spheres) + scene->n_triangles + scene->n_meshes > uint64_t(kMaxObjects))
+        return fail(RBRT_ERR_UNSUPPORTED, "more than 255 objects (spheres + triangles + meshes) in one scene");
     for (uint32_t i = 0; i < scene->n_spheres; ++i)
         if (int rc = check_material(scene->spheres[i].mat)) return rc;
+    for (uint32_t i = 0; i < scene->n_triangles; ++i)
+        if (int rc = check_material(scene->triangles[i].mat)) return rc;
+    // Scene::elements order: the given one (every sphere and triangle exactly once), else spheres then triangles
+    const uint32_t n_elem = scene->n_spheres + scene->n_triangles;
+    std::vector<uint32_t> elems(n_elem);
+    for (uint32_t e = 0; e < n_elem; ++e) elems[e] = e < scene->n_spheres ? e : (0x80000000u | (e - scene->n_spheres));
+    if (scene->element_order && n_elem) {
+        std::vector<uint8_t> seen_s(scene->n_spheres, 0), seen_t(scene->n_triangles, 0);
+        for (uint32_t e = 0; e < n_elem; ++e) {
+            const uint32_t d = scene->element_order[e], idx = d & 0x7FFFFFFFu;
+            std::vector<uint8_t>& seen = (d >> 31) ? seen_t : seen_s;
+            if (idx >= seen.size() || seen[idx]) return fail(RBRT_ERR_INVALID_ARG, "element_order must name every sphere and triangle exactly once");
+            seen[idx] = 1;
+            elems[e] = d;
+        }
+    }
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         const rbrt_mesh_t& m = scene->meshes[i];
         if (int rc = check_material(m.mat)) return rc;
@@ -423,6 +445,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
     s->device = device;
     s->n_spheres = scene->n_spheres;
     s->n_meshes = scene->n_meshes;
+    s->n_elem_tris = scene->n_triangles;
     auto bail = [&](int rc) {
         rbrt_hip_scene_destroy(s);
         return rc;
@@ -441,13 +464,22 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             b.lo[c] = scene->spheres[i].center[c] - scene->spheres[i].radius, b.hi[c] = scene->spheres[i].center[c] + scene->spheres[i].radius;
         s->h_bounds.push_back(b);
     }
+    for (uint32_t i = 0; i < scene->n_triangles; ++i) {
+        rbrt_hip_scene::Bound b;
+        for (int c = 0; c < 3; ++c) {
+            const float x0 = scene->triangles[i].corners[0][c], x1 = scene->triangles[i].corners[1][c], x2 = scene->triangles[i].corners[2][c];
+            b.lo[c] = std::min(x0, std::min(x1, x2)), b.hi[c] = std::max(x0, std::max(x1, x2));
+        }
+        s->h_bounds.push_back(b);
+    }
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         rbrt_hip_scene::Bound b;
         for (int c = 0; c < 3; ++c) b.lo[c] = scene->meshes[i].bbox_lo[c], b.hi[c] = scene->meshes[i].bbox_hi[c];
         s->h_bounds.push_back(b);
     }
     std::vector<DevSphere> spheres(scene->n_spheres);
-    std::vector<DevMaterial> mats(scene->n_spheres + scene->n_meshes);
+    std::vector<DevTriangle> etris(scene->n_triangles);
+    std::vector<DevMaterial> mats(n_elem + scene->n_meshes);  // [object id]: elements in their order, then meshes
     auto put_mat = [&](size_t k, const rbrt_material_t& m) {
         for (int c = 0; c < 3; ++c) mats[k].albedo[c] = m.albedo[c];
         mats[k].param = m.param;
@@ -456,8 +488,17 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
     for (uint32_t i = 0; i < scene->n_spheres; ++i) {
         for (int c = 0; c < 3; ++c) spheres[i].center[c] = scene->spheres[i].center[c];
         spheres[i].radius = scene->spheres[i].radius;
-        put_mat(i, scene->spheres[i].mat);
     }
+    for (uint32_t i = 0; i < scene->n_triangles; ++i) {  // BasicTriangle::new (triangle.rs:19-28): edges and normal, f32, unfused
+        const rbrt_triangle_t& t = scene->triangles[i];
+        DevTriangle& o = etris[i];
+        for (int c = 0; c < 3; ++c) o.v0[c] = t.corners[0][c], o.e0[c] = t.corners[1][c] - t.corners[0][c], o.e1[c] = t.corners[2][c] - t.corners[0][c];
+        const float cx = o.e0[1] * o.e1[2] - o.e0[2] * o.e1[1], cy = o.e0[2] * o.e1[0] - o.e0[0] * o.e1[2], cz = o.e0[0] * o.e1[1] - o.e0[1] * o.e1[0];
+        const float len = std::sqrt((cx * cx + cy * cy) + cz * cz);  // vec3.rs:111-126: length, then three divisions
+        o.normal[0] = cx / len, o.normal[1] = cy / len, o.normal[2] = cz / len;
+    }
+    for (uint32_t e = 0; e < n_elem; ++e)
+        put_mat(e, (elems[e] >> 31) ? scene->triangles[elems[e] & 0x7FFFFFFFu].mat : scene->spheres[elems[e]].mat);
     std::vector<DevMesh> meshes(scene->n_meshes);
     // One triangle array for the scene (leaf links are absolute positions in it): mesh i owns the records
     // [tri_base[i], tri_base[i] + cap[i]), cap = what its builder can emit at most (the scan-visible entries + a dummy).
@@ -489,7 +530,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
     }
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         const rbrt_mesh_t& m = scene->meshes[i];
-        put_mat(scene->n_spheres + i, m.mat);
+        put_mat(n_elem + i, m.mat);
         DevMesh& dm = meshes[i];
         Normal4* d_normals = nullptr;
         {
@@ -557,6 +598,10 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         if (!std::isfinite(dm.radius)) dm.radius = std::numeric_limits<float>::max();
     }
     if (int rc = upload(s, spheres, &s->d_spheres)) return bail(rc);
+    if (scene->n_triangles != 0) {
+        if (int rc = upload(s, etris, &s->d_elem_tris)) return bail(rc);
+        if (int rc = upload(s, elems, &s->d_elems)) return bail(rc);
+    }
     if (int rc = upload(s, mats, &s->d_materials)) return bail(rc);
     if (int rc = upload(s, meshes, &s->d_meshes)) return bail(rc);
     {
@@ -589,7 +634,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         if (const char* e = lab_env("RBRT_SHARE_BELOW")) s->share_below = std::strtoull(e, nullptr, 10);
         if (s->stack_entries > s->stack_need) s->stack_entries = s->stack_need;
         // resident waves per CU: LDS-limited (160 KiB per CU), at most 5 per SIMD (VGPR budget)
-        int per_cu = int((160u * 1024u) / megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes));
+        int per_cu = int((160u * 1024u) / megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes, s->n_elem_tris));
         if (per_cu > 20) per_cu = 20;
         if (per_cu < 1) per_cu = 1;
         if (waves_per_cu != 0) per_cu = int(waves_per_cu), s->waves_fixed = true;
@@ -896,7 +941,7 @@ int rbrt_hip_scene_info(rbrt_hip_scene_t* s, rbrt_hip_scene_info_t* out) {
     out->bvh_stack_need = s->stack_need;
     out->n_nodes = s->total_nodes, out->n_triangles = s->total_tris;
     out->trace_waves = s->n_waves;
-    out->lds_bytes_per_wave = uint32_t(megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes));
+    out->lds_bytes_per_wave = uint32_t(megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes, s->n_elem_tris));
     (void)hipSetDevice(s->device);
     out->occupancy_api_waves_per_cu = uint32_t(megakernel_occupancy_per_cu(s->pool, out->lds_bytes_per_wave));
     out->n_cus = s->n_cus;

@@ -62,6 +62,11 @@ struct DevSphere {
     float radius;
 };
 
+// A BasicTriangle element (triangle.rs:9-34): first corner, the two edges from it, the stored normal.
+struct DevTriangle {
+    float v0[3], e0[3], e1[3], normal[3];
+};
+
 struct DevMaterial {
     float albedo[3];
     float param;
@@ -102,8 +107,12 @@ struct TraceParams {
     uint32_t max_depth;
     uint64_t seed_key;  // splitmix64(seed)
     uint32_t n_spheres, n_meshes;
+    uint32_t n_elem_tris;          // BasicTriangle elements (rbrt_scene_t::triangles)
     const DevSphere* spheres;
-    const DevMaterial* materials;  // [object id]: spheres first, then meshes
+    const DevTriangle* elem_tris;
+    const uint32_t* elems;         // [n_spheres + n_elem_tris] Scene::elements order: bit 31 set = elem_tris[low bits], else spheres[..];
+                                   // null when there are no triangles (element e is sphere e)
+    const DevMaterial* materials;  // [object id]: the elements in their order, then the meshes
     const DevMesh* meshes;
     const BvhTri* tris;  // the triangle records of ALL meshes, one array; leaf links hold absolute positions in it
     // work decomposition

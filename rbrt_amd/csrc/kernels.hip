@@ -172,6 +172,34 @@ __device__ __forceinline__ bool sphere_hit(V3 c, float radius, V3 o, V3 d, float
     return true;
 }
 
+// triangle.rs:92-130 (basic_triangle_intersect_w_ray) + :412-441: one BasicTriangle element. Scalar Moller-Trumbore
+// with the reference's tests in the reference's order; `(0.0..=1.0).contains(&u)` is false for a NaN u, the other
+// compares are false for NaN operands, so a NaN t ends in `t > eps` being false. No upper bound on t but the
+// distance window.
+__device__ __forceinline__ bool basic_triangle_hit(const float* tri /* v0, e0, e1 */, V3 o, V3 d, float min_dist, float max_dist,
+                                                   float& t_out, float& dist_out) {
+    const float eps = min_dist;
+    const V3 v0 = mk(tri), e0 = mk(tri + 3), e1 = mk(tri + 6);
+    const V3 h = cross(d, e1);
+    const float a = dot(e0, h);
+    if (-eps < a && a < eps) return false;
+    const float f = 1.0f / a;
+    const V3 s = o - v0;
+    const float u = f * dot(s, h);
+    if (!(0.0f <= u && u <= 1.0f)) return false;
+    const V3 q = cross(s, e0);
+    const float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = f * dot(e1, q);
+    if (!(t > eps)) return false;
+    const V3 p = o + t * d;
+    const float dist = length(o - p);
+    if (dist < min_dist || dist > max_dist) return false;
+    t_out = t;
+    dist_out = dist;
+    return true;
+}
+
 // aabbox.rs:28-58, verbatim: six true divisions, NaN-ignoring min/max (fminf/fmaxf = f32::min/max).
 __device__ __forceinline__ bool bbox_gate(const float* lo, const float* hi, V3 o, V3 d) {
     float t_lower_x = (lo[0] - o.x) / d.x;
@@ -438,7 +466,7 @@ __device__ __forceinline__ void mesh_closest(const DevMesh& M, V3 o, V3 d, float
 struct HitRec {
     float dist;   // dist_from_ray_orig of the winner (lib.rs:35)
     float t;      // its ray parameter
-    int32_t obj;  // -1 miss, [0,n_spheres) sphere, n_spheres + m mesh
+    int32_t obj;  // -1 miss, [0, n_elem) an element of Scene::elements (sphere or BasicTriangle), n_elem + m mesh
     uint32_t tri;
 };
 
@@ -451,15 +479,21 @@ __device__ __forceinline__ void scene_hit(const TraceParams& P, V3 o, V3 d, uint
     h.t = 0.0f;
     h.tri = 0;
     if (STATS) ++lc.rays;
-    for (uint32_t i = 0; i < P.n_spheres; ++i) {
-        const DevSphere sp = P.spheres[i];
+    const uint32_t n_elem = P.n_spheres + P.n_elem_tris;
+    for (uint32_t e = 0; e < n_elem; ++e) {  // Scene::elements in their order (scene.rs:23-31)
+        const uint32_t desc = P.elems != nullptr ? P.elems[e] : e;
         float t, dist;
-        if (sphere_hit(mk(sp.center), sp.radius, o, d, P.min_dist, P.max_dist, t, dist, P.counters)) {
-            if (dist < closest) {
-                closest = dist;
-                h.t = t;
-                h.obj = int32_t(i);
-            }
+        bool hit;
+        if (desc >> 31) {
+            hit = basic_triangle_hit(P.elem_tris[desc & 0x7FFFFFFFu].v0, o, d, P.min_dist, P.max_dist, t, dist);
+        } else {
+            const DevSphere sp = P.spheres[desc];
+            hit = sphere_hit(mk(sp.center), sp.radius, o, d, P.min_dist, P.max_dist, t, dist, P.counters);
+        }
+        if (hit && dist < closest) {
+            closest = dist;
+            h.t = t;
+            h.obj = int32_t(e);
         }
     }
     for (uint32_t m = 0; m < P.n_meshes; ++m) {
@@ -477,7 +511,7 @@ __device__ __forceinline__ void scene_hit(const TraceParams& P, V3 o, V3 d, uint
                 if (dist < closest) {
                     closest = dist;
                     h.t = t;
-                    h.obj = int32_t(P.n_spheres + m);
+                    h.obj = int32_t(n_elem + m);
                     h.tri = idx;
                 }
             }
@@ -567,7 +601,8 @@ __device__ __forceinline__ bool scatter(const DevMaterial& m, V3 in_d, V3 p, V3 
     }
 }
 
-__host__ __device__ inline uint32_t megakernel_lds_dwords(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes);
+__host__ __device__ inline uint32_t megakernel_lds_dwords(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes,
+                                                          uint32_t n_elem_tris);
 #include "megakernel.inl"
 
 // lib.rs:116-122: (sqrt(c) * 256) as u8 — Rust's float->int cast saturates and maps NaN to 0.
@@ -686,7 +721,7 @@ __global__ __launch_bounds__(kRaysBlock) void trace_rays_kernel(const TraceParam
     const float nanv = __int_as_float(0x7fc00000);
     if (out_t) out_t[i] = hit ? h.t : nanv;
     if (out_obj) out_obj[i] = h.obj;
-    if (out_tri) out_tri[i] = (hit && uint32_t(h.obj) >= P.n_spheres) ? int32_t(h.tri) : -1;
+    if (out_tri) out_tri[i] = (hit && uint32_t(h.obj) >= P.n_spheres + P.n_elem_tris) ? int32_t(h.tri) : -1;
     if (out_dist) out_dist[i] = hit ? h.dist : nanv;
 }
 
@@ -763,15 +798,18 @@ __global__ __launch_bounds__(kBlock) void scatter_debug_kernel(const DevMaterial
 size_t megakernel_gseq_bytes(uint32_t n_waves) { return size_t(n_waves) * kPoolMax * kSeqWords * sizeof(uint32_t); }
 size_t megakernel_gstack_bytes(uint32_t n_waves) { return size_t(n_waves) * kStackMax * 64u * sizeof(uint32_t); }
 
-__host__ __device__ inline uint32_t megakernel_lds_dwords(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
-    const uint32_t scene = n_spheres * kSphDw + (n_spheres + n_meshes) * kMatDw + n_meshes * kMeshDw + kGenDw;
+__host__ __device__ inline uint32_t megakernel_lds_dwords(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes,
+                                                          uint32_t n_elem_tris) {
+    const uint32_t n_elem = n_spheres + n_elem_tris;
+    const uint32_t scene = n_spheres * kSphDw + (n_elem + n_meshes) * kMatDw + n_meshes * kMeshDw + kGenDw +
+                           (n_elem_tris != 0u ? n_elem_tris * kTriDw + n_elem : 0u);  // triangle table + element order
     const uint32_t pool_pad = (pool + 63u) & ~63u;  // status + list: one byte per (padded) slot each
     uint32_t dw = uint32_t(kFields) * pool + kCellDw + kTqDw + kHelpDw + pool_pad / 2u + stack_entries * 64u + scene;
     if (RBRT_REGION_TIMERS) dw += uint32_t(kNumRegions);  // analysis build: a u32 cycle accumulator per region
     return dw;
 }
-size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes) {
-    return size_t(megakernel_lds_dwords(pool, stack_entries, n_spheres, n_meshes)) * sizeof(uint32_t);
+size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes, uint32_t n_elem_tris) {
+    return size_t(megakernel_lds_dwords(pool, stack_entries, n_spheres, n_meshes, n_elem_tris)) * sizeof(uint32_t);
 }
 
 // What the HIP runtime says fits: resident single-wave workgroups of the trace kernel per CU at this much LDS (0 on error).
@@ -787,7 +825,7 @@ int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes) {
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats, bool share,
                                    hipStream_t stream) {
     if (P.n_items == 0 || n_waves == 0) return hipSuccess;
-    const size_t lds = megakernel_lds_bytes(pool, P.stack_entries, P.n_spheres, P.n_meshes);
+    const size_t lds = megakernel_lds_bytes(pool, P.stack_entries, P.n_spheres, P.n_meshes, P.n_elem_tris);
 #define RBRT_LAUNCH_MK(POOLN, STATS, SHARE) \
     hipLaunchKernelGGL((trace_megakernel<POOLN, STATS, SHARE>), dim3(n_waves), dim3(64), lds, stream, P)
 #define RBRT_LAUNCH_POOL(POOLN)                            \

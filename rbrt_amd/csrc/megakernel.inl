@@ -82,6 +82,7 @@ __device__ __forceinline__ uint32_t pack_meta(uint32_t depth, uint32_t nrec, int
 // Scene constants staged in LDS at kernel start (a copy of the DevSphere / DevMaterial / DevMesh
 // arrays as dwords), so that the shading passes do not chain dependent global loads.
 constexpr uint32_t kSphDw = sizeof(DevSphere) / 4, kMatDw = sizeof(DevMaterial) / 4, kMeshDw = sizeof(DevMesh) / 4;
+constexpr uint32_t kTriDw = sizeof(DevTriangle) / 4;  // v0, e0, e1, normal
 static_assert(sizeof(DevSphere) == 16 && sizeof(DevMaterial) == 20 && sizeof(DevMesh) == 80, "LDS scene table layout");
 enum { MD_NODES = 0, MD_TRIS = 2, MD_NORMALS = 4, MD_BBOX_LO = 6, MD_BBOX_HI = 9, MD_CENTER = 12, MD_RADIUS = 15 };
 static_assert(offsetof(DevMesh, tris) == 8 && offsetof(DevMesh, normals) == 16 && offsetof(DevMesh, bbox_lo) == 24 &&
@@ -92,8 +93,10 @@ enum { G_POS = 0, G_RIGHT = 3, G_UP = 6, G_CENTER = 9, G_MMH = 12, G_MMV, G_W, G
        G_TILES_X_MAGIC, G_TILE_WORLD, G_TILE_RANK, G_N_LOCAL, G_REVERSED, G_SAMPLE_BASE, G_MAX_DEPTH, G_SEED_LO, G_SEED_HI, kGenDw };
 struct SceneLds {
     const float* sph;      // [n_spheres][4]: centre xyz, radius
-    const uint32_t* mat;   // [n_spheres + n_meshes][5]: albedo xyz, param, kind
+    const uint32_t* mat;   // [n_elem + n_meshes][5]: albedo xyz, param, kind (n_elem = spheres + BasicTriangle elements)
     const uint32_t* mesh;  // [n_meshes][20]: DevMesh as dwords
+    const float* tri;      // [n_elem_tris][12]: v0, e0, e1, normal of the BasicTriangle elements (only when there are any)
+    const uint32_t* elem;  // [n_elem] Scene::elements order, bit 31 = triangle (only when there are triangles: else element e = sphere e)
 };
 template <class T>
 __device__ __forceinline__ const T* lds_ptr(const uint32_t* p) {  // a 64-bit device pointer stored as two dwords
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     // (the accumulators sit at the very end of the workgroup's LDS: megakernel_lds_bytes adds room for them)
     // (u32: a wave spends at most a few million cycles in a region per launch; 76 bytes fit the slack of the product's
     // allocation granule, so this build keeps the product's 16 workgroups per CU)
-    uint32_t* const rt_acc = lds + (megakernel_lds_dwords(POOLN, P.stack_entries, P.n_spheres, P.n_meshes) - uint32_t(kNumRegions));
+    uint32_t* const rt_acc = lds + (megakernel_lds_dwords(POOLN, P.stack_entries, P.n_spheres, P.n_meshes, P.n_elem_tris) - uint32_t(kNumRegions));
     if (lane < uint32_t(kNumRegions)) rt_acc[lane] = 0u;
     unsigned long long rt_prev = __builtin_amdgcn_s_memtime();
     const unsigned long long rt_wall0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same clock on every CU
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     cell[lane] = kNoHitKey;
     if (lane < kHelpDw) helpers[lane] = 0u;
     // scene tables behind the stacks
-    const uint32_t n_obj = P.n_spheres + P.n_meshes;
+    const uint32_t n_elem = P.n_spheres + P.n_elem_tris;  // Scene::elements: spheres and BasicTriangles, in the scene's order
+    const uint32_t n_obj = n_elem + P.n_meshes;
     uint32_t* const sc_base = stack_base + P.stack_entries * 64u;
     {
         const uint32_t* gs = reinterpret_cast<const uint32_t*>(P.spheres);
@@ -258,6 +262,14 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         // what path generation reads (camera, work decomposition): kept in LDS rather than in ~30 SGPRs that the
         // rest of the kernel would have to spill around (the spill code is VALU: v_readlane / v_writelane)
         dst += P.n_meshes * kMeshDw;
+        uint32_t* const gen_dst = dst;
+        if (P.n_elem_tris != 0u) {  // behind the generation parameters: the triangle elements and the element order
+            const uint32_t* gt = reinterpret_cast<const uint32_t*>(P.elem_tris);
+            uint32_t* td = gen_dst + kGenDw;
+            for (uint32_t i = lane; i < P.n_elem_tris * kTriDw; i += 64) td[i] = gt[i];
+            td += P.n_elem_tris * kTriDw;
+            for (uint32_t i = lane; i < n_elem; i += 64) td[i] = P.elems[i];
+        }
         if (lane == 0) {
             float* gf = reinterpret_cast<float*>(dst);
             for (int c = 0; c < 3; ++c) {
@@ -277,7 +289,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     const uint32_t* const gp = sc_base + P.n_spheres * kSphDw + n_obj * kMatDw + P.n_meshes * kMeshDw;
     const float* const gpf = reinterpret_cast<const float*>(gp);
     const SceneLds sc = {reinterpret_cast<const float*>(sc_base), sc_base + P.n_spheres * kSphDw,
-                         sc_base + P.n_spheres * kSphDw + n_obj * kMatDw};
+                         sc_base + P.n_spheres * kSphDw + n_obj * kMatDw, reinterpret_cast<const float*>(gp + kGenDw),
+                         gp + kGenDw + P.n_elem_tris * kTriDw};
     // work items are reserved from the global counter in chunks, the next chunk asynchronously
     WorkSource work;
     work.init(P);
@@ -350,8 +363,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 int32_t obj = int32_t((meta >> 14) & 255u) - 1;
                 float closest = 3.40282347e+38f;  // f32::MAX (scene.rs:21)
                 if (obj >= 0) {                   // dist_from_ray_orig of the closest hit so far
-                    if (uint32_t(obj) < P.n_spheres) {
-                        closest = __uint_as_float(POOL(F_TRI, slot));  // a sphere: stored by the pass that found it
+                    if (uint32_t(obj) < n_elem) {
+                        closest = __uint_as_float(POOL(F_TRI, slot));  // an element (sphere / triangle): stored by the pass that found it
                     } else {                      // an earlier mesh of this ray: recomputed as it was computed
                         const V3 pc = t_o + __uint_as_float(POOL(F_T, slot)) * t_d;
                         closest = length(t_o - pc);
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         if (STATS) ++lc.mesh_hits;
                         if (dist < closest) {
                             closest = dist;
-                            obj = int32_t(P.n_spheres + t_mesh);
+                            obj = int32_t(n_elem + t_mesh);
                             POOL(F_T, slot) = __float_as_uint(t_best);
                             POOL(F_TRI, slot) = t_best_idx;
                         }
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                                            // its distance to the same few ulps)
                             const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t_o.x), __builtin_fabsf(t_o.y)),
                                                                __builtin_fabsf(t_o.z));
-                            const float ref = __uint_as_float(uint32_t(r_obj) < P.n_spheres ? POOL(F_TRI, slot) : POOL(F_T, slot));
+                            const float ref = __uint_as_float(uint32_t(r_obj) < n_elem ? POOL(F_TRI, slot) : POOL(F_T, slot));
                             const float bound = ref * 1.001f + 0.001f * (1.0f + omax);
                             if (bound < 100000.0f) t_best = bound, t_best_idx = 0xFFFFFFFFu;
                         }
@@ -943,11 +956,13 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             if (scat) {
                 const V3 p = o + s_ht * d;  // same expression as inside the intersection routines
                 V3 n;
-                if (uint32_t(s_obj) < P.n_spheres) {
-                    n = p - mk(sc.sph + uint32_t(s_obj) * kSphDw);  // sphere.rs:56, unnormalised
+                if (uint32_t(s_obj) < n_elem) {
+                    const uint32_t desc = P.n_elem_tris != 0u ? sc.elem[uint32_t(s_obj)] : uint32_t(s_obj);
+                    if (desc >> 31) n = mk(sc.tri + (desc & 0x7FFFFFFFu) * kTriDw + 9);  // triangle.rs:432: the stored normal
+                    else n = p - mk(sc.sph + desc * kSphDw);                            // sphere.rs:56, unnormalised
                 } else {
                     const Normal4 nn =
-                        lds_ptr<Normal4>(sc.mesh + (uint32_t(s_obj) - P.n_spheres) * kMeshDw + MD_NORMALS)[s_tri];
+                        lds_ptr<Normal4>(sc.mesh + (uint32_t(s_obj) - n_elem) * kMeshDw + MD_NORMALS)[s_tri];
                     n = mk(nn.x, nn.y, nn.z);  // mesh.rs:253-257
                 }
                 DevMaterial m;
@@ -1003,8 +1018,10 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 if (STATS) ++lc.rays;
                 s_obj = -1;
                 s_ht = 0.0f;
-                for (uint32_t i = 0; i < P.n_spheres; ++i) {
-                    const float* sp = sc.sph + i * kSphDw;
+                // Scene::elements in their order (scene.rs:23-31). Two copies of the loop: a scene without BasicTriangles
+                // (every scene the reference's YAML can describe) runs the one that knows only spheres -- with the
+                // element-kind test inside a single loop the sphere-only frame was 2 % slower.
+                auto test_sphere = [&](uint32_t e, const float* sp) {
                     float t, dist;
                     if (STATS) {  // how often a wave runs the expensive part of sphere_hit, and for how many lanes
                         const V3 l = o - mk(sp);
@@ -1017,7 +1034,26 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         if (dist < closest) {
                             closest = dist;
                             s_ht = t;
-                            s_obj = int32_t(i);
+                            s_obj = int32_t(e);
+                        }
+                    }
+                };
+                if (P.n_elem_tris == 0u) {
+                    for (uint32_t i = 0; i < P.n_spheres; ++i) test_sphere(i, sc.sph + i * kSphDw);
+                } else {
+                    for (uint32_t e = 0; e < n_elem; ++e) {
+                        const uint32_t desc = sc.elem[e];  // (wave-uniform: which kind of element this is)
+                        if (desc >> 31) {
+                            float t, dist;
+                            if (basic_triangle_hit(sc.tri + (desc & 0x7FFFFFFFu) * kTriDw, o, d, P.min_dist, P.max_dist, t, dist)) {
+                                if (dist < closest) {
+                                    closest = dist;
+                                    s_ht = t;
+                                    s_obj = int32_t(e);
+                                }
+                            }
+                        } else {
+                            test_sphere(e, sc.sph + desc * kSphDw);
                         }
                     }
                 }

@@ -116,6 +116,13 @@ struct Sphere {
     Material material;
 };
 
+// triangle.rs:9-34: a single triangle as a scene element (the reference's second Intersectable). The YAML factory
+// never creates one; a C++ caller may (Scene::basic_triangles / element_order below).
+struct BasicTriangle {
+    std::array<Vec3, 3> corners;  // counter-clockwise
+    Material material;
+};
+
 struct TriangleMesh {
     // mesh.rs:12-25; vertices[1], vertices[2] are kept like the reference keeps them, although
     // nothing on the hot path reads them.
@@ -142,11 +149,18 @@ Vec3 get_triangle_normal(const std::array<Vec3, 3>& corners);                   
 void compute_min_max_3d(const std::vector<std::array<Vec3, 3>>& tris, Vec3& lo, Vec3& hi);  // aabbox.rs:62-88
 
 struct Scene {
+    // scene.rs:12-16: `elements: Vec<Box<dyn Intersectable + Sync>>` holds Spheres and BasicTriangles. Here the two
+    // kinds sit in their own vectors; `element_order` gives the order Scene::hit tests them in (scene.rs:23-31: an
+    // earlier element keeps a tie) as entries (index, or 0x80000000 | index for a triangle) -- empty = all spheres,
+    // then all triangles, which is what every scene the YAML factory can build looks like.
     std::vector<Sphere> elements;
+    std::vector<BasicTriangle> basic_triangles;
+    std::vector<uint32_t> element_order;
     std::vector<TriangleMesh> triangle_meshes;
     // POD view for the C ABI; valid while this Scene is alive and unmodified.
     struct AbiView {
         std::vector<rbrt_sphere_t> spheres;
+        std::vector<rbrt_triangle_t> triangles;
         std::vector<rbrt_mesh_t> meshes;
         rbrt_scene_t scene{};
     };

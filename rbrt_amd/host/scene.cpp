@@ -384,9 +384,22 @@ Scene::AbiView Scene::to_abi() const {
         a.mat = s.material.abi;
         v.spheres.push_back(a);
     }
+    for (const BasicTriangle& t : basic_triangles) {
+        rbrt_triangle_t a{};
+        for (int k = 0; k < 3; ++k) put3(a.corners[k], t.corners[k]);
+        a.mat = t.material.abi;
+        v.triangles.push_back(a);
+    }
     for (const TriangleMesh& m : triangle_meshes) v.meshes.push_back(m.to_abi());
     v.scene.n_spheres = uint32_t(v.spheres.size());
     v.scene.spheres = v.spheres.data();
+    v.scene.n_triangles = uint32_t(v.triangles.size());
+    v.scene.triangles = v.triangles.data();
+    if (!element_order.empty()) {
+        if (element_order.size() != elements.size() + basic_triangles.size())
+            throw Error("Scene::element_order must name every sphere and triangle exactly once");
+        v.scene.element_order = element_order.data();
+    }
     v.scene.n_meshes = uint32_t(v.meshes.size());
     v.scene.meshes = v.meshes.data();
     return v;

@@ -31,6 +31,9 @@ CASES = {
     "mesh2003_160x120x4_seed2": dict(kind="mesh", n=2003, w=160, h=120, spp=4, seed=2),
     "mesh2004_160x120x4_seed2": dict(kind="mesh", n=2004, w=160, h=120, spp=4, seed=2),
     "mesh2006_160x120x4_seed2": dict(kind="mesh", n=2006, w=160, h=120, spp=4, seed=2),
+    # BasicTriangle elements (triangle.rs:9-34) interleaved with the example spheres, without and with a mesh behind them
+    "triangles_200x150x8_seed3": dict(kind="triangles", n=0, w=200, h=150, spp=8, seed=3),
+    "triangles_mesh1203_160x120x4_seed4": dict(kind="triangles", n=1203, w=160, h=120, spp=4, seed=4),
 }
 
 
@@ -39,6 +42,8 @@ def build_scene(case):
         return scenes.spheres_scene()
     if case["kind"] == "header_spheres":
         return scenes.spheres_scene(scenes.HEADER_SPHERES)
+    if case["kind"] == "triangles":
+        return scenes.triangle_scene(pyoracle, case["n"])
     return scenes.example_scene(pyoracle, case["n"])
 
 
@@ -46,8 +51,10 @@ def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def main():
+def main(only=None):
     for name, case in CASES.items():
+        if only and only not in name:
+            continue
         cam = scenes.camera(pyoracle, case["w"], case["h"])
         sc = build_scene(case)
         rad, rgb, rays = pyoracle.render(cam, sc, abi.default_opts(spp=case["spp"], seed=case["seed"]))
@@ -55,6 +62,8 @@ def main():
                             radiance_sub=rad[::4, ::4].copy(), rgb8_sub=rgb[::4, ::4].copy(), rays=np.int64(rays),
                             mean=rad.mean(axis=(0, 1)))
         print(name, sha(rad)[:16], rays)
+    if only:
+        return
     # single-ray records: Scene::hit on a fixed bundle of rays through the example scene + 3001-triangle stand-in
     sc = scenes.example_scene(pyoracle, 3001)
     md = sc.meshes[0]
@@ -116,6 +125,8 @@ def make_scatter_events():
 if __name__ == "__main__":
     if sys.argv[1:] == ["scatter"]:
         make_scatter_events()
+    elif sys.argv[1:2] == ["only"]:
+        main(sys.argv[2])
     else:
         main()
         make_scatter_events()

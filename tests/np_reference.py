@@ -205,19 +205,55 @@ def mesh_hit(mesh, o, d, min_dist, max_dist):  # mesh.rs:225-267
 # ---------------------------------------------------------------------------------------------------------------
 # scene.rs:19-43
 # ---------------------------------------------------------------------------------------------------------------
+def basic_triangle_hit(corners, o, d, min_dist, max_dist):
+    """triangle.rs:92-130 + 412-441 (BasicTriangle): returns None or (point, normal, dist, t). corners: (3,3) f32."""
+    eps = f32(min_dist)
+    v0 = corners[0]
+    e0, e1 = corners[1] - corners[0], corners[2] - corners[0]  # triangle.rs:25
+    h = cross(d, e1)
+    a = dot(e0, h)
+    if -eps < a < eps:
+        return None
+    f = f32(f32(1.0) / a)
+    s = o - v0
+    u = f32(f * dot(s, h))
+    if not (f32(0.0) <= u <= f32(1.0)):  # (0.0..=1.0).contains(&u): false for NaN
+        return None
+    q = cross(s, e0)
+    v = f32(f * dot(d, q))
+    if v < f32(0.0) or f32(u + v) > f32(1.0):
+        return None
+    t = f32(f * dot(e1, q))
+    if not (t > eps):
+        return None
+    p = point_at(o, d, t)
+    dist = length(o - p)
+    if dist < f32(min_dist) or dist > f32(max_dist):
+        return None
+    return p, normalize(cross(e0, e1)), dist, t  # triangle.rs:30-34: stored at construction, never flipped
+
+
 def scene_hit(scene, o, d, min_dist, max_dist):
-    """scene: dict(spheres=[(center, radius, mat)], meshes=[mesh dicts with 'mat']). Returns None or a dict."""
+    """scene: dict(spheres=[(center, radius, mat)], meshes=[mesh dicts with 'mat'], optional triangles=[(corners, mat)] and
+    order=[(kind, index)] = Scene::elements order, kind 's' or 't'). Returns None or a dict."""
     best, closest = None, np.finfo(f32).max
-    for i, (c, r, m) in enumerate(scene["spheres"]):
-        h = sphere_hit(c, r, o, d, min_dist, max_dist)
+    tris = scene.get("triangles", [])
+    order = scene.get("order") or [("s", i) for i in range(len(scene["spheres"]))] + [("t", i) for i in range(len(tris))]
+    for e, (kind, i) in enumerate(order):
+        if kind == "s":
+            c, r, m = scene["spheres"][i]
+            h = sphere_hit(c, r, o, d, min_dist, max_dist)
+        else:
+            corners, m = tris[i]
+            h = basic_triangle_hit(corners, o, d, min_dist, max_dist)
         if h is not None and h[2] < closest:
             closest = h[2]
-            best = dict(point=h[0], normal=h[1], dist=h[2], t=h[3], mat=m, obj=i, tri=-1)
+            best = dict(point=h[0], normal=h[1], dist=h[2], t=h[3], mat=m, obj=e, tri=-1)
     for k, mesh in enumerate(scene["meshes"]):
         h = mesh_hit(mesh, o, d, min_dist, max_dist)
         if h is not None and h[2] < closest:
             closest = h[2]
-            best = dict(point=h[0], normal=h[1], dist=h[2], t=h[3], mat=mesh["mat"], obj=len(scene["spheres"]) + k, tri=h[4])
+            best = dict(point=h[0], normal=h[1], dist=h[2], t=h[3], mat=mesh["mat"], obj=len(order) + k, tri=h[4])
     return best
 
 

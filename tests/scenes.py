@@ -69,3 +69,22 @@ def random_soup(rng: np.random.Generator, n, extent=1.0, size=0.3):
     """n random triangles (n,3,3) float32 inside a cube of half-size `extent`."""
     c = rng.uniform(-extent, extent, (n, 1, 3))
     return (c + rng.uniform(-size, size, (n, 3, 3))).astype(np.float32)
+
+
+# A scene with BasicTriangle elements (triangle.rs:9-34; the reference's YAML cannot express them, its API can):
+# the example scene's spheres + a metal mirror quad (two triangles) behind them, a glass triangle in front of the camera
+# and a diffuse one lying on the ground. Elements are INTERLEAVED with the spheres (Scene::elements order matters for
+# ties only, but object ids follow it).
+TRIANGLES = [
+    (((-9.0, 0.0, -19.0), (3.0, 0.0, -21.0), (3.0, 7.0, -21.0)), abi.material(M, (0.9, 0.85, 0.8), 0.02)),
+    (((-9.0, 0.0, -19.0), (3.0, 7.0, -21.0), (-9.0, 7.0, -19.0)), abi.material(M, (0.9, 0.85, 0.8), 0.02)),
+    (((-1.5, 0.3, -5.5), (1.0, 0.4, -6.0), (-0.2, 2.6, -6.5)), abi.material(D, (0, 0, 0), 1.5)),
+    (((2.0, 0.02, -6.0), (5.5, 0.02, -7.0), (3.0, 0.02, -9.5)), abi.material(L, (0.8, 0.3, 0.1))),
+]
+T = 0x80000000
+TRIANGLE_ORDER = [0, T | 0, 1, T | 2, 2, T | 1, 3, T | 3]  # sphere 0, tri 0, sphere 1, tri 2, sphere 2, tri 1, sphere 3, tri 3
+
+
+def triangle_scene(oracle=None, n_mesh_triangles=0, order=TRIANGLE_ORDER):
+    meshes = [standin_mesh(oracle, n_mesh_triangles, **EXAMPLE_MESH)] if n_mesh_triangles else []
+    return abi.SceneData(spheres=EXAMPLE_SPHERES, meshes=meshes, triangles=TRIANGLES, element_order=order)

@@ -11,7 +11,7 @@ from rbrt_amd import abi, tiles
 
 ROOT = Path(__file__).resolve().parent.parent
 STRUCTS = {"rbrt_material_t": abi.Material, "rbrt_sphere_t": abi.Sphere, "rbrt_mesh_t": abi.Mesh,
-           "rbrt_scene_t": abi.Scene, "rbrt_camera_t": abi.Camera, "rbrt_render_opts_t": abi.RenderOpts,
+           "rbrt_scene_t": abi.Scene, "rbrt_triangle_t": abi.Triangle, "rbrt_camera_t": abi.Camera, "rbrt_render_opts_t": abi.RenderOpts,
            "rbrt_hip_stats_t": abi.Stats, "rbrt_hip_scene_info_t": abi.SceneInfo}
 
 
@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         for name in sorted(declared):
             assert hasattr(lib, name), f"{name} is declared in {header_name} but not exported"
         assert declared == set(table), (header_name, declared ^ set(table))
-    assert lib.rbrt_hip_abi_version() == 1
+    assert lib.rbrt_hip_abi_version() == 2
 
 
 def test_drop_in_header_has_no_test_hooks():
