@@ -338,6 +338,8 @@ def load_host() -> C.CDLL:
     lib.rbrt_host_scene_scene.argtypes = [C.c_void_p]
     lib.rbrt_host_scene_free.restype = None
     lib.rbrt_host_scene_free.argtypes = [C.c_void_p]
+    lib.rbrt_host_save_image.restype = C.c_int
+    lib.rbrt_host_save_image.argtypes = [C.c_char_p, u8p, C.c_uint32, C.c_uint32]
     lib.rbrt_host_write_png.restype = C.c_int
     lib.rbrt_host_write_png.argtypes = [C.c_char_p, u8p, C.c_uint32, C.c_uint32]
     lib.rbrt_host_camera_new.restype = None
@@ -382,6 +384,15 @@ class HostScene:
             self.close()
         except Exception:
             pass
+
+
+def save_image(path, rgb8: np.ndarray) -> None:
+    """rbrt::ImageBuffer::save: encoder by file extension (src/main.rs:86)."""
+    h, w, _ = rgb8.shape
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    lib = load_host()
+    if lib.rbrt_host_save_image(str(path).encode(), rgb8.ctypes.data_as(u8p), w, h) != 0:
+        raise RuntimeError(lib.rbrt_host_last_error().decode(errors="replace"))
 
 
 def write_png(path, rgb8: np.ndarray) -> None:

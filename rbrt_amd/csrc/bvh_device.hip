@@ -516,15 +516,21 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
         uint32_t mcur = n, radius = uint32_t(kPlocRadius);
         if (const char* e = std::getenv("RBRT_PLOC_RADIUS")) radius = uint32_t(std::min(256, std::max(1, std::atoi(e))));
         int cur = 0, rounds = 0;
-        while (mcur > 1u && rounds < 400) {  // (every round merges at least the globally best pair; typically ~45 % of the clusters)
+        bool stalled = false;
+        // (a round typically merges ~45 % of the clusters; with many ties in merged surface -- coincident or duplicate
+        // triangles, non-finite areas -- the lowest-position tie-break leaves one mutual pair per round: a round that
+        // merges under 1 % of the clusters hands the build to the radix tree below instead of running hundreds more)
+        while (mcur > 1u && rounds < 400 && !stalled) {
             hipLaunchKernelGGL(ploc_nearest, dim3(blocks(mcur)), dim3(kTpb), 0, stream, cl[cur], mcur, t.nbox, nn, radius);
             hipLaunchKernelGGL(ploc_merge, dim3(blocks(mcur)), dim3(kTpb), 0, stream, w, cl[cur], mcur, nn, t, n, cl_tmp, valid);
             DEV_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, valid, pos, 0u, mcur, rocprim::plus<uint32_t>(), stream));
             hipLaunchKernelGGL(ploc_compact, dim3(blocks(mcur)), dim3(kTpb), 0, stream, cl_tmp, valid, pos, mcur, cl[cur ^ 1], d_m);
+            const uint32_t before = mcur;
             DEV_TRY(hipMemcpyAsync(&mcur, d_m, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             DEV_TRY(hipStreamSynchronize(stream));
             cur ^= 1;
             ++rounds;
+            stalled = before > 256u && uint64_t(before - mcur) * 100u < before;
         }
         if (mcur == 1u) {
             hipLaunchKernelGGL(ploc_root, dim3(1), dim3(1), 0, stream, w, cl[cur]);

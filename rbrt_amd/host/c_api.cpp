@@ -51,6 +51,20 @@ int rbrt_host_write_png(const char* path, const uint8_t* rgb, uint32_t width, ui
     }
 }
 
+// ImageBuffer::save (src/main.rs:86): the encoder is picked from the extension.
+int rbrt_host_save_image(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height) {
+    try {
+        rbrt::ImageBuffer img;
+        img.width = width, img.height = height;
+        img.rgb.assign(rgb, rgb + size_t(width) * height * 3);
+        img.save(path);
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 // Camera::new alone (cam.rs:22-62), for parity tests against the oracle's restatement.
 void rbrt_host_camera_new(const float position[3], const float look_at[3], const float up[3], uint32_t height,
                           uint32_t width, float focal_len_mm, rbrt_camera_t* out) {

@@ -49,24 +49,127 @@ void write_png(const std::string& path, const uint8_t* rgb, uint32_t width, uint
         throw Error("Unable to save target img to " + path + "! Maybe the directory does not exist?");
 }
 
-void ImageBuffer::save(const std::string& path) const {
-    auto ends_with = [&](const char* ext) {
-        size_t n = std::strlen(ext);
-        if (path.size() < n) return false;
-        for (size_t i = 0; i < n; ++i)
-            if (std::tolower((unsigned char)path[path.size() - n + i]) != ext[i]) return false;
-        return true;
-    };
-    if (ends_with(".ppm")) {
-        FILE* f = std::fopen(path.c_str(), "wb");
-        if (!f) throw Error("Unable to save target img to " + path + "! Maybe the directory does not exist?");
-        std::fprintf(f, "P6\n%u %u\n255\n", width, height);
-        std::fwrite(rgb.data(), 1, rgb.size(), f);
-        std::fclose(f);
-        return;
+namespace {
+
+void write_file(const std::string& path, const std::vector<uint8_t>& bytes) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) throw Error("Unable to save target img to " + path + "! Maybe the directory does not exist?");
+    const size_t w = std::fwrite(bytes.data(), 1, bytes.size(), f);
+    if (std::fclose(f) != 0 || w != bytes.size())
+        throw Error("Unable to save target img to " + path + "! Maybe the directory does not exist?");
+}
+void le16(std::vector<uint8_t>& v, uint32_t x) { v.push_back(uint8_t(x)), v.push_back(uint8_t(x >> 8)); }
+void le32(std::vector<uint8_t>& v, uint32_t x) { le16(v, x & 0xFFFFu), le16(v, x >> 16); }
+
+// 24-bit uncompressed BMP (BITMAPINFOHEADER, bottom-up, BGR, rows padded to 4 bytes)
+std::vector<uint8_t> encode_bmp(const uint8_t* rgb, uint32_t w, uint32_t h) {
+    const uint32_t row = (w * 3u + 3u) & ~3u;
+    std::vector<uint8_t> o = {'B', 'M'};
+    le32(o, 54u + row * h), le32(o, 0), le32(o, 54);
+    le32(o, 40), le32(o, w), le32(o, h), le16(o, 1), le16(o, 24), le32(o, 0), le32(o, row * h), le32(o, 2835), le32(o, 2835), le32(o, 0), le32(o, 0);
+    for (uint32_t y = h; y-- > 0;) {
+        for (uint32_t x = 0; x < w; ++x) {
+            const uint8_t* p = rgb + (size_t(y) * w + x) * 3;
+            o.push_back(p[2]), o.push_back(p[1]), o.push_back(p[0]);
+        }
+        for (uint32_t k = w * 3u; k < row; ++k) o.push_back(0);
     }
-    if (!ends_with(".png")) throw Error("Unable to save target img to " + path + ": only .png and .ppm are supported");
-    write_png(path, rgb.data(), width, height);
+    return o;
+}
+// uncompressed true-colour TGA (type 2), top-left origin, BGR
+std::vector<uint8_t> encode_tga(const uint8_t* rgb, uint32_t w, uint32_t h) {
+    if (w > 65535u || h > 65535u) throw Error("tga: image larger than 65535 pixels on a side");
+    std::vector<uint8_t> o = {0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    le16(o, w), le16(o, h), o.push_back(24), o.push_back(0x20);
+    for (size_t i = 0; i < size_t(w) * h; ++i) o.push_back(rgb[i * 3 + 2]), o.push_back(rgb[i * 3 + 1]), o.push_back(rgb[i * 3]);
+    return o;
+}
+// baseline TIFF: one uncompressed RGB strip, little-endian
+std::vector<uint8_t> encode_tiff(const uint8_t* rgb, uint32_t w, uint32_t h) {
+    const uint32_t n = w * h * 3u;
+    std::vector<uint8_t> o = {'I', 'I', 42, 0};
+    le32(o, 8u + n + (n & 1u));               // IFD after the pixel data
+    o.insert(o.end(), rgb, rgb + n);
+    if (n & 1u) o.push_back(0);
+    const uint32_t bps_off = uint32_t(o.size()) + 2u + 12u * 10u + 4u;
+    const auto entry = [&](uint32_t tag, uint32_t type, uint32_t count, uint32_t value) { le16(o, tag), le16(o, type), le32(o, count), le32(o, value); };
+    le16(o, 10);
+    entry(256, 4, 1, w), entry(257, 4, 1, h), entry(258, 3, 3, bps_off), entry(259, 3, 1, 1), entry(262, 3, 1, 2), entry(273, 4, 1, 8);
+    entry(277, 3, 1, 3), entry(278, 4, 1, h), entry(279, 4, 1, n), entry(284, 3, 1, 1);
+    le32(o, 0);
+    le16(o, 8), le16(o, 8), le16(o, 8);
+    return o;
+}
+// QOI (qoiformat.org), 3 channels, sRGB
+std::vector<uint8_t> encode_qoi(const uint8_t* rgb, uint32_t w, uint32_t h) {
+    std::vector<uint8_t> o = {'q', 'o', 'i', 'f'};
+    put_u32(o, w), put_u32(o, h), o.push_back(3), o.push_back(0);
+    uint8_t index[64][4] = {};
+    uint8_t pr = 0, pg = 0, pb = 0;
+    uint32_t run = 0;
+    const size_t n = size_t(w) * h;
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t r = rgb[i * 3], g = rgb[i * 3 + 1], b = rgb[i * 3 + 2];
+        if (r == pr && g == pg && b == pb) {
+            if (++run == 62 || i + 1 == n) o.push_back(uint8_t(0xC0 | (run - 1))), run = 0;
+            continue;
+        }
+        if (run) o.push_back(uint8_t(0xC0 | (run - 1))), run = 0;
+        const uint32_t hsh = (r * 3u + g * 5u + b * 7u + 255u * 11u) % 64u;
+        if (index[hsh][3] == 255 && index[hsh][0] == r && index[hsh][1] == g && index[hsh][2] == b) {
+            o.push_back(uint8_t(hsh));
+        } else {
+            index[hsh][0] = r, index[hsh][1] = g, index[hsh][2] = b, index[hsh][3] = 255;
+            const int dr = int8_t(r - pr), dg = int8_t(g - pg), db = int8_t(b - pb), dr_dg = dr - dg, db_dg = db - dg;
+            if (dr > -3 && dr < 2 && dg > -3 && dg < 2 && db > -3 && db < 2) {
+                o.push_back(uint8_t(0x40 | ((dr + 2) << 4) | ((dg + 2) << 2) | (db + 2)));
+            } else if (dr_dg > -9 && dr_dg < 8 && dg > -33 && dg < 32 && db_dg > -9 && db_dg < 8) {
+                o.push_back(uint8_t(0x80 | (dg + 32))), o.push_back(uint8_t(((dr_dg + 8) << 4) | (db_dg + 8)));
+            } else {
+                o.push_back(0xFE), o.push_back(r), o.push_back(g), o.push_back(b);
+            }
+        }
+        pr = r, pg = g, pb = b;
+    }
+    for (int k = 0; k < 7; ++k) o.push_back(0);
+    o.push_back(1);
+    return o;
+}
+
+}  // namespace
+
+// src/main.rs:86 `img_buf.save(target_image_path)`: the `image` crate picks the encoder from the file extension. The
+// same here for the formats that hold an 8-bit RGB image LOSSLESSLY (so that the decoded pixels are the reference's):
+// png, ppm / pnm (binary P6), pam (P7), bmp, tga, tif / tiff, qoi. The crate's lossy or palette encoders (jpeg, gif,
+// webp, avif, ico) are not restated: the error names what is available.
+void ImageBuffer::save(const std::string& path) const {
+    std::string ext;
+    const size_t dot = path.find_last_of('.');
+    if (dot != std::string::npos && path.find_first_of("/\\", dot) == std::string::npos)
+        for (size_t i = dot + 1; i < path.size(); ++i) ext += char(std::tolower((unsigned char)path[i]));
+    if (ext == "png") return write_png(path, rgb.data(), width, height);
+    std::vector<uint8_t> bytes;
+    if (ext == "ppm" || ext == "pnm") {
+        const std::string hd = "P6\n" + std::to_string(width) + " " + std::to_string(height) + "\n255\n";
+        bytes.assign(hd.begin(), hd.end());
+        bytes.insert(bytes.end(), rgb.begin(), rgb.end());
+    } else if (ext == "pam") {
+        const std::string hd = "P7\nWIDTH " + std::to_string(width) + "\nHEIGHT " + std::to_string(height) + "\nDEPTH 3\nMAXVAL 255\nTUPLTYPE RGB\nENDHDR\n";
+        bytes.assign(hd.begin(), hd.end());
+        bytes.insert(bytes.end(), rgb.begin(), rgb.end());
+    } else if (ext == "bmp") {
+        bytes = encode_bmp(rgb.data(), width, height);
+    } else if (ext == "tga") {
+        bytes = encode_tga(rgb.data(), width, height);
+    } else if (ext == "tif" || ext == "tiff") {
+        bytes = encode_tiff(rgb.data(), width, height);
+    } else if (ext == "qoi") {
+        bytes = encode_qoi(rgb.data(), width, height);
+    } else {
+        throw Error("Unable to save target img to " + path + ": the extension '" + ext +
+                    "' is not one of png, ppm, pnm, pam, bmp, tga, tif, tiff, qoi (the lossless 8-bit RGB formats of the reference's image crate)");
+    }
+    write_file(path, bytes);
 }
 
 }  // namespace rbrt

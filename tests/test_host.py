@@ -162,6 +162,32 @@ def test_png_roundtrip(tmp_path):
     assert back.shape == img.shape and np.array_equal(back, img)
 
 
+@pytest.mark.parametrize("ext", ["png", "ppm", "pnm", "bmp", "tga", "tif", "tiff", "qoi", "PNG"])
+def test_image_formats_by_extension_decode_to_the_same_pixels(tmp_path, ext):
+    """src/main.rs:86: `img_buf.save(path)` picks the encoder from the extension (image crate). The lossless 8-bit RGB
+    formats are restated; whatever PIL decodes from the file must be the image (flat areas, noise and odd sizes: run
+    lengths, row padding and the QOI index all get used)."""
+    from PIL import Image
+    rng = np.random.default_rng(len(ext))
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    img[5:20, 8:40] = (200, 30, 30)                       # runs
+    img[20:30, :, :] = np.linspace(0, 255, 53, dtype=np.uint8)[None, :, None]  # small deltas (QOI diff / luma ops)
+    abi.save_image(tmp_path / f"x.{ext}", img)
+    back = np.array(Image.open(tmp_path / f"x.{ext}").convert("RGB"))
+    assert back.shape == img.shape and np.array_equal(back, img)
+
+
+def test_pam_and_unknown_extensions(tmp_path):
+    img = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)
+    abi.save_image(tmp_path / "x.pam", img)
+    raw = (tmp_path / "x.pam").read_bytes()
+    assert raw.startswith(b"P7\nWIDTH 3\nHEIGHT 2\nDEPTH 3\nMAXVAL 255\nTUPLTYPE RGB\nENDHDR\n") and raw.endswith(img.tobytes())
+    for bad in ("x.jpg", "x.gif", "noextension", "dir.png/x"):
+        with pytest.raises(RuntimeError) as e:
+            abi.save_image(tmp_path / bad, img)
+        assert "Unable to save target img" in str(e.value)
+
+
 def test_cli_flags_help_and_errors(tmp_path):
     exe = ROOT / "rbrt_amd" / "bin" / "rbrt"
     assert exe.exists(), "build the CLI with `make`"
