@@ -46,8 +46,15 @@ PIXEL_ALG_BYTES = 12   # fp32 radiance store per pixel
 # VALU issue, measured on this chip (profiles/r03_valu_rate.txt): SIMD cycles per wave64 instruction of plain f32 / u32
 # VALU with >= 4 resident waves per SIMD, and what ONE wave alone sustains.
 VALU_CYCLES_PER_INST = 2.0
-VALU_CYCLES_ONE_WAVE = 4.0
+VALU_CYCLES_ONE_WAVE = 4.5
 CLOCK_GHZ = 2.4
+# The same file prices the other instruction classes (SIMD cycles each, four waves resident): VALU that is not
+# fma/add/mul/sub/add_u32/xor (compares, selects, min/max, integer multiplies, conversions, lane ops) ~3.1, transcendental
+# 6.1, a scalar instruction ~2.0 (it takes an issue slot of its own), an LDS instruction ~6, a vector-memory one ~4. The
+# kernel's static VALU mix (tools/static_cost.py: 62 % full-rate, 35 % of the 3.1 kind, 2 % transcendental) applied to the
+# counted instructions gives the AGGREGATE issue bound reported as roofline.issue_mix -- the bound this kernel runs
+# against (calibration: 100 extra v_add_f32 per traversal step cost 0.47 ms = 2.15 cycles each).
+ISSUE_COST = {"valu_mean": 0.62 * 2.0 + 0.355 * 3.1 + 0.025 * 6.1, "salu": 2.0, "lds": 6.0, "vmem": 4.0}
 
 
 def parse_args():
@@ -341,6 +348,16 @@ def main():
                                           "frac": round(bound_ms / kernel_ms, 4),
                                           "one_wave_cycles_per_inst": VALU_CYCLES_ONE_WAVE,
                                           "valu_lane_utilisation": rec.get("valu_lane_utilisation"), "source": src}
+                if rec.get("sq_insts_salu") and rec.get("sq_insts_lds") is not None:
+                    cyc = (rec["sq_insts_valu"] * ISSUE_COST["valu_mean"] + rec["sq_insts_salu"] * ISSUE_COST["salu"] +
+                           rec.get("sq_insts_lds", 0) * ISSUE_COST["lds"] + rec.get("sq_insts_vmem_rd", 0) * ISSUE_COST["vmem"])
+                    mix_ms = cyc / 1024.0 / CLOCK_GHZ / 1e9 * 1e3
+                    roofline["issue_mix"] = {"bound_ms": round(mix_ms, 3), "frac": round(mix_ms / kernel_ms, 4),
+                                             "cycles_per_class": {k: round(v, 3) for k, v in ISSUE_COST.items()},
+                                             "insts": {"valu": rec["sq_insts_valu"], "salu": rec["sq_insts_salu"], "lds": rec.get("sq_insts_lds"),
+                                                       "vmem_rd": rec.get("sq_insts_vmem_rd")},
+                                             "what": "SIMD issue cycles of ALL instruction classes at their measured costs (profiles/r03_valu_rate.txt) "
+                                                     "/ 1024 SIMDs / 2.4 GHz: the bound that binds (the tree is served from L1/L2)"}
 
     out = {
         "metric": "Mray-samples/sec (WxHxspp/s) on bunny scene; achieved HBM GB/s vs peak",

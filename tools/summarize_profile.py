@@ -40,7 +40,13 @@ for leg in ("isolated", "default"):
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = collections.defaultdict(set)
 meta = {}
+# (gpurun merges a run's files into whatever gpurun_out/profile already holds: only the NEWEST file of each pass counts)
+newest = {}
 for f in glob.glob(str(SRC / "*" / "*" / "*counter_collection.csv")):
+    d = Path(f).parent.parent.name
+    if d not in newest or Path(f).stat().st_mtime > Path(newest[d]).stat().st_mtime:
+        newest[d] = f
+for f in newest.values():
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "trace_megakernel" not in k or not re.search(r"<\d+, false", k):  # (the build without counters)

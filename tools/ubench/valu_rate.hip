@@ -10,10 +10,15 @@
 // fuse, reorder or delete them, nor put s_nop between them). Each wave stamps s_memtime (shader cycles) and s_memrealtime (100 MHz)
 // around the loop and records which SIMD it ran on (HW_REG_HW_ID + HW_REG_XCC_ID). Reported per case:
 //   cyc/inst per wave        median over waves of  cycles / instructions of the wave
-//   resident                 waves that really shared a SIMD: per SIMD, sum of wave durations / (last end - first start),
-//                            median over SIMDs (W when the LDS sizing worked; less if workgroups ran in turns)
-//   SIMD cyc per wave-inst   cyc/inst per wave / resident = the reciprocal issue rate of the SIMD
-// A value that stops falling as W grows is the pipe's issue cost.
+//   SIMD cyc per wave-inst   cyc/inst per wave / W = the reciprocal issue rate of the SIMD with W waves competing
+//   overlap                  per SIMD, sum of wave durations / (last end - first start), median over SIMDs: a check that
+//                            the W waves really ran side by side
+// A value that stops falling as W grows is the pipe's issue cost. Read-out on MI355X (profiles/r03_valu_rate.txt):
+//   one wave alone: 4.5 cycles per VALU instruction of any kind (8.5 transcendental) -- a wave cannot issue faster;
+//   W >= 4: v_fma/add/mul/sub_f32, v_add_u32, v_xor_b32 reach 2.0 (64 lanes over two passes of the SIMD-32);
+//   v_max/min(3)_f32, v_cmp, v_cndmask, v_mul_lo/hi_u32, v_and_or, v_lshl_add, v_alignbit, v_cvt, DPP moves, v_readlane,
+//   v_mbcnt and every v_pk_*_f32 stay at ~3.1; v_rcp / v_sqrt 6.1; a scalar instruction in the stream costs ~2.0 (v_fma +
+//   s_add pairs: 4.1 per pair): it takes an issue slot of its own; ds_read_b32 6, ds_write_b32 12, ds_bpermute_b32 18.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -234,8 +239,10 @@ void run(const char* name, kern_t kern, int ilp, int per_op, int waves_per_simd)
     const double med = double(cyc[cyc.size() / 2]), n_inst = double(iters) * 64 * per_op;
     const double per_wave = med / n_inst;
     const double clock_ghz = med / (rt_sum / double(tt.size()) * 10.0);  // s_memrealtime ticks are 10 ns
-    printf("%-26s ILP=%d W=%d : %6.2f cyc/inst per wave, resident %.2f on %zu SIMDs -> %5.2f SIMD cyc per wave-inst   (%.3f ms, %.2f GHz)\n",
-           name, ilp, waves_per_simd, per_wave, resident, simds.size(), per_wave / resident, ms, clock_ghz);
+    // (the W waves of a SIMD belong to one workgroup -- two for W = 8 -- and are resident together by construction; `overlap`
+    // is what their time stamps say, below W when they start a little apart)
+    printf("%-26s ILP=%d W=%d : %6.2f cyc/inst per wave -> %5.2f SIMD cyc per wave-inst   (overlap %.2f on %zu SIMDs, %.3f ms, %.2f GHz)\n",
+           name, ilp, waves_per_simd, per_wave, per_wave / waves_per_simd, resident, simds.size(), ms, clock_ghz);
     fflush(stdout);
     CK(hipFree(out));
     CK(hipFree(st));
