@@ -425,6 +425,27 @@ def test_full_size_cfg2_invariants(hip, oracle, monkeypatch):
     assert_same_image(ref[:, ::stride], exp[:, ::stride], "config 2, every 64th column")
 
 
+@pytest.mark.parametrize("which", ["example_scene.yaml", "header_card.yaml"])
+def test_product_host_scene_path_meets_the_kernel(hip, oracle, tmp_path, which):
+    """Most GPU tests take the camera and the mesh SoA arrays from the ORACLE's preparation. Here the product's own
+    path feeds the kernels: the shipped YAML through the C++ host (yaml_lite, the .obj loader, the transform and the SoA
+    conversion of scene.cpp, Camera::create) -> rbrt_scene_t -> HIP render; the expected image comes from the oracle
+    on the oracle-prepared scene. Both shipped scenes, ragged image size."""
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    n_tris = 2003
+    v, f = standin.make_mesh(n_tris)
+    standin.write_obj(tmp_path / "bunny.obj", v, f)
+    (tmp_path / "scene.yaml").write_text((root / "scenes" / which).read_text().replace("bunny.obj", str(tmp_path / "bunny.obj")))
+    W, H, spp, seed = 150, 92, 5, 12
+    hs = abi.HostScene(tmp_path / "scene.yaml", H, W)
+    got, got8 = hip.render_scene(hs.camera, spp, hs, seed=seed)
+    sc = scenes.example_scene(oracle, n_tris) if which.startswith("example") else scenes.header_scene(oracle, n_tris)
+    exp, exp8, _ = oracle.render(scenes.camera(oracle, W, H), sc, abi.default_opts(spp=spp, seed=seed))
+    assert_same_image(got, exp, which)
+    assert np.array_equal(got8, exp8)
+
+
 def test_cli_end_to_end_png(hip, oracle, tmp_path):
     """The drop-in path a user of the reference runs: `rbrt -c scene.yaml -t out.png` (YAML -> .obj -> SoA ->
     HIP render -> PNG, C++ host + C ABI). The PNG must hold the oracle's 8-bit image of the same scene and seed."""
