@@ -24,9 +24,10 @@
  *       rgb8    : uint8[H][W][3]  — (sqrt(c)*256) saturating cast (lib.rs:116-122)
  *   - there is NO CPU fallback: without a usable HIP device every render entry
  *     point fails with RBRT_ERR_NO_DEVICE.
- *   - environment: the library reads two variables, both optional --
+ *   - environment: the library reads three variables, all optional --
  *       RBRT_HIP_WORKSPACE_MB   cap of one pipeline lane's sample workspace in MiB (default 1024)
  *       RBRT_BVH_BUILDER        host | device: force one BVH builder (default: by mesh size)
+ *       RBRT_BVH_THREADS        threads of the host BVH builder (default: the machine's, at most 16)
  *     Everything else that tunes the kernels' scheduling is a lab knob: ignored unless RBRT_HIP_LAB=1 is set, and
  *     documented with the test / diagnostic entry points in rbrt_hip_debug.h, not here. No knob changes the image.
  */

@@ -15,6 +15,7 @@
  *   RBRT_DRAIN_MODE=<bits 0,1,3>  RBRT_WORK_STRIPES, RBRT_WORK_STRIPES_OVERLAP=<chunks, power of two>
  *   RBRT_SHADE_ROUNDS=1..64, RBRT_SHADE_CONT_MIN=1..64          register-resident shading rounds
  *   RBRT_WAVES_PER_CU=1..32      RBRT_PIPELINE=0..8             RBRT_LANE_PRIORITY=low|default|high
+ *   RBRT_BVH_CT=<SAH traversal cost, 4.0>   RBRT_PLOC_RADIUS=1..256 (device builder's neighbour search)
  *   RBRT_BVH_DEVICE_MIN=<entries>, RBRT_BVH_DEVICE_ALGO=ploc|lbvh   RBRT_POISON_SAMPLES=1 (tests)
  */
 #ifndef RBRT_HIP_DEBUG_H

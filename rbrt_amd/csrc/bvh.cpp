@@ -18,7 +18,8 @@ constexpr int kBins = 16;
 // instructions, so leaves are allowed to fill up (<= kLeafMax) before another level is added.
 float cost_traverse() {
     static const float v = [] {
-        const char* e = std::getenv("RBRT_BVH_CT");
+        const char* lab = std::getenv("RBRT_HIP_LAB");  // (a lab knob: include/rbrt_hip_debug.h)
+        const char* e = (lab && lab[0] == '1') ? std::getenv("RBRT_BVH_CT") : nullptr;
         float x = e ? float(std::atof(e)) : 4.0f;
         return x > 0.0f ? x : 4.0f;
     }();

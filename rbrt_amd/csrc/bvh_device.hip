@@ -514,7 +514,8 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
         DEV_TRY(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 16));
         hipLaunchKernelGGL(iota_kernel, dim3(blocks(n)), dim3(kTpb), 0, stream, cl[0], n);
         uint32_t mcur = n, radius = uint32_t(kPlocRadius);
-        if (const char* e = std::getenv("RBRT_PLOC_RADIUS")) radius = uint32_t(std::min(256, std::max(1, std::atoi(e))));
+        const char* lab = std::getenv("RBRT_HIP_LAB");  // (a lab knob: include/rbrt_hip_debug.h)
+        if (const char* e = (lab && lab[0] == '1') ? std::getenv("RBRT_PLOC_RADIUS") : nullptr) radius = uint32_t(std::min(256, std::max(1, std::atoi(e))));
         int cur = 0, rounds = 0;
         bool stalled = false;
         // (a round typically merges ~45 % of the clusters; with many ties in merged surface -- coincident or duplicate

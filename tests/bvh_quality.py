@@ -7,6 +7,7 @@ with the child boxes as stored in the nodes (C_node = 1 per 4-wide visit, C_tri 
 ratio). A script, not a test (it uses the oracle's mesh preparation, so it lives under tests/). Run on the GPU box:
 python tests/bvh_quality.py [n_triangles ...]"""
 import os
+os.environ.setdefault("RBRT_HIP_LAB", "1")  # the knobs below are lab knobs (include/rbrt_hip_debug.h)
 import sys
 from pathlib import Path
 
