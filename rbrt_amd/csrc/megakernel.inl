@@ -153,9 +153,15 @@ struct WorkSource {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
         shard = xcc % kWorkShards;
     }
+    // (everything below is wave-uniform arithmetic on 32-bit values -- n_items < 2^32, api.cpp -- and is FORCED into
+    // scalar registers with readfirstlane: left to itself the compiler kept this state in VGPRs, because the request in
+    // flight lives in lane 0 only, and turned the chunk bookkeeping of every TERM pass into ~300 exec-masked vector and
+    // scalar instructions with 64-bit compares)
+    static __device__ __forceinline__ uint32_t uni(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
     __device__ __forceinline__ uint32_t shard_lo(const TraceParams& P, uint32_t k) const {
-        if (k >= kWorkShards) return uint32_t(P.n_items);
-        return uint32_t((P.n_items / kWorkChunk) * k / kWorkShards) * kWorkChunk;
+        const uint32_t n_chunks = uint32_t(P.n_items >> 6);
+        if (k >= kWorkShards) return n_chunks * kWorkChunk;
+        return uint32_t((uint64_t(n_chunks) * k) / kWorkShards) * kWorkChunk;
     }
     __device__ __forceinline__ void prefetch(const TraceParams& P, uint32_t lane) {
         if (pending) return;
@@ -165,35 +171,37 @@ struct WorkSource {
     }
     // Blocks until a chunk is in hand: [lo, hi) global items. Returns false when every shard is exhausted.
     __device__ __forceinline__ bool next_chunk(const TraceParams& P, uint32_t lane, uint32_t& lo, uint32_t& hi) {
+        const uint32_t n_chunks = uni(uint32_t(P.n_items >> 6));  // (n_items is a multiple of the chunk size: 64 pixel slots per tile)
         for (;;) {
             prefetch(P, lane);
-            // (lane 0's result, through SGPRs: what follows is scalar arithmetic. next_chunk runs in wave-uniform
-            // control flow, so the first active lane IS lane 0.)
-            const unsigned long long local =
-                (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(pend_base)))) |
-                ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(pend_base >> 32)))) << 32);
+            // (lane 0's result, through SGPRs. next_chunk runs in wave-uniform control flow, so the first active lane IS lane 0.)
+            const uint32_t l_lo = uni(uint32_t(pend_base)), l_hi = uni(uint32_t(pend_base >> 32));
+            const uint32_t ps = uni(pend_shard);
             pending = false;
-            if (P.work_stripes) {  // (a power of two: api.cpp)
-                const uint32_t sh = 31u - uint32_t(__builtin_clz(P.work_stripes));
-                const unsigned long long l = local / kWorkChunk;  // chunk number inside the shard
-                const unsigned long long g = (((l >> sh) * kWorkShards + pend_shard) << sh) + (l & (P.work_stripes - 1u));
-                if (g * kWorkChunk < P.n_items) {  // (n_items is a multiple of the chunk size: 64 pixel slots per tile)
-                    lo = uint32_t(g * kWorkChunk);
-                    hi = lo + kWorkChunk;
-                    n_dry = 0;
-                    return true;
-                }
-            } else {
-                const unsigned long long base = shard_lo(P, pend_shard), end = shard_lo(P, pend_shard + 1u);
-                if (base + local < end) {
-                    lo = uint32_t(base + local);
-                    hi = uint32_t(base + local + kWorkChunk < end ? base + local + kWorkChunk : end);
-                    n_dry = 0;
-                    return true;
+            if (l_hi == 0u) {  // (a counter beyond 2^32 is far beyond every shard's end)
+                if (P.work_stripes) {  // (a power of two: api.cpp)
+                    const uint32_t sh = 31u - uint32_t(__builtin_clz(P.work_stripes));
+                    const uint32_t l = l_lo >> 6;  // chunk number inside the shard (< 2^26)
+                    const uint32_t g = (((l >> sh) * kWorkShards + ps) << sh) + (l & (P.work_stripes - 1u));  // < 8 l + 8 stripes: fits
+                    if (g < n_chunks) {
+                        lo = g * kWorkChunk;
+                        hi = lo + kWorkChunk;
+                        n_dry = 0;
+                        return true;
+                    }
+                } else {
+                    const uint32_t base = shard_lo(P, ps), end = shard_lo(P, ps + 1u);
+                    if (l_lo < end - base) {
+                        lo = base + l_lo;
+                        hi = lo + kWorkChunk < end ? lo + kWorkChunk : end;
+                        n_dry = 0;
+                        return true;
+                    }
                 }
             }
-            shard = (pend_shard + 1u) % kWorkShards;  // this shard is exhausted: move on
-            if (++n_dry >= kWorkShards) {
+            shard = uni((ps + 1u) % kWorkShards);  // this shard is exhausted: move on
+            n_dry = uni(n_dry + 1u);
+            if (n_dry >= kWorkShards) {
                 lo = hi = 0;
                 return false;
             }
@@ -914,10 +922,10 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     }
                 }
                 if (avail < n_want) {
-                    work.res_next = new_lo + (n_want - avail) < new_hi ? new_lo + (n_want - avail) : new_hi;
-                    work.res_end = new_hi;
+                    work.res_next = WorkSource::uni(new_lo + (n_want - avail) < new_hi ? new_lo + (n_want - avail) : new_hi);
+                    work.res_end = WorkSource::uni(new_hi);
                 } else {
-                    work.res_next += n_want;
+                    work.res_next = WorkSource::uni(work.res_next + n_want);
                 }
                 // reserve the next chunk now; its result is not needed before a later TERM pass
                 if (more_work && work.res_end - work.res_next < 64u) work.prefetch(P, lane);

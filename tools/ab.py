@@ -19,6 +19,7 @@ def main():
     ap.add_argument("variants", nargs="+", help='space-separated KEY=VALUE lists, "-" for the default build')
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--isolated-steps", type=int, default=6, help="isolated launches timed per run (more = less noise)")
     ap.add_argument("--extra", default="", help="extra bench.py arguments")
     args = ap.parse_args()
     res = {v: [] for v in args.variants}
@@ -30,7 +31,7 @@ def main():
                     k, val = kv.split("=", 1)
                     env[k] = val
             cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", str(args.steps), "--warmup", "2",
-                   "--cpu-col-stride", "0", "--single-frames", "0", "--isolated-steps", "6"] + args.extra.split()
+                   "--cpu-col-stride", "0", "--single-frames", "0", "--isolated-steps", str(args.isolated_steps)] + args.extra.split()
             p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             if p.returncode != 0:
                 print(f"[{v}] FAILED rc={p.returncode}: {p.stderr[-400:]}", flush=True)

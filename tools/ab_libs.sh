@@ -4,5 +4,5 @@ TAG=$1; shift
 V=()
 for n in "$@"; do V+=("RBRT_HIP_LIB=rbrt_amd/lib/variants/librbrt_hip_$n.so"); done
 mkdir -p gpurun_out/r3
-timeout -k 10 1000 python3 tools/ab.py --rounds 3 --steps 20 "${V[@]}" > gpurun_out/r3/ab_$TAG.log 2>&1
+timeout -k 10 1000 python3 tools/ab.py --rounds ${ROUNDS:-3} --steps ${STEPS:-20} --isolated-steps ${ISO:-6} "${V[@]}" > gpurun_out/r3/ab_$TAG.log 2>&1
 tail -$(( ${#V[@]} + 1 )) gpurun_out/r3/ab_$TAG.log
