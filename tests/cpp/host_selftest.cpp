@@ -151,6 +151,39 @@ int main(int argc, char** argv) {
         CHECK(slurp(tmp + "/selftest.png").size() > 60);
         CHECK(throws([&] { rbrt::write_png("/nonexistent_dir/x.png", rgb.data(), 33, 17); }));
     }
+    // ---- every image writer (src/main.rs:86: encoder by extension), odd sizes: row padding, run lengths ----
+    {
+        rbrt::ImageBuffer img;
+        img.width = 31, img.height = 7;
+        img.rgb.resize(size_t(img.width) * img.height * 3);
+        for (size_t i = 0; i < img.rgb.size(); ++i) img.rgb[i] = uint8_t(i < 200 ? 17 : i * 13);
+        for (const char* ext : {"png", "ppm", "pnm", "pam", "bmp", "tga", "tif", "tiff", "qoi"}) {
+            const std::string p = tmp + "/selftest_img." + ext;
+            img.save(p);
+            CHECK(slurp(p).size() > 40);
+        }
+        CHECK(throws([&] { img.save(tmp + "/selftest_img.jpg"); }));
+        CHECK(throws([&] { img.save(tmp + "/selftest_img"); }));
+        CHECK(throws([&] { img.save("/nonexistent_dir/x.bmp"); }));
+        rbrt::ImageBuffer one;
+        one.width = one.height = 1;
+        one.rgb = {1, 2, 3};
+        one.save(tmp + "/selftest_one.qoi");
+        one.save(tmp + "/selftest_one.bmp");
+    }
+    // ---- BasicTriangle elements and the element order in the ABI view (triangle.rs:9-34, scene.rs:23-31) ----
+    {
+        rbrt::Scene sc;
+        sc.elements.push_back(rbrt::Sphere{rbrt::Vec3(0, 0, -5), 1.0f, rbrt::Material::lambertian(rbrt::Vec3(0.5f, 0.5f, 0.5f))});
+        sc.basic_triangles.push_back(rbrt::BasicTriangle{{rbrt::Vec3(0, 0, -3), rbrt::Vec3(1, 0, -3), rbrt::Vec3(0, 1, -3)},
+                                                         rbrt::Material::metal(rbrt::Vec3(1, 1, 1), 0.1f)});
+        sc.element_order = {0x80000000u, 0u};
+        const rbrt::Scene::AbiView v = sc.to_abi();
+        CHECK(v.scene.n_spheres == 1 && v.scene.n_triangles == 1 && v.scene.element_order && v.scene.element_order[0] == 0x80000000u);
+        CHECK(v.scene.triangles[0].corners[1][0] == 1.0f && v.scene.triangles[0].mat.kind == RBRT_MAT_METAL);
+        sc.element_order = {0u};
+        CHECK(throws([&] { (void)sc.to_abi(); }));
+    }
     // ---- the threaded BVH build (>= 32768 triangles): splice of worker subtrees ----
     {
         write_obj(tmp + "/selftest_big.obj", 70003, 3);
