@@ -383,11 +383,23 @@ def main():
                                "what": "one blocking frame: render + synchronise + copy of the fp32 radiance to pinned host memory"}
 
     # ---- CPU baseline (rank 0, N = 1 only): bounded sample of the same workload ---------------------
-    if args.cpu_col_stride < 0:
-        args.cpu_col_stride = 1 if len(os.sched_getaffinity(0)) >= 64 else 8
-    if world == 1 and args.cpu_col_stride > 0:
+    cpu_note = ""
+    if world == 1 and args.cpu_col_stride != 0:
         from oracle import pyoracle  # the checker, used here only as the timed CPU baseline
         n_threads = args.cpu_threads or len(os.sched_getaffinity(0))  # every core this process may use
+        if args.cpu_col_stride < 0:
+            # Default: the WHOLE frame where the host can do it in a few minutes (SURVEY 8(d) times config 2 in full: >= 64
+            # cores), every 8th column otherwise. A 64th of the frame is timed first; if the whole frame would take more
+            # than 5 minutes on this host (cores shared, a slow box), the largest power-of-two fraction that fits is
+            # timed instead and the line says so.
+            args.cpu_col_stride = 1 if n_threads >= 64 else 8
+            t0 = time.perf_counter()
+            pyoracle.render(cam, host_scene, abi.default_opts(spp=spp, seed=args.seed), n_threads=n_threads, want_rgb8=False, col_stride=64)
+            est_full_s = (time.perf_counter() - t0) * 64.0
+            while est_full_s / args.cpu_col_stride > 300.0 and args.cpu_col_stride < 64:
+                args.cpu_col_stride *= 2
+            if args.cpu_col_stride > 1 and n_threads >= 64:
+                cpu_note = f"; the whole frame was estimated at {est_full_s:.0f} s on this host: a fraction is timed"
         cols = len(range(0, W, args.cpu_col_stride))
         t0 = time.perf_counter()
         rad, _, cpu_rays = pyoracle.render(cam, host_scene, abi.default_opts(spp=spp, seed=args.seed),
@@ -399,7 +411,7 @@ def main():
             "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{'every column' if args.cpu_col_stride == 1 else f'every {args.cpu_col_stride}th column'} ({cols} of {W}) x {H} rows x {spp} spp of the same "
                       f"scene and seed, {cpu_s:.1f} s; C++ restatement of the reference AVX path (brute force over "
-                      f"all triangles), not the Rust binary",
+                      f"all triangles), not the Rust binary{cpu_note}",
         }
         if args.check:
             import numpy as np
