@@ -652,7 +652,8 @@ def test_short_ieee_forms_match_the_compilers(hip):
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RBRT_FUZZ_SCENES", "10"))))
 def test_random_scenes_bit_exact(hip, oracle, seed):
-    """Randomised scenes: 0-9 spheres and 0-3 overlapping triangle soups / stand-in meshes with random materials and
+    """Randomised scenes: 0-9 spheres, on every third seed 1-6 BasicTriangle elements shuffled in between them, and
+    0-3 overlapping triangle soups / stand-in meshes with random materials and
     transforms, ragged image sizes, random depth limits. Exercises mesh order, ties between meshes and spheres, the
     per-scene triangle array with absolute leaf links, and both BVH builders (small meshes forced to the GPU builder
     on odd seeds)."""
@@ -676,7 +677,16 @@ def test_random_scenes_bit_exact(hip, oracle, seed):
         else:
             meshes.append(scenes.standin_mesh(oracle, n + 50, float(rng.uniform(15, 60)), tuple(rng.uniform(-4, 4, 3) + np.array([0, 0, -10])),
                                               tuple(rng.uniform(-1, 1, 3)), rand_mat()))
-    sc = abi.SceneData(spheres=spheres, meshes=meshes)
+    # (drawn from a second generator, so that the scenes of the seeds that have no triangles stay what they were)
+    rng_t = np.random.default_rng(5000 + seed)
+    tris, order = [], None
+    if seed % 3 == 0:  # BasicTriangle elements (triangle.rs:9-34), shuffled in between the spheres
+        for _ in range(int(rng_t.integers(1, 7))):
+            c = rng_t.uniform(-5, 5, 3) + np.array([0, 2, -9])
+            tris.append((tuple(map(tuple, c + rng_t.uniform(-3, 3, (3, 3)))), rand_mat()))
+        order = [i for i in range(len(spheres))] + [scenes.T | i for i in range(len(tris))]
+        rng_t.shuffle(order)
+    sc = abi.SceneData(spheres=spheres, meshes=meshes, triangles=tris, element_order=order)
     w, h = int(rng.integers(20, 90)), int(rng.integers(20, 70))
     cam = scenes.camera(oracle, w, h, position=tuple(rng.uniform(-2, 2, 3) + np.array([0, 4, 4])))
     spp, depth = int(rng.integers(1, 5)), int(rng.choice([1, 3, 50]))
