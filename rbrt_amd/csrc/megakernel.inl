@@ -41,8 +41,7 @@ enum { RBRT_REGIONS(RBRT_REGION_ENUM) kNumRegions };
 #define RBRT_FAST_GATE 1  // mesh bbox gate through bbox_gate_fast (same decisions, no IEEE divisions on the common path)
 #endif
 #ifndef RBRT_PUSH_ORDER
-#define RBRT_PUSH_ORDER 0  // 0: children pushed far-to-near (sorted); 1: nearest next, the rest in slot order;
-                           // 2: like 1 without branches (stores of children that are not pushed go to a sink word in LDS)
+#define RBRT_PUSH_ORDER 0  // 0: children pushed far-to-near (sorted); 1: nearest next, the rest in slot order
 #endif
 #ifndef RBRT_SPHERE_BOUND
 #define RBRT_SPHERE_BOUND 1  // the triangle search of a ray that has hit a sphere starts at that hit's distance
@@ -686,45 +685,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links);
                     if (STATS) ++lc.nodes;
                     if (STATS && t_cur == 0 && k[0] == kMissKey) ++dg_root_only;  // a traversal that ends at the root
-#if RBRT_PUSH_ORDER == 2
-                    // The nearest child next, the other hit children onto the stack in slot order -- without a branch
-                    // per child: every child's link is stored, to the top of the stack if the child is to be pushed
-                    // and to a sink word otherwise (tq[lane]: the leaf rounds' queue, idle during a walk). Keys are
-                    // distinct (the slot is in their low bits), so "hit and not the nearest" is ONE unsigned compare:
-                    // k - kmin - 1 < miss - kmin - 1. A lane whose stack could leave its LDS part in this step takes the
-                    // general code below (the wave, that is: the test is a vote).
-                    const uint32_t kmin = min(min(k[0], k[1]), min(k[2], k[3]));
-                    if (!wany(t_sp + 4u > n_lds_stack)) {
-                        const uint32_t c1 = ~kmin, lim = kMissKey + c1;
-                        const uint32_t stack_off = uint32_t(uintptr_t((lds_u32*)stack)), sink_off = uint32_t(uintptr_t((lds_u32*)(tq + lane)));
-                        const int32_t lk4[4] = {__float_as_int(links.x), __float_as_int(links.y), __float_as_int(links.z), __float_as_int(links.w)};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool v = (k[j] + c1) < lim;
-                            const uint32_t addr = v ? stack_off + t_sp * 256u : sink_off;
-                            asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(lk4[j]) : "memory");
-                            t_sp += v ? 1u : 0u;
-                        }
-                        if (kmin != kMissKey) {
-                            t_cur = link_of(links, kmin);
-                        } else if (t_sp != 0) {
-                            --t_sp;
-                            int32_t popped;
-                            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(popped) : "v"(stack_off + t_sp * 256u) : "memory");
-                            t_cur = popped;
-                        } else {
-                            t_cur = kNoChild;
-                        }
-                    } else if (kmin != kMissKey) {
-                        if (k[0] != kMissKey && k[0] != kmin) push(__float_as_int(links.x));
-                        if (k[1] != kMissKey && k[1] != kmin) push(__float_as_int(links.y));
-                        if (k[2] != kMissKey && k[2] != kmin) push(__float_as_int(links.z));
-                        if (k[3] != kMissKey && k[3] != kmin) push(__float_as_int(links.w));
-                        t_cur = link_of(links, kmin);
-                    } else {
-                        t_cur = t_sp != 0 ? pop() : kNoChild;
-                    }
-#elif RBRT_PUSH_ORDER == 0
+#if RBRT_PUSH_ORDER == 0
                     if (k[0] != kMissKey) {  // farthest first, so that the nearest is popped first
                         if (k[3] != kMissKey) push(link_of(links, k[3]));
                         if (k[2] != kMissKey) push(link_of(links, k[2]));
