@@ -152,6 +152,13 @@ class HipScene:
                  sphere_tail_runs=int(buf[62]), sphere_tail_lanes=int(buf[63]))
         return d
 
+    def primary_cull(self, cam):
+        """The primary-ray culling table for `cam` (rbrt_hip_debug_primary_cull; test hook): uint32 (tiles_y, tiles_x)."""
+        tx, ty = (cam.img_width_pix + 7) // 8, (cam.img_height_pix + 7) // 8
+        out = np.zeros(tx * ty, np.uint32)
+        abi.check(self._lib.rbrt_hip_debug_primary_cull(self._h, C.byref(cam), out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
+        return out.reshape(ty, tx)
+
     def trace_rays(self, rays, min_dist=0.001, max_dist=2000.0):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         n = rays.shape[0]

@@ -171,6 +171,7 @@ DEBUG_SYMBOLS = {
     "rbrt_hip_scene_launch_mix": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rbrt_hip_debug_scatter": (C.c_int, [C.POINTER(Material), f32p, f32p, f32p, C.POINTER(C.c_uint32), C.c_size_t, f32p, u8p,
                                         C.POINTER(C.c_uint32)]),
+    "rbrt_hip_debug_primary_cull": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(C.c_uint32), C.c_size_t]),
 }
 
 

@@ -23,7 +23,8 @@ size_t megakernel_gseq_bytes(uint32_t n_waves);
 size_t megakernel_gstack_bytes(uint32_t n_waves);
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes, uint32_t n_elem_tris);
 int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes);
-int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes);
+hipError_t launch_primary_cull(const TraceParams& P, hipStream_t stream);
+hipError_t launch_sky_resolve(const TraceParams& P, const ResolveParams& R, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
                          size_t rank_stride_pixels, float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
@@ -120,6 +121,17 @@ struct rbrt_hip_scene {
         unsigned long long* d_work_counter = nullptr;
         uint32_t* d_gseq = nullptr;
         uint32_t* d_gstack = nullptr;
+        // the tile pass (kernels.hip primary_cull_kernel + tile_lists_kernel): which of the rank's tiles see only the
+        // background. Recomputed on the lane's trace stream when the camera or the tile partition differs from `tile_key`.
+        uint32_t* d_tile_cull = nullptr;   // [n_tiles]
+        uint32_t* d_tile_lists = nullptr;  // [kTileListHeader + 2 * n_local]
+        size_t tile_cull_words = 0, tile_lists_words = 0;
+        hipEvent_t ev_lists = nullptr;     // recorded behind the tile pass
+        struct TileKey {
+            rbrt_camera_t cam;
+            uint32_t rank, world;
+        } tile_key;
+        bool tile_key_valid = false;
         hipEvent_t ev_traced = nullptr, ev_resolved = nullptr;
         bool in_use = false;  // ev_resolved has been recorded at least once
     };
@@ -151,6 +163,7 @@ struct rbrt_hip_scene {
     uint32_t drain_mode = 1;      // RBRT_DRAIN_MODE
     uint32_t work_stripes = 16;   // RBRT_WORK_STRIPES: chunks (of 64 work items) per stripe for a launch that has the GPU to itself; 0 = contiguous shards
     uint32_t work_stripes_overlap = 0;  // RBRT_WORK_STRIPES_OVERLAP: the same for a launch issued while another is running
+    uint32_t primary_cull = 1;    // RBRT_PRIMARY_CULL (0: no tile pass, the trace kernel renders every tile)
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
     // stats / timing
@@ -624,7 +637,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             lab_u32("RBRT_WORK_STRIPES_OVERLAP", 0, 65536, stripes_overlap, err) && lab_u32("RBRT_DRAIN_MODE", 0, 11, s->drain_mode, err) &&
             lab_u32("RBRT_SHADE_ROUNDS", 1, kMaxShadeRounds, s->shade_rounds, err) &&
             lab_u32("RBRT_SHADE_CONT_MIN", 1, 64, s->shade_cont_min, err) && lab_u32("RBRT_PIPELINE", 0, kMaxPipeline, s->pipeline, err) &&
-            lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err);
+            lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err) && lab_u32("RBRT_PRIMARY_CULL", 0, 1, s->primary_cull, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
         if ((stripes & (stripes - 1u)) != 0u || (stripes_overlap & (stripes_overlap - 1u)) != 0u)  // the kernel shifts
             return bail(fail(RBRT_ERR_INVALID_ARG, "lab knob RBRT_WORK_STRIPES / RBRT_WORK_STRIPES_OVERLAP must be 0 or a power of two"));
@@ -657,6 +670,9 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
         if (L.ev_traced) (void)hipEventDestroy(L.ev_traced);
         if (L.ev_resolved) (void)hipEventDestroy(L.ev_resolved);
         if (L.d_sample_buf) (void)hipFree(L.d_sample_buf);
+        if (L.d_tile_cull) (void)hipFree(L.d_tile_cull);
+        if (L.d_tile_lists) (void)hipFree(L.d_tile_lists);
+        if (L.ev_lists) (void)hipEventDestroy(L.ev_lists);
     }
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->d_acc) (void)hipFree(s->d_acc);
@@ -822,6 +838,24 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             HIP_TRY(hipMalloc(&p, need));
             L.d_sample_buf = static_cast<float*>(p), L.sample_buf_bytes = need;
         }
+        const bool tile_pass = s->primary_cull != 0;
+        const size_t lists_need = size_t(kTileListHeader) + 2u * size_t(n_local);
+        if (tile_pass && (n_tiles > L.tile_cull_words || lists_need > L.tile_lists_words)) {
+            if (L.d_tile_cull || L.d_tile_lists) {
+                if (int rc = sync_lanes()) return rc;
+                if (L.d_tile_cull) HIP_TRY(hipFree(L.d_tile_cull));
+                L.d_tile_cull = nullptr, L.tile_cull_words = 0;
+                if (L.d_tile_lists) HIP_TRY(hipFree(L.d_tile_lists));
+                L.d_tile_lists = nullptr, L.tile_lists_words = 0;
+            }
+            L.tile_key_valid = false;
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, size_t(n_tiles) * sizeof(uint32_t)));
+            L.d_tile_cull = static_cast<uint32_t*>(p), L.tile_cull_words = n_tiles;
+            HIP_TRY(hipMalloc(&p, lists_need * sizeof(uint32_t)));
+            L.d_tile_lists = static_cast<uint32_t*>(p), L.tile_lists_words = lists_need;
+            if (!L.ev_lists) HIP_TRY(hipEventCreateWithFlags(&L.ev_lists, hipEventDisableTiming));
+        }
         if (piped) {
             // this lane's sample buffer is free once the resolve of its previous launch has run
             if (L.in_use) HIP_TRY(hipStreamWaitEvent(L.stream, L.ev_resolved, 0));
@@ -842,24 +876,47 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.work_counter = L.d_work_counter;
         P.gseq = L.d_gseq;
         P.gstack = L.d_gstack;
+        P.tile_cull = tile_pass ? L.d_tile_cull : nullptr;
+        P.tile_lists = tile_pass ? L.d_tile_lists : nullptr;
         // (L.d_work_counter is zero: from its allocation, afterwards from the resolve kernel of the lane's last launch)
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
+        if (tile_pass) {
+            // The tile pass, on the trace launch's stream (inside its timed span): the lists are the lane's own -- another
+            // lane may be rendering another camera -- and are kept for as long as camera and partition stay what they were.
+            rbrt_hip_scene::Lane::TileKey key;
+            std::memset(&key, 0, sizeof(key));
+            key.cam = *cam, key.rank = o->tile_rank, key.world = world;
+            if (!L.tile_key_valid || std::memcmp(&key, &L.tile_key, sizeof(key)) != 0) {
+                HIP_TRY(launch_primary_cull(P, ts));
+                HIP_TRY(hipEventRecord(L.ev_lists, ts));
+                L.tile_key = key, L.tile_key_valid = true;
+            } else {
+                HIP_TRY(hipStreamWaitEvent(ts, L.ev_lists, 0));  // (kept lists: made on whatever stream the lane's launch had then)
+            }
+        }
         const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped);
         (grid < s->n_waves ? s->n_half_grid : s->n_full_grid) += 1;
         HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, s->share_idle != 0u && P.n_items < s->share_below, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
-        if (piped) {
-            HIP_TRY(hipEventRecord(L.ev_traced, ts));
-            HIP_TRY(hipStreamWaitEvent(stream, L.ev_traced, 0));
-        }
         R.sample_buf = L.d_sample_buf;
         R.work_counter = L.d_work_counter;
         R.batch = nb;
         R.first_batch = base == 0;
         R.last_batch = base + nb == o->spp;
+        R.tile_lists = P.tile_lists;
+        R.counters = stats ? s->d_counters : nullptr;
+        if (piped) {
+            HIP_TRY(hipEventRecord(L.ev_traced, ts));
+            HIP_TRY(hipStreamWaitEvent(stream, L.ev_traced, 0));
+        }
         HIP_TRY(launch_resolve(R, stream));
+        // The background-only tiles never reach the trace kernel: their pixels are finished here, on the caller's stream
+        // like every write to its buffers. BEHIND the resolve although it needs only the lists: issued beside its own
+        // trace launch it waited for wave slots that persistent trace waves hold until their launch ends (1.2 ms on
+        // average for 0.05 ms of work, with the resolve queued behind it); now it runs in the slots that launch just freed.
+        if (tile_pass) HIP_TRY(launch_sky_resolve(P, R, stream));
         if (depth > 1) {  // (also after a counting launch: it used lane 0's buffers on the caller's stream)
             HIP_TRY(hipEventRecord(L.ev_resolved, stream));
             L.in_use = true;
@@ -942,9 +999,6 @@ int rbrt_hip_scene_info(rbrt_hip_scene_t* s, rbrt_hip_scene_info_t* out) {
     out->n_nodes = s->total_nodes, out->n_triangles = s->total_tris;
     out->trace_waves = s->n_waves;
     out->lds_bytes_per_wave = uint32_t(megakernel_lds_bytes(s->pool, s->stack_entries, s->n_spheres, s->n_meshes, s->n_elem_tris));
-    (void)hipSetDevice(s->device);
-    out->occupancy_api_waves_per_cu = uint32_t(megakernel_occupancy_per_cu(s->pool, out->lds_bytes_per_wave));
-    out->n_cus = s->n_cus;
     (void)hipSetDevice(s->device);
     out->occupancy_api_waves_per_cu = uint32_t(megakernel_occupancy_per_cu(s->pool, out->lds_bytes_per_wave));
     out->n_cus = s->n_cus;
@@ -1208,6 +1262,28 @@ int rbrt_hip_debug_scatter(const rbrt_material_t* mats, const float* in_dir, con
     if (e == hipSuccess && out_rng_state) e = hipMemcpy(out_rng_state, d_rng_out, st, hipMemcpyDeviceToHost);
     cleanup();
     if (e != hipSuccess) return fail(RBRT_ERR_HIP, std::string("debug_scatter: ") + hipGetErrorString(e));
+    return RBRT_OK;
+}
+
+int rbrt_hip_debug_primary_cull(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, uint32_t* out_words, size_t n_words) {
+    if (!s || !cam || !out_words) return fail(RBRT_ERR_INVALID_ARG, "debug_primary_cull: null argument");
+    const uint32_t tiles_x = (cam->img_width_pix + RBRT_TILE - 1) / RBRT_TILE, tiles_y = (cam->img_height_pix + RBRT_TILE - 1) / RBRT_TILE;
+    if (uint64_t(tiles_x) * tiles_y != n_words || n_words == 0 || n_words > 0xFFFFFFFFull)
+        return fail(RBRT_ERR_INVALID_ARG, "debug_primary_cull: n_words must be the number of 8x8 tiles of the camera's image");
+    HIP_TRY(hipSetDevice(s->device));
+    rbrt_render_opts_t o;
+    rbrt_render_opts_default(&o);
+    TraceParams P;
+    fill_trace_params(s, cam, &o, P);
+    P.tiles_x = tiles_x, P.tiles_y = tiles_y, P.n_tiles = uint32_t(n_words);
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, n_words * sizeof(uint32_t)));
+    P.tile_cull = static_cast<uint32_t*>(d);
+    hipError_t e = launch_primary_cull(P, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out_words, d, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RBRT_ERR_HIP, std::string("debug_primary_cull: ") + hipGetErrorString(e));
     return RBRT_OK;
 }
 

@@ -7,6 +7,7 @@
 namespace rbrt {
 
 // Compile-time limits.
+constexpr uint32_t kTileListHeader = 4;  // words ahead of the lists in TraceParams::tile_lists
 constexpr int kBlock = 256;          // threads per workgroup of the simple kernels (resolve, unpack, trace_rays)
 constexpr int kMaxBvhDepth = 20;     // deepest 4-wide node (root = 0) the builder may create
 constexpr int kStackMax = 3 * (kMaxBvhDepth + 1) + 1;  // a visit defers at most 3 children per level
@@ -139,6 +140,14 @@ struct TraceParams {
     uint32_t drain_mode;               // scheduling once the work items have run out (bits: megakernel.inl "drain")
     uint32_t shade_rounds;             // shading pass: rounds a sphere-only bounce chain may stay in registers
     uint32_t shade_cont_min;           // ... as long as at least this many lanes continue (ignored once the work has run out)
+    // The tile pass (kernels.hip primary_cull_kernel + tile_lists_kernel, run before the trace launch; both null: off).
+    // tile_cull: one word per tile of the image: bit e < 24 = no camera ray of the tile can reach element e (a sphere),
+    // bit 24 + m (m < 7) = none passes mesh m's box, bit 31 = all of them and the scene has nothing else: the tile sees
+    // the background only. tile_lists: [0] = n_work, [1] = n_sky, then from [kTileListHeader] the rank's n_work local
+    // tile numbers the trace kernel renders, ascending, and from [kTileListHeader + n_local_tiles] the n_sky
+    // background-only ones, which sky_resolve_kernel finishes without the trace kernel ever seeing them.
+    uint32_t* tile_cull;
+    uint32_t* tile_lists;
 };
 
 struct ResolveParams {
@@ -152,6 +161,8 @@ struct ResolveParams {
     float* out_radiance;  // row-major image if tile_world <= 1, else packed tiles; may be null
     uint8_t* out_rgb8;    // same indexing; may be null
     unsigned long long* work_counter;  // the finished launch's work counters, zeroed here for the lane's next launch
+    const uint32_t* tile_lists;        // TraceParams::tile_lists (null: every local tile has samples in sample_buf)
+    DevCounters* counters;             // sky_resolve_kernel in a counting launch: its samples and rays; else null
 };
 
 }  // namespace rbrt

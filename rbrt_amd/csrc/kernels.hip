@@ -601,6 +601,25 @@ __device__ __forceinline__ bool scatter(const DevMaterial& m, V3 in_d, V3 p, V3 
     }
 }
 
+// cam.rs:64-82: direction of the camera ray of sample (pixel, stream state); the column jitter is drawn first.
+__device__ __forceinline__ V3 camera_ray_direction(V3 pos, V3 center, V3 right, V3 up, float mm_hor, float mm_vert, uint32_t img_w,
+                                                   uint32_t img_h, uint32_t row, uint32_t col, Rng& rng) {
+    const float col_off = float(col) - float(img_w / 2);
+    const float row_off = float(row) - float(img_h / 2);
+    const float u0 = rng.next_f32();
+    const float col_mm = ((col_off + u0) - 0.5f) * mm_hor;
+    const float u1 = rng.next_f32();
+    const float row_mm = ((row_off + u1) - 0.5f) * mm_vert;
+    const V3 target = (center + (0.001f * col_mm) * right) - (0.001f * row_mm) * up;
+    return normalize(target - pos);
+}
+
+// lib.rs:68-71: what a ray that hits nothing sees; the direction as it is (not re-normalised).
+__device__ __forceinline__ V3 background(float dy, const float* bg) {
+    const float t = 0.5f * (dy + 1.0f);
+    return t * mk(1.0f, 1.0f, 1.0f) + (1.0f - t) * mk(bg);
+}
+
 __host__ __device__ inline uint32_t megakernel_lds_dwords(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes,
                                                           uint32_t n_elem_tris);
 #include "megakernel.inl"
@@ -614,49 +633,25 @@ __device__ __forceinline__ uint8_t quantise(float c) {
     return uint8_t(v);
 }
 
-// Sequential per-pixel sum over the samples of this batch (lib.rs:95-100 adds them in sample
-// order; keeping that order keeps the mean bit-identical), then on the last batch the multiply by
-// 1/spp (lib.rs:101) and the optional quantisation.
-__global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) {
-    const size_t npix = size_t(R.n_local_tiles) * 64u;
-    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
-    // the trace launch this resolves has ended: its work counters are reset for the lane's next launch (which
-    // waits for this kernel), saving a memset launch that would have to queue behind the resident megakernels
-    static_assert(kWorkShards * kWorkCounterStride <= kBlock, "one thread per counter word");
-    if (blockIdx.x == 0 && threadIdx.x < kWorkShards * kWorkCounterStride) R.work_counter[threadIdx.x] = 0ull;
-    if (i >= npix) return;
-    const uint32_t tile_local = uint32_t(i >> 6), p = uint32_t(i & 63u);
-    const uint32_t tile = tile_local * R.tile_world + R.tile_rank;
-    const uint32_t ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
-    const uint32_t row = ty * RBRT_TILE + (p >> 3), col = tx * RBRT_TILE + (p & 7u);
-    const bool valid = row < R.height && col < R.width;
+// The end of a pixel's batch: the running sum goes back to `acc`, or -- on the last batch -- the mean (lib.rs:101) and
+// the optional quantisation go out. `j`: the pixel's place in the rank's packed tiles.
+__device__ __forceinline__ void resolve_store(const ResolveParams& R, size_t j, uint32_t row, uint32_t col, bool valid, float ax, float ay,
+                                              float az) {
     const bool packed = R.tile_world > 1;
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;
     if (valid) {
-        if (!R.first_batch) {
-            ax = R.acc[i * 3 + 0];
-            ay = R.acc[i * 3 + 1];
-            az = R.acc[i * 3 + 2];
-        }
-        for (uint32_t s = 0; s < R.batch; ++s) {
-            const float* sp = R.sample_buf + (size_t(s) * npix + i) * 3u;
-            ax = ax + sp[0];
-            ay = ay + sp[1];
-            az = az + sp[2];
-        }
         if (!R.last_batch) {
-            R.acc[i * 3 + 0] = ax;
-            R.acc[i * 3 + 1] = ay;
-            R.acc[i * 3 + 2] = az;
+            R.acc[j * 3 + 0] = ax;
+            R.acc[j * 3 + 1] = ay;
+            R.acc[j * 3 + 2] = az;
             return;
         }
         ax = ax * R.inv_spp;
         ay = ay * R.inv_spp;
         az = az * R.inv_spp;
     } else if (!R.last_batch || !packed) {
-        return;
+        return;  // (a pixel slot beyond a ragged image edge: packed outputs carry it as zeros)
     }
-    const size_t o = packed ? i * 3u : (size_t(row) * R.width + col) * 3u;
+    const size_t o = packed ? j * 3u : (size_t(row) * R.width + col) * 3u;
     if (R.out_radiance) {
         R.out_radiance[o + 0] = ax;
         R.out_radiance[o + 1] = ay;
@@ -666,6 +661,287 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) 
         R.out_rgb8[o + 0] = quantise(ax);
         R.out_rgb8[o + 1] = quantise(ay);
         R.out_rgb8[o + 2] = quantise(az);
+    }
+}
+
+// Sequential per-pixel sum over the samples of this batch (lib.rs:95-100 adds them in sample
+// order; keeping that order keeps the mean bit-identical), then on the last batch the multiply by
+// 1/spp (lib.rs:101) and the optional quantisation.
+__global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) {
+    // (with a tile pass the launch rendered the tiles of the work list only; the grid covers all of the rank's)
+    const size_t npix = size_t(R.tile_lists ? R.tile_lists[0] : R.n_local_tiles) * 64u;
+    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    // the trace launch this resolves has ended: its work counters are reset for the lane's next launch (which
+    // waits for this kernel), saving a memset launch that would have to queue behind the resident megakernels
+    static_assert(kWorkShards * kWorkCounterStride <= kBlock, "one thread per counter word");
+    if (blockIdx.x == 0 && threadIdx.x < kWorkShards * kWorkCounterStride) R.work_counter[threadIdx.x] = 0ull;
+    if (i >= npix) return;
+    const uint32_t p = uint32_t(i & 63u);
+    const uint32_t tile_local = R.tile_lists ? R.tile_lists[kTileListHeader + (i >> 6)] : uint32_t(i >> 6);
+    const size_t j = size_t(tile_local) * 64u + p;  // the pixel's place in the rank's packed tiles (acc, packed outputs)
+    const uint32_t tile = tile_local * R.tile_world + R.tile_rank;
+    const uint32_t ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
+    const uint32_t row = ty * RBRT_TILE + (p >> 3), col = tx * RBRT_TILE + (p & 7u);
+    const bool valid = row < R.height && col < R.width;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    if (valid) {
+        if (!R.first_batch) {
+            ax = R.acc[j * 3 + 0];
+            ay = R.acc[j * 3 + 1];
+            az = R.acc[j * 3 + 2];
+        }
+        for (uint32_t s = 0; s < R.batch; ++s) {
+            const float* sp = R.sample_buf + (size_t(s) * npix + i) * 3u;
+            ax = ax + sp[0];
+            ay = ay + sp[1];
+            az = az + sp[2];
+        }
+    }
+    resolve_store(R, j, row, col, valid, ax, ay, az);
+}
+
+// The pixels of the tiles that see only the background (TraceParams::tile_lists, second list): every sample of such a
+// pixel is one camera ray that hits nothing (cam.rs:64-82, lib.rs:68-71), so its batch is generated, summed in sample
+// order and stored right here -- the same streams, the same arithmetic, the same order as the trace kernel followed by
+// resolve_kernel would produce -- and the trace kernel never sees these tiles. One thread per pixel.
+__global__ __launch_bounds__(kBlock) void sky_resolve_kernel(const TraceParams P, const ResolveParams R) {
+    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= size_t(R.tile_lists[1]) * 64u) return;
+    const uint32_t p = uint32_t(i & 63u);
+    const uint32_t tile_local = R.tile_lists[kTileListHeader + R.n_local_tiles + (i >> 6)];
+    const size_t j = size_t(tile_local) * 64u + p;
+    const uint32_t tile = tile_local * R.tile_world + R.tile_rank;
+    const uint32_t ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
+    const uint32_t row = ty * RBRT_TILE + (p >> 3), col = tx * RBRT_TILE + (p & 7u);
+    const bool valid = row < R.height && col < R.width;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    if (valid) {
+        if (!R.first_batch) {
+            ax = R.acc[j * 3 + 0];
+            ay = R.acc[j * 3 + 1];
+            az = R.acc[j * 3 + 2];
+        }
+        const V3 pos = mk(P.cam.position), center = mk(P.cam.img_center_point), right = mk(P.cam.right), up = mk(P.cam.up);
+        for (uint32_t s = 0; s < R.batch; ++s) {
+            Rng rng;
+            rng.init(P.seed_key, row * R.width + col, P.sample_base + s);
+            const V3 d = camera_ray_direction(pos, center, right, up, P.cam.mm_per_pix_hor, P.cam.mm_per_pix_vert, R.width, R.height, row, col, rng);
+            const V3 c = background(d.y, P.bg);
+            ax = ax + c.x;
+            ay = ay + c.y;
+            az = az + c.z;
+        }
+        if (R.counters) {  // a counting launch: one ray, one sample, zero bounces each
+            atomicAdd(&R.counters->rays, (unsigned long long)R.batch);
+            atomicAdd(&R.counters->samples, (unsigned long long)R.batch);
+            atomicAdd(&R.counters->diag[32], (unsigned long long)R.batch);
+        }
+    }
+    resolve_store(R, j, row, col, valid, ax, ay, az);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Primary-ray culling. Every camera ray of an 8x8 tile starts at cam.position and passes through a small rectangle
+// of the image plane (cam.rs:64-82), so which spheres and mesh boxes the tile's rays can reach at all is known before
+// a single ray is made: half of all rays are camera rays, and most of them face four sphere tests and a box test
+// whose outcome the tile already decides. This kernel writes one word per tile (TraceParams::tile_cull); the trace
+// kernel skips the tests it rules out. A skipped test is one the reference would have run and FAILED, so the image
+// does not change; the proof obligation is that the rule never skips a test that could succeed.
+//
+// Directions. The tile's exact ray directions are the unit vectors from the position to a (widened) rectangle of the
+// image plane: a convex spherical quadrilateral, inside the cone of half-angle rho (largest angle to a corner) around
+// the direction c of its middle. A sphere of radius R at distance l > R fills the cone of half-angle asin(R / l) around
+// q = (centre - position) / l. So with the OUTER radius R_out (inflated, below):
+//   forward rays miss it     when angle(c, q)  > asin(R_out / l) + rho,
+//   backward lines miss it   when angle(-c, q) > asin(R_out / l) + rho,
+//   backward lines cut DEEP  when angle(-c, q) + rho < asin(R_in / l)   (R_in: deflated; the position clearly outside).
+// sphere.rs:20-66 needs the forward condition and one of the backward ones: it looks at the LINE first (discriminant),
+// and with a discriminant of exactly zero it accepts a negative parameter (sphere.rs:41-49: the `sol > 0.0 &&` guard),
+// so a line that grazes the sphere BEHIND the camera could be a hit; one that misses it there cannot, and one that cuts
+// deep has a discriminant well above zero, takes the guarded branch and is rejected with both roots negative (b > 0 and
+// 4 a c >= 8e-3 r^2 keep the larger root negative in float as well). This is what lets the sky tiles drop the ground
+// sphere, which every line through the camera cuts somewhere. The box test (aabbox.rs:28-58) rejects `t_max < 0`
+// first, so for a mesh the forward condition on the box's bounding sphere is enough.
+//
+// A second, independent rule catches long thin cases the cones cannot: with a = img_center - position, f_x(p) =
+// [a + 0.001 x right, up, p - position] (triple product) vanishes on the plane of the camera lines of column
+// coordinate x, and a point of the line of coordinate cm at parameter s has f_x = s 0.001 (cm - x) [a, up, right]:
+// over the tile's interval [lo, hi] every point of every one of its lines has f_lo f_hi <= 0, whatever the signs. An
+// object entirely inside {f_lo > 0, f_hi > 0} or {f_lo < 0, f_hi < 0} meets none of the lines at all. Same with rows.
+//
+// Margins. The kernel's rays are float: the target point carries an absolute error of a few ulp of |img_center| and
+// |position| (target - position cancels), an angle of err / |target - position| against the exact line; the
+// discriminant b^2 - 4ac carries ~10 ulp of 4 (|l|^2 + r^2), which admits lines up to 3e-7 (|l|^2 + r^2) / r outside
+// the sphere. Radii are inflated (deflated) by 30x that plus 0.1 %, angles widened by the direction error, the pixel
+// interval by 1e-3 pixel plus the rounding of (col_off + u) - 0.5. A degenerate camera makes the quantities NaN and
+// every comparison false: nothing is culled. Non-finite or non-positive radii and non-finite boxes (a mesh without
+// triangles has lo = +inf) are never culled: the reference's NaN panic (sphere.rs:33), reported through
+// nan_discriminants, must still be reached. BasicTriangle elements are never culled (the YAML cannot describe them).
+// ---------------------------------------------------------------------------------------------
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ D3 d3(const float* p) { return D3{double(p[0]), double(p[1]), double(p[2])}; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D3 operator*(double s, D3 a) { return D3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 dcross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ double dlen(D3 a) { return sqrt(ddot(a, a)); }
+__device__ __forceinline__ D3 unit_or_nan(D3 v) { return (1.0 / dlen(v)) * v; }  // (a zero vector gives NaN: nothing is culled with it)
+__device__ __forceinline__ double angle_between(D3 u, D3 v) {  // unit vectors; NaN stays NaN
+    const double c = ddot(u, v);
+    return acos(c > 1.0 ? 1.0 : c < -1.0 ? -1.0 : c);
+}
+
+// Two planes through the camera position (unit normals) bounding the camera lines of a pixel interval.
+struct CullSlab {
+    D3 n_lo, n_hi;
+    // every point within `reach` of q (relative to the position) strictly on one and the same side of both planes?
+    __device__ __forceinline__ bool outside(D3 q, double reach) const {
+        const double g0 = ddot(n_lo, q), g1 = ddot(n_hi, q);
+        return (g0 > reach && g1 > reach) || (g0 < -reach && g1 < -reach);  // (false for NaN)
+    }
+};
+// The tile's ray directions: inside the cone of half-angle rho around mid (unit).
+struct CullCone {
+    D3 mid;
+    double rho;
+    // forward rays (sign +1) or backward extensions (sign -1) all miss the ball of radius R at q = l * qhat?
+    __device__ __forceinline__ bool misses(D3 qhat, double l, double R, double sign) const {
+        return R < l && angle_between(sign * mid, qhat) > asin(R / l) + rho;
+    }
+    __device__ __forceinline__ bool backward_deep(D3 qhat, double l, double r_in) const {
+        return r_in > 0.0 && r_in < l && angle_between(-1.0 * mid, qhat) + rho < asin(r_in / l);
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void primary_cull_kernel(const TraceParams P) {
+    const uint32_t tile = blockIdx.x * kBlock + threadIdx.x;
+    if (tile >= P.n_tiles) return;
+    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const rbrt_camera_t& c = P.cam;
+    const uint32_t W = c.img_width_pix, H = c.img_height_pix;
+    const D3 pos = d3(c.position), right = d3(c.right), up = d3(c.up), ctr = d3(c.img_center_point);
+    const D3 a = ctr - pos;
+    // the tile's pixel interval in the units of cam.rs:70-75, widened
+    const double pad = 1e-3 + double(W > H ? W : H) * (1.0 / 4194304.0);
+    const uint32_t c0 = tx * RBRT_TILE, r0 = ty * RBRT_TILE;
+    const uint32_t c1 = (c0 + RBRT_TILE < W ? c0 + RBRT_TILE : W) - 1u, r1 = (r0 + RBRT_TILE < H ? r0 + RBRT_TILE : H) - 1u;
+    const double mmh = double(c.mm_per_pix_hor), mmv = double(c.mm_per_pix_vert);
+    const double cm0 = (double(c0) - double(W / 2u) - 0.5 - pad) * mmh, cm1 = (double(c1) - double(W / 2u) + 0.5 + pad) * mmh;
+    const double rm0 = (double(r0) - double(H / 2u) - 0.5 - pad) * mmv, rm1 = (double(r1) - double(H / 2u) + 0.5 + pad) * mmv;
+    CullSlab cols, rows;
+    cols.n_lo = unit_or_nan(dcross(a + (0.001 * cm0) * right, up));
+    cols.n_hi = unit_or_nan(dcross(a + (0.001 * cm1) * right, up));
+    rows.n_lo = unit_or_nan(dcross(a - (0.001 * rm0) * up, right));
+    rows.n_hi = unit_or_nan(dcross(a - (0.001 * rm1) * up, right));
+    // the float ray against the exact line: absolute error of (target - position), as an angle
+    const double cm_abs = fabs(cm0) > fabs(cm1) ? fabs(cm0) : fabs(cm1), rm_abs = fabs(rm0) > fabs(rm1) ? fabs(rm0) : fabs(rm1);
+    const double err = 8.0 * (1.0 / 8388608.0) * (dlen(ctr) + dlen(pos) + 0.001 * cm_abs * dlen(right) + 0.001 * rm_abs * dlen(up));
+    const double plane_dist = fabs(ddot(a, unit_or_nan(dcross(right, up))));  // no target is closer to the position
+    const double angle = 2.0 * err / plane_dist + 1e-6;                          // (NaN or inf for a degenerate camera)
+    CullCone cone;
+    cone.mid = unit_or_nan(a + (0.0005 * (cm0 + cm1)) * right - (0.0005 * (rm0 + rm1)) * up);
+    cone.rho = 0.0;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const D3 u = unit_or_nan(a + (0.001 * (k & 1u ? cm1 : cm0)) * right - (0.001 * (k & 2u ? rm1 : rm0)) * up);
+        const double t = angle_between(cone.mid, u);
+        cone.rho = t > cone.rho || !(t == t) ? t : cone.rho;  // (a NaN sticks)
+    }
+    cone.rho += angle;
+
+    const uint32_t n_elem = P.n_spheres + P.n_elem_tris;
+    uint32_t word = 0;
+    bool all = n_elem <= 24u && P.n_meshes <= 7u && P.n_elem_tris == 0u;
+    for (uint32_t e = 0; e < n_elem && e < 24u; ++e) {
+        const uint32_t desc = P.elems ? P.elems[e] : e;
+        bool out = false;
+        if (!(desc >> 31)) {
+            const DevSphere sp = P.spheres[desc];
+            const D3 q = d3(sp.center) - pos;
+            const double r = double(sp.radius), l = dlen(q);
+            if (r > 0.0 && r < 1e30 && l < 1e30) {  // (false for NaN)
+                const double slack = r * 1e-3 + 1e-5 * (l * l + r * r) / r + 1e-4 * l;
+                const double reach = r + slack + angle * (l + r);
+                const D3 qhat = (1.0 / l) * q;
+                out = cols.outside(q, reach) || rows.outside(q, reach) ||
+                      (cone.misses(qhat, l, r + slack, 1.0) && (cone.misses(qhat, l, r + slack, -1.0) || cone.backward_deep(qhat, l, r - slack)));
+            }
+        }
+        if (out) word |= 1u << e;
+        else all = false;
+    }
+    for (uint32_t m = 0; m < P.n_meshes && m < 7u; ++m) {
+        const DevMesh& md = P.meshes[m];
+        double far = 0.0;
+        bool finite = true;
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const D3 q = D3{double(k & 1u ? md.bbox_hi[0] : md.bbox_lo[0]), double(k & 2u ? md.bbox_hi[1] : md.bbox_lo[1]),
+                            double(k & 4u ? md.bbox_hi[2] : md.bbox_lo[2])} - pos;
+            const double l = dlen(q);
+            finite = finite && l < 1e30;
+            far = l > far ? l : far;
+        }
+        bool out = false;
+        if (finite) {
+            // aabbox.rs:28-58 in float: six quotients and their min / max, a few ulp of the largest magnitude
+            const double slack = 1e-4 * far;
+            const D3 lo = d3(md.bbox_lo), hi = d3(md.bbox_hi);
+            const D3 q = 0.5 * (lo + hi) - pos;
+            const double l = dlen(q);
+            out = cone.misses((1.0 / l) * q, l, 0.5 * dlen(hi - lo) * 1.001 + slack, 1.0);
+            for (uint32_t slab = 0; slab < 2u && !out; ++slab) {
+                const CullSlab& sl = slab ? rows : cols;
+                const double reach = slack + angle * far;
+                bool pos_side = true, neg_side = true;
+                for (uint32_t k = 0; k < 8u; ++k) {
+                    const D3 v = D3{double(k & 1u ? md.bbox_hi[0] : md.bbox_lo[0]), double(k & 2u ? md.bbox_hi[1] : md.bbox_lo[1]),
+                                    double(k & 4u ? md.bbox_hi[2] : md.bbox_lo[2])} - pos;
+                    const double g0 = ddot(sl.n_lo, v), g1 = ddot(sl.n_hi, v);
+                    pos_side = pos_side && g0 > reach && g1 > reach;
+                    neg_side = neg_side && g0 < -reach && g1 < -reach;
+                }
+                out = pos_side || neg_side;
+            }
+        }
+        if (out) word |= 1u << (24u + m);
+        else all = false;
+    }
+    if (all) word |= 1u << 31;
+    P.tile_cull[tile] = word;
+}
+
+// The rank's tiles split by what primary_cull_kernel found, each list in ascending order (TraceParams::tile_lists): one
+// workgroup, every thread a contiguous run of local tiles, an exclusive scan of the runs' counts in between.
+constexpr int kListBlock = 1024;
+__global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParams P) {
+    __shared__ uint32_t sums[kListBlock];
+    const uint32_t n = P.n_local_tiles, t = threadIdx.x;
+    const uint32_t per = (n + kListBlock - 1) / kListBlock;
+    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    uint32_t mine = 0;  // tiles of this run that go to the trace kernel
+    for (uint32_t tl = lo; tl < hi; ++tl) mine += (P.tile_cull[tl * P.tile_world + P.tile_rank] >> 31) ? 0u : 1u;
+    sums[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < kListBlock; d <<= 1) {  // inclusive scan
+        const uint32_t v = t >= d ? sums[t - d] : 0u;
+        __syncthreads();
+        sums[t] += v;
+        __syncthreads();
+    }
+    uint32_t w = sums[t] - mine;       // work tiles before this run
+    uint32_t k = lo - w;               // background-only tiles before it
+    uint32_t* const work = P.tile_lists + kTileListHeader;
+    uint32_t* const sky = work + n;
+    for (uint32_t tl = lo; tl < hi; ++tl) {
+        if (P.tile_cull[tl * P.tile_world + P.tile_rank] >> 31) sky[k++] = tl;
+        else work[w++] = tl;
+    }
+    if (t == kListBlock - 1) {
+        P.tile_lists[0] = sums[t];
+        P.tile_lists[1] = n - sums[t];
+        P.tile_lists[2] = 0u, P.tile_lists[3] = 0u;
     }
 }
 
@@ -843,6 +1119,21 @@ hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint3
         return hipErrorInvalidValue;
 #undef RBRT_LAUNCH_POOL
 #undef RBRT_LAUNCH_MK
+    return hipGetLastError();
+}
+
+// The tile pass: the culling table of P.cam, then (tile_lists given) the rank's two tile lists from it.
+hipError_t launch_primary_cull(const TraceParams& P, hipStream_t stream) {
+    if (P.n_tiles == 0 || !P.tile_cull) return hipSuccess;
+    hipLaunchKernelGGL(primary_cull_kernel, dim3((P.n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, P);
+    if (P.tile_lists) hipLaunchKernelGGL(tile_lists_kernel, dim3(1), dim3(kListBlock), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_sky_resolve(const TraceParams& P, const ResolveParams& R, hipStream_t stream) {
+    const size_t npix = size_t(R.n_local_tiles) * 64u;  // (an upper bound: the list's length is known on the device)
+    if (npix == 0 || !R.tile_lists) return hipSuccess;
+    hipLaunchKernelGGL(sky_resolve_kernel, dim3(uint32_t((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, P, R);
     return hipGetLastError();
 }
 

@@ -147,7 +147,10 @@ struct WorkSource {
     unsigned long long pend_base = 0;    // lane 0: result of the request in flight
     bool pending = false;                // wave-uniform
 
-    __device__ __forceinline__ void init(const TraceParams& P) {
+    uint32_t n_chunks = 0;               // wave-uniform: chunks of the launch (its work items / 64)
+
+    __device__ __forceinline__ void init(uint32_t n_items) {
+        n_chunks = n_items >> 6;  // (a multiple of the chunk size: 64 pixel slots per tile)
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
         shard = xcc % kWorkShards;
@@ -157,8 +160,7 @@ struct WorkSource {
     // flight lives in lane 0 only, and turned the chunk bookkeeping of every TERM pass into ~300 exec-masked vector and
     // scalar instructions with 64-bit compares)
     static __device__ __forceinline__ uint32_t uni(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
-    __device__ __forceinline__ uint32_t shard_lo(const TraceParams& P, uint32_t k) const {
-        const uint32_t n_chunks = uint32_t(P.n_items >> 6);
+    __device__ __forceinline__ uint32_t shard_lo(uint32_t k) const {
         if (k >= kWorkShards) return n_chunks * kWorkChunk;
         return uint32_t((uint64_t(n_chunks) * k) / kWorkShards) * kWorkChunk;
     }
@@ -170,7 +172,6 @@ struct WorkSource {
     }
     // Blocks until a chunk is in hand: [lo, hi) global items. Returns false when every shard is exhausted.
     __device__ __forceinline__ bool next_chunk(const TraceParams& P, uint32_t lane, uint32_t& lo, uint32_t& hi) {
-        const uint32_t n_chunks = uni(uint32_t(P.n_items >> 6));  // (n_items is a multiple of the chunk size: 64 pixel slots per tile)
         for (;;) {
             prefetch(P, lane);
             // (lane 0's result, through SGPRs. next_chunk runs in wave-uniform control flow, so the first active lane IS lane 0.)
@@ -189,7 +190,7 @@ struct WorkSource {
                         return true;
                     }
                 } else {
-                    const uint32_t base = shard_lo(P, ps), end = shard_lo(P, ps + 1u);
+                    const uint32_t base = shard_lo(ps), end = shard_lo(ps + 1u);
                     if (l_lo < end - base) {
                         lo = base + l_lo;
                         hi = lo + kWorkChunk < end ? lo + kWorkChunk : end;
@@ -226,6 +227,11 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     uint8_t* const status = reinterpret_cast<uint8_t*>(helpers + kHelpDw);       // [kPoolPad] one byte per slot
     uint8_t* const list = status + kPoolPad;                                     // [kPoolPad] slot ids (< 256)
     const uint32_t lane = threadIdx.x;
+    // The launch's tiles: all of the rank's, or what the tile pass (kernels.hip tile_lists_kernel) left of them; the
+    // count of the latter is known on the device only. Work items and the sample buffer are laid out over THESE tiles.
+    const uint32_t n_work = P.tile_lists ? uint32_t(__builtin_amdgcn_readfirstlane(int(P.tile_lists[0]))) : P.n_local_tiles;
+    const uint32_t npix = n_work * 64u;
+    const uint32_t n_items = npix * P.batch;  // (< 2^32: api.cpp sizes the batches for all of the rank's tiles)
     uint32_t* const stack_base = helpers + kHelpDw + kPoolPad / 2u;                     // 2 * kPoolPad bytes of byte arrays
     uint32_t* const stack = stack_base + lane;
 #if RBRT_REGION_TIMERS
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             dst[G_BATCH] = P.batch, dst[G_BATCH_MAGIC] = P.batch_magic;
             dst[G_TILES_X] = P.tiles_x, dst[G_TILES_X_MAGIC] = P.tiles_x_magic;
             dst[G_TILE_WORLD] = P.tile_world, dst[G_TILE_RANK] = P.tile_rank;
-            dst[G_N_LOCAL] = P.n_local_tiles, dst[G_REVERSED] = P.tiles_reversed;
+            dst[G_N_LOCAL] = n_work, dst[G_REVERSED] = P.tiles_reversed;
             dst[G_SAMPLE_BASE] = P.sample_base, dst[G_MAX_DEPTH] = P.max_depth;
             dst[G_SEED_LO] = uint32_t(P.seed_key), dst[G_SEED_HI] = uint32_t(P.seed_key >> 32);
         }
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                          gp + kGenDw + P.n_elem_tris * kTriDw};
     // work items are reserved from the global counter in chunks, the next chunk asynchronously
     WorkSource work;
-    work.init(P);
+    work.init(n_items);
     LocalCounters lc = {0, 0, 0, 0, 0};
     uint32_t n_samples_done = 0;
     uint32_t dg_pass[kNumStatus] = {0, 0, 0, 0, 0, 0}, dg_lanes[kNumStatus] = {0, 0, 0, 0, 0, 0};
@@ -315,7 +321,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         dg_rt0 = __builtin_amdgcn_s_memrealtime();
     }
     bool more_work = true;  // wave-uniform: the global work counter has not run out yet
-    const size_t npix = size_t(P.n_local_tiles) * 64u;
     const float eps = P.min_dist;
 
     // ---- per-lane traversal state; lives in registers across shading passes ----
@@ -784,11 +789,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 nrec = (meta >> 7) & 127u;
                 const int32_t obj = int32_t((meta >> 14) & 255u) - 1;
                 V3 color = mk(0.0f, 0.0f, 0.0f);  // hit with depth 0 or a failed scatter: lib.rs:63-66
-                if (obj < 0) {                    // lib.rs:68-71, direction as is (not re-normalised)
-                    const float dy = __uint_as_float(POOL(F_DY, slot));
-                    const float t = 0.5f * (dy + 1.0f);
-                    color = t * mk(1.0f, 1.0f, 1.0f) + (1.0f - t) * mk(P.bg);
-                }
+                if (obj < 0) color = background(__uint_as_float(POOL(F_DY, slot)), P.bg);  // lib.rs:68-71
                 if (nrec != 0) {  // lib.rs:62: attenuation * colorize(...), innermost bounce first
                     word = POOL(F_WORD, slot);
                     for (uint32_t k = nrec; k-- > 0;) {
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         }
                     }
                 }
-                if (item < P.n_items) {
+                if (item < n_items) {
                     float* out = P.sample_buf + size_t(item) * 3u;
                     out[0] = color.x;
                     out[1] = color.y;
@@ -855,8 +856,10 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         const uint32_t batch = gp[G_BATCH];
                         const uint32_t tpos = div_magic(ts, batch, gp[G_BATCH_MAGIC]);
                         const uint32_t s = ts - tpos * batch;
-                        const uint32_t tile_local = gp[G_REVERSED] ? gp[G_N_LOCAL] - 1u - tpos : tpos;  // row-major, either way
-                        item = s * uint32_t(npix) + tile_local * 64u + pp;       // < 2^32: the host sizes batches so
+                        const uint32_t widx = gp[G_REVERSED] ? gp[G_N_LOCAL] - 1u - tpos : tpos;  // row-major, either way
+                        item = s * npix + widx * 64u + pp;                       // < 2^32: the host sizes batches so
+                        // the launch's tiles: all of the rank's, or those the tile pass left (TraceParams::tile_lists)
+                        const uint32_t tile_local = P.tile_lists ? P.tile_lists[kTileListHeader + widx] : widx;
                         const uint32_t tile = tile_local * gp[G_TILE_WORLD] + gp[G_TILE_RANK];
                         const uint32_t tiles_x = gp[G_TILES_X];
                         const uint32_t ty = div_magic(tile, tiles_x, gp[G_TILES_X_MAGIC]), tx = tile - ty * tiles_x;
@@ -864,17 +867,9 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         const uint32_t img_w = gp[G_W], img_h = gp[G_H];
                         if (row < img_h && col < img_w) {
                             rng.init((uint64_t(gp[G_SEED_HI]) << 32) | gp[G_SEED_LO], row * img_w + col, gp[G_SAMPLE_BASE] + s);
-                            const float col_off = float(col) - float(img_w / 2);
-                            const float row_off = float(row) - float(img_h / 2);
-                            const float u0 = rng.next_f32();
-                            const float col_mm = ((col_off + u0) - 0.5f) * gpf[G_MMH];
-                            const float u1 = rng.next_f32();
-                            const float row_mm = ((row_off + u1) - 0.5f) * gpf[G_MMV];
-                            const V3 pos = mk(gpf + G_POS);
-                            const V3 target = (mk(gpf + G_CENTER) + (0.001f * col_mm) * mk(gpf + G_RIGHT)) -
-                                              (0.001f * row_mm) * mk(gpf + G_UP);
-                            o = pos;
-                            d = normalize(target - pos);
+                            o = mk(gpf + G_POS);
+                            d = camera_ray_direction(o, mk(gpf + G_CENTER), mk(gpf + G_RIGHT), mk(gpf + G_UP), gpf[G_MMH], gpf[G_MMV], img_w,
+                                                     img_h, row, col, rng);
                             depth = gp[G_MAX_DEPTH];
                             nrec = 0;
                             word = 0;

@@ -1,0 +1,251 @@
+"""The tile pass (kernels.hip primary_cull_kernel, tile_lists_kernel, sky_resolve_kernel; DESIGN.md "The tile pass").
+
+The library decides per 8x8 tile which sphere tests (sphere.rs:20-66) and mesh box tests (aabbox.rs:28-58) the tile's
+camera rays (cam.rs:64-82) would fail; a tile whose rays fail all of them sees the background only, and its pixels
+are finished by a streaming kernel instead of the trace kernel. A wrong bit changes the image, so the table is checked
+on its own, ahead of the image tests: every set bit is a promise "no camera ray of this tile passes this test", and the
+oracle's routines are run over the tile's rays -- all four corners of the jitter square, its middle, random jitter -- to
+look for a counter-example. Cameras: the example scene's, one looking up (sky tiles: the ground sphere is BEHIND their
+rays, where sphere.rs accepts a grazing line), straight down, from inside the ground sphere, from its surface, from far
+away with a long lens, with mirrored pixel pitch, and a degenerate one (nothing may be culled with it).
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import scenes
+from rbrt_amd import abi
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+U_MAX = f32(1.0) - f32(2.0 ** -24)  # the largest value of rand's Standard f32 (np_reference.Rng.next_f32)
+
+
+def _v(a):
+    return np.array(list(a), f32)
+
+
+def camera_rays(cam, u0, u1):
+    """cam.rs:64-82 for every pixel at once, float32 operation for operation (np_reference.camera_ray): (H*W, 6)."""
+    W, H = cam.img_width_pix, cam.img_height_pix
+    col = np.broadcast_to(np.arange(W, dtype=f32)[None, :], (H, W))
+    row = np.broadcast_to(np.arange(H, dtype=f32)[:, None], (H, W))
+    col_off = col - f32(W // 2)
+    row_off = row - f32(H // 2)
+    col_mm = ((col_off + u0).astype(f32) - f32(0.5)) * f32(cam.mm_per_pix_hor)
+    row_mm = ((row_off + u1).astype(f32) - f32(0.5)) * f32(cam.mm_per_pix_vert)
+    right, up, ctr, pos = _v(cam.right), _v(cam.up), _v(cam.img_center_point), _v(cam.position)
+    target = (ctr + (f32(0.001) * col_mm)[..., None] * right) - (f32(0.001) * row_mm)[..., None] * up
+    d = (target - pos).astype(f32)
+    with np.errstate(all="ignore"):
+        ln = np.sqrt(((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]).astype(f32) + d[..., 2] * d[..., 2]).astype(f32))
+        d = (d / ln[..., None]).astype(f32)
+    o = np.broadcast_to(pos, d.shape)
+    return np.concatenate([o, d], -1).reshape(-1, 6).astype(f32)
+
+
+def bbox_gate(lo, hi, rays):
+    """aabbox.rs:28-58 over an array of rays (np_reference.bbox_hit, vectorised)."""
+    o, d = rays[:, :3], rays[:, 3:]
+    with np.errstate(all="ignore"):
+        tl = ((lo - o) / d).astype(f32)
+        tu = ((hi - o) / d).astype(f32)
+    t_min = np.fmax(np.fmax(np.fmin(tl, tu)[:, 0], np.fmin(tl, tu)[:, 1]), np.fmin(tl, tu)[:, 2])
+    t_max = np.fmin(np.fmin(np.fmax(tl, tu)[:, 0], np.fmax(tl, tu)[:, 1]), np.fmax(tl, tu)[:, 2])
+    return ~(t_max < 0) & ~(t_min > t_max)
+
+
+def tiles_of(mask, W, H):
+    """(H*W,) bool per pixel -> (tiles_y, tiles_x) bool: any pixel of the tile."""
+    ty, tx = (H + 7) // 8, (W + 7) // 8
+    m = np.zeros((ty * 8, tx * 8), bool)
+    m[:H, :W] = mask.reshape(H, W)
+    return m.reshape(ty, 8, tx, 8).any(axis=(1, 3))
+
+
+def jitters(rng, W, H):
+    z, m = np.zeros((H, W), f32), np.full((H, W), U_MAX, f32)
+    yield z, z
+    yield m, m
+    yield z, m
+    yield m, z
+    yield np.full((H, W), f32(0.5)), np.full((H, W), f32(0.5))
+    for _ in range(3):
+        yield ((rng.integers(0, 1 << 24, (H, W)).astype(f32) * f32(2.0 ** -24)),
+               (rng.integers(0, 1 << 24, (H, W)).astype(f32) * f32(2.0 ** -24)))
+
+
+def check_table(hip, oracle, cam, sc, rng, max_dist=2000.0):
+    """Looks for a ray that passes a test its tile's word rules out. Returns the table."""
+    W, H = cam.img_width_pix, cam.img_height_pix
+    with hip.HipScene(sc) as hs:
+        table = hs.primary_cull(cam)
+    n_el = len(sc.spheres)
+    reach = [np.zeros(table.shape, bool) for _ in range(n_el + len(sc.meshes))]
+    for u0, u1 in jitters(rng, W, H):
+        rays = camera_rays(cam, u0, u1)
+        for e, sp in enumerate(sc.spheres):
+            _, obj, _, _ = oracle.trace_rays(abi.SceneData(spheres=[sp]), rays, 0.001, max_dist)
+            reach[e] |= tiles_of(obj >= 0, W, H)
+        for m, md in enumerate(sc.meshes):
+            reach[n_el + m] |= tiles_of(bbox_gate(md.bbox_lo.astype(f32), md.bbox_hi.astype(f32), rays), W, H)
+    for e in range(min(n_el, 24)):
+        bad = reach[e] & (((table >> e) & 1) != 0)
+        assert not bad.any(), f"sphere {e}: culled in tiles {np.argwhere(bad)[:5].tolist()} that a camera ray hits it from"
+    for m in range(min(len(sc.meshes), 7)):
+        bad = reach[n_el + m] & (((table >> (24 + m)) & 1) != 0)
+        assert not bad.any(), f"mesh {m}: box culled in tiles {np.argwhere(bad)[:5].tolist()} that a camera ray enters it from"
+    every = np.uint32(((1 << n_el) - 1) | (((1 << len(sc.meshes)) - 1) << 24))
+    sky = (table >> 31) != 0
+    assert np.array_equal(sky, (table & every) == every) or n_el > 24 or len(sc.meshes) > 7
+    return table, reach
+
+
+CAMERAS = {
+    "example": {},
+    "looking_up": dict(look_at=(0.0, 0.6, -1.0), up=(0.0, 1.0, 0.0)),
+    "straight_down": dict(look_at=(0.0, -1.0, -0.001), up=(0.0, 0.0, -1.0)),
+    "inside_the_ground": dict(position=(0.0, -5.0, 4.0)),
+    "on_the_ground": dict(position=(0.0, 0.0, -5.0), look_at=(0.3, 0.2, -1.0), up=(0.0, 1.0, 0.0)),
+    "far_long_lens": dict(position=(300.0, 900.0, 2500.0), look_at=(-0.115, -0.34, -0.93), up=(0.0, 1.0, 0.0), focal_mm=900.0),
+    "wide": dict(focal_mm=6.0),
+    "sideways": dict(position=(-30.0, 2.0, -12.0), look_at=(1.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), focal_mm=50.0),
+}
+
+
+@pytest.mark.parametrize("name", list(CAMERAS))
+def test_no_camera_ray_passes_a_culled_test(hip, oracle, name):
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    cam = scenes.camera(oracle, 200, 136, **CAMERAS[name])
+    sc = scenes.example_scene(oracle, 1203)
+    table, reach = check_table(hip, oracle, cam, sc, rng)
+    if name in ("example", "looking_up", "sideways"):
+        assert (table >> 31).any()            # there is sky, and it is found
+    if name == "inside_the_ground":
+        assert not ((table >> 0) & 1).any()   # every ray hits the sphere the camera is in
+
+
+def test_the_rule_is_worth_having_on_the_bench_frame(hip, oracle):
+    """Config 2's camera at full size: how much the table removes (a regression here is a performance bug, not a wrong
+    image): more than a quarter of the tiles see sky only, and the camera rays keep less than one sphere test of four."""
+    rng = np.random.default_rng(5)
+    cam = scenes.camera(oracle, 1024, 768)
+    sc = scenes.example_scene(oracle, 3000)
+    table, reach = check_table(hip, oracle, cam, sc, rng)
+    sky = np.count_nonzero(table >> 31) / table.size
+    left = sum(np.count_nonzero(((table >> e) & 1) == 0) for e in range(4)) / table.size
+    exact = sum(np.count_nonzero(r) for r in reach[:4]) / table.size
+    assert sky > 0.25 and left < 1.0, (sky, left)
+    assert left < exact + 0.25, (left, exact)  # within a quarter of a test per tile of what the sampled rays reach
+
+
+def test_mirrored_pitch_two_meshes_many_spheres_and_degenerate_cameras(hip, oracle):
+    rng = np.random.default_rng(11)
+    sc = scenes.example_scene(oracle, 1203)
+    second = scenes.standin_mesh(oracle, 603, 30.0, (-9.0, 0.5, -14.0), (0.0, 0.4, 0.0), abi.material(abi.MAT_METAL, (0.7, 0.7, 0.7), 0.1))
+    extra = [((float(x), 0.4, float(z)), 0.4, abi.material(abi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))) for x in range(-12, 13, 4) for z in (-6, -11, -17, -25)]
+    sc2 = abi.SceneData(spheres=list(scenes.EXAMPLE_SPHERES) + extra, meshes=[sc.meshes[0], second])  # 32 spheres: 8 beyond the mask
+    cam = scenes.camera(oracle, 136, 100)
+    check_table(hip, oracle, cam, sc2, rng)
+    cam.mm_per_pix_hor = -cam.mm_per_pix_hor  # mirrored image: the intervals' ends swap
+    check_table(hip, oracle, cam, sc2, rng)
+    cam.mm_per_pix_vert = -cam.mm_per_pix_vert
+    check_table(hip, oracle, cam, sc, rng)
+    # degenerate: right parallel to up (no image plane), a zero pitch, a NaN position -> nothing may be culled
+    for breaker in ("parallel", "zero_pitch", "nan"):
+        cam = scenes.camera(oracle, 64, 48)
+        if breaker == "parallel":
+            cam.right[0], cam.right[1], cam.right[2] = cam.up[0], cam.up[1], cam.up[2]
+        elif breaker == "zero_pitch":
+            cam.mm_per_pix_hor = 0.0
+            cam.mm_per_pix_vert = 0.0
+        else:
+            cam.position[1] = float("nan")
+        with hip.HipScene(sc) as hs:
+            table = hs.primary_cull(cam)
+        if breaker == "zero_pitch":   # every ray is the central one: culling is legitimate, and must still be right
+            check_table(hip, oracle, cam, sc, rng)
+        else:
+            assert not table.any(), breaker
+
+
+def test_images_with_and_without_sky_tiles_equal_the_oracle(hip, oracle):
+    """Whole images through the culled path against the oracle, bit for bit, for the cameras above that differ most from
+    the example's (the parity suite renders the example camera everywhere), with the sample and ray counts."""
+    import torch
+    sc = scenes.example_scene(oracle, 1203)
+    for name in ("looking_up", "straight_down", "inside_the_ground", "on_the_ground", "sideways"):
+        cam = scenes.camera(oracle, 136, 100, **CAMERAS[name])
+        exp, _, rays = oracle.render(cam, sc, abi.default_opts(spp=5, seed=9))
+        out = torch.empty((100, 136, 3), dtype=torch.float32, device="cuda")
+        with hip.HipScene(sc) as hs:
+            hs.render_device(cam, abi.default_opts(spp=5, seed=9, flags=abi.FLAG_COLLECT_STATS), out.data_ptr())
+            st = hs.stats()
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), exp.view(np.uint32)), name
+            assert st["samples"] == 136 * 100 * 5 and st["rays"] == rays, name
+            hs.render_device(cam, abi.default_opts(spp=5, seed=9), out.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), exp.view(np.uint32)), name
+
+
+def test_cameras_change_inside_a_stream_of_frames_into_one_buffer(hip, oracle):
+    """The tile lists belong to a pipeline lane and are kept while its camera stays the same. Frames with two cameras
+    whose background-only tiles differ, issued back to back without synchronisation (three lanes in flight), each
+    written into ONE output buffer and copied out on the same stream: every frame is its camera's image. A list made
+    for the other camera, or a write that overtakes the previous frame's, would show."""
+    import torch
+    sc = scenes.example_scene(oracle, 1203)
+    cams = [scenes.camera(oracle, 136, 100), scenes.camera(oracle, 136, 100, **CAMERAS["looking_up"]),
+            scenes.camera(oracle, 136, 100, **CAMERAS["sideways"])]
+    order = [0, 1, 1, 0, 2, 0, 0, 1, 2, 2, 0, 1]
+    exp = [oracle.render(c, sc, abi.default_opts(spp=3, seed=4))[0] for c in cams]
+    out = torch.empty((100, 136, 3), dtype=torch.float32, device="cuda")
+    copies = []
+    with hip.HipScene(sc) as hs:
+        for k in order:
+            hs.render_device(cams[k], abi.default_opts(spp=3, seed=4), out.data_ptr(), None, None)
+            copies.append(out.clone())  # (same stream: ordered behind the frame, ahead of the next one)
+        torch.cuda.synchronize()
+        hs.check()
+    for n, (k, img) in enumerate(zip(order, copies)):
+        assert np.array_equal(img.cpu().numpy().view(np.uint32), exp[k].view(np.uint32)), (n, k)
+
+
+def test_ranks_and_passes_with_background_tiles(hip, oracle):
+    """Three ranks' packed tiles, rendered in two passes each (running sums through rbrt_hip_render_pass), on a ragged
+    image whose upper half is sky: the background-only tiles take the streaming kernel in both passes, the others the
+    trace kernel; merged, the image is the oracle's."""
+    import torch
+    from rbrt_amd import tiles
+    W, H, spp = 100, 76, 5
+    cam = scenes.camera(oracle, W, H, **CAMERAS["looking_up"])
+    sc = scenes.example_scene(oracle, 1203)
+    exp, _, _ = oracle.render(cam, sc, abi.default_opts(spp=spp, seed=2))
+    parts = []
+    with hip.HipScene(sc) as hs:
+        for rank in range(3):
+            n = hip.packed_pixels(W, H, rank, 3)
+            acc = torch.zeros(n * 3, dtype=torch.float32, device="cuda")
+            out = torch.full((n * 3,), float("nan"), dtype=torch.float32, device="cuda")
+            o = abi.default_opts(spp=spp, seed=2, tile_rank=rank, tile_world=3)
+            hs.render_pass(cam, o, 0, 2, acc.data_ptr(), out.data_ptr())
+            hs.render_pass(cam, o, 2, spp, acc.data_ptr(), out.data_ptr())
+            torch.cuda.synchronize()
+            parts.append(out.cpu().numpy().reshape(-1, 3))
+        hs.check()
+    got = tiles.unpack(parts, W, H)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_tile_pass_switched_off_gives_the_same_image(hip, oracle, monkeypatch):
+    import torch
+    cam = scenes.camera(oracle, 136, 100)
+    sc = scenes.example_scene(oracle, 1203)
+    exp, _, rays = oracle.render(cam, sc, abi.default_opts(spp=4, seed=3))
+    out = torch.empty((100, 136, 3), dtype=torch.float32, device="cuda")
+    monkeypatch.setenv("RBRT_PRIMARY_CULL", "0")
+    with hip.HipScene(sc) as hs:
+        hs.render_device(cam, abi.default_opts(spp=4, seed=3, flags=abi.FLAG_COLLECT_STATS), out.data_ptr())
+        assert hs.stats()["rays"] == rays
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), exp.view(np.uint32))
