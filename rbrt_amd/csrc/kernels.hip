@@ -872,6 +872,25 @@ __global__ __launch_bounds__(kBlock) void primary_cull_kernel(const TraceParams 
         if (out) word |= 1u << e;
         else all = false;
     }
+    // can a forward camera ray of the tile enter this box? (bounding sphere against the cone; corners against the slabs)
+    const auto box_unreachable = [&](D3 lo, D3 hi, double slack, double far) -> bool {
+        const D3 q = 0.5 * (lo + hi) - pos;
+        const double l = dlen(q);
+        if (cone.misses((1.0 / l) * q, l, 0.5 * dlen(hi - lo) * 1.001 + slack, 1.0)) return true;
+        const double reach = slack + angle * far;
+        for (uint32_t slab = 0; slab < 2u; ++slab) {
+            const CullSlab& sl = slab ? rows : cols;
+            bool pos_side = true, neg_side = true;
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const D3 v = D3{k & 1u ? hi.x : lo.x, k & 2u ? hi.y : lo.y, k & 4u ? hi.z : lo.z} - pos;
+                const double g0 = ddot(sl.n_lo, v), g1 = ddot(sl.n_hi, v);
+                pos_side = pos_side && g0 > reach && g1 > reach;
+                neg_side = neg_side && g0 < -reach && g1 < -reach;
+            }
+            if (pos_side || neg_side) return true;
+        }
+        return false;
+    };
     for (uint32_t m = 0; m < P.n_meshes && m < 7u; ++m) {
         const DevMesh& md = P.meshes[m];
         double far = 0.0;
@@ -883,30 +902,39 @@ __global__ __launch_bounds__(kBlock) void primary_cull_kernel(const TraceParams 
             finite = finite && l < 1e30;
             far = l > far ? l : far;
         }
-        bool out = false;
-        if (finite) {
-            // aabbox.rs:28-58 in float: six quotients and their min / max, a few ulp of the largest magnitude
-            const double slack = 1e-4 * far;
-            const D3 lo = d3(md.bbox_lo), hi = d3(md.bbox_hi);
-            const D3 q = 0.5 * (lo + hi) - pos;
-            const double l = dlen(q);
-            out = cone.misses((1.0 / l) * q, l, 0.5 * dlen(hi - lo) * 1.001 + slack, 1.0);
-            for (uint32_t slab = 0; slab < 2u && !out; ++slab) {
-                const CullSlab& sl = slab ? rows : cols;
-                const double reach = slack + angle * far;
-                bool pos_side = true, neg_side = true;
-                for (uint32_t k = 0; k < 8u; ++k) {
-                    const D3 v = D3{double(k & 1u ? md.bbox_hi[0] : md.bbox_lo[0]), double(k & 2u ? md.bbox_hi[1] : md.bbox_lo[1]),
-                                    double(k & 4u ? md.bbox_hi[2] : md.bbox_lo[2])} - pos;
-                    const double g0 = ddot(sl.n_lo, v), g1 = ddot(sl.n_hi, v);
-                    pos_side = pos_side && g0 > reach && g1 > reach;
-                    neg_side = neg_side && g0 < -reach && g1 < -reach;
+        // aabbox.rs:28-58 in float: six quotients and their min / max, a few ulp of the largest magnitude; the triangle
+        // test (triangle.rs:134-262) likewise admits rays a few ulp outside a triangle: the same slack for both
+        const double slack = 1e-4 * far;
+        const bool out = finite && box_unreachable(d3(md.bbox_lo), d3(md.bbox_hi), slack, far);
+        if (out) word |= 1u << (24u + m);
+        // A ray may pass the mesh's box and still have no triangle to hit: the tile is free of the mesh as well when
+        // every box in the top kCullLevels levels of its tree (bvh.cpp: each bounds its triangles, padded outwards) is
+        // out of the tile's reach. Depth first, descending only where a box is in reach.
+        bool mesh_free = out;
+        if (!out && finite && md.n_nodes != 0u) {
+            constexpr uint32_t kCullLevels = 4;
+            uint32_t stack[3 * kCullLevels + 4];
+            uint32_t sp = 0;
+            stack[sp++] = 0u;  // (node index << 3 | level)
+            mesh_free = true;
+            while (sp != 0u && mesh_free) {
+                const uint32_t e = stack[--sp];
+                const BvhNode4& nd = md.nodes[e >> 3];
+                for (uint32_t c = 0; c < 4u && mesh_free; ++c) {
+                    const int32_t link = nd.child[c];
+                    if (link == kNoChild) continue;
+                    const D3 lo = D3{double(nd.lo_x[c]), double(nd.lo_y[c]), double(nd.lo_z[c])};
+                    const D3 hi = D3{double(nd.hi_x[c]), double(nd.hi_y[c]), double(nd.hi_z[c])};
+                    if (!(dlen(lo - pos) < 1e30 && dlen(hi - pos) < 1e30)) {
+                        mesh_free = false;  // (not a box this rule understands)
+                    } else if (!box_unreachable(lo, hi, slack, far)) {
+                        if (link >= 0 && (e & 7u) + 1u < kCullLevels && sp < 3u * kCullLevels + 4u) stack[sp++] = (uint32_t(link) << 3) | ((e & 7u) + 1u);
+                        else mesh_free = false;
+                    }
                 }
-                out = pos_side || neg_side;
             }
         }
-        if (out) word |= 1u << (24u + m);
-        else all = false;
+        if (!mesh_free) all = false;
     }
     if (all) word |= 1u << 31;
     P.tile_cull[tile] = word;

@@ -76,15 +76,19 @@ def jitters(rng, W, H):
                (rng.integers(0, 1 << 24, (H, W)).astype(f32) * f32(2.0 ** -24)))
 
 
-def check_table(hip, oracle, cam, sc, rng, max_dist=2000.0):
+def check_table(hip, oracle, cam, sc, rng, max_dist=2000.0, full_scene_jitters=8):
     """Looks for a ray that passes a test its tile's word rules out. Returns the table."""
     W, H = cam.img_width_pix, cam.img_height_pix
     with hip.HipScene(sc) as hs:
         table = hs.primary_cull(cam)
     n_el = len(sc.spheres)
     reach = [np.zeros(table.shape, bool) for _ in range(n_el + len(sc.meshes))]
-    for u0, u1 in jitters(rng, W, H):
+    anything = np.zeros(table.shape, bool)
+    for n, (u0, u1) in enumerate(jitters(rng, W, H)):
         rays = camera_rays(cam, u0, u1)
+        if n < full_scene_jitters:  # Scene::hit itself (all triangles, brute force): what a "background only" tile promises
+            _, obj, _, _ = oracle.trace_rays(sc, rays, 0.001, max_dist)
+            anything |= tiles_of(obj >= 0, W, H)
         for e, sp in enumerate(sc.spheres):
             _, obj, _, _ = oracle.trace_rays(abi.SceneData(spheres=[sp]), rays, 0.001, max_dist)
             reach[e] |= tiles_of(obj >= 0, W, H)
@@ -96,9 +100,17 @@ def check_table(hip, oracle, cam, sc, rng, max_dist=2000.0):
     for m in range(min(len(sc.meshes), 7)):
         bad = reach[n_el + m] & (((table >> (24 + m)) & 1) != 0)
         assert not bad.any(), f"mesh {m}: box culled in tiles {np.argwhere(bad)[:5].tolist()} that a camera ray enters it from"
-    every = np.uint32(((1 << n_el) - 1) | (((1 << len(sc.meshes)) - 1) << 24))
+    # bit 31: every sphere out of reach, and every mesh -- by its box, or by the boxes of the top of its tree
+    elements = np.uint32((1 << n_el) - 1)
+    every = np.uint32(int(elements) | (((1 << len(sc.meshes)) - 1) << 24))
     sky = (table >> 31) != 0
-    assert np.array_equal(sky, (table & every) == every) or n_el > 24 or len(sc.meshes) > 7
+    if n_el <= 24 and len(sc.meshes) <= 7:
+        assert not (sky & ((table & elements) != elements)).any()
+        assert not (~sky & ((table & every) == every)).any()
+    else:
+        assert not sky.any()
+    bad = sky & anything
+    assert not bad.any(), f"background-only tiles {np.argwhere(bad)[:5].tolist()} have a camera ray that hits something"
     return table, reach
 
 
@@ -128,15 +140,15 @@ def test_no_camera_ray_passes_a_culled_test(hip, oracle, name):
 
 def test_the_rule_is_worth_having_on_the_bench_frame(hip, oracle):
     """Config 2's camera at full size: how much the table removes (a regression here is a performance bug, not a wrong
-    image): more than a quarter of the tiles see sky only, and the camera rays keep less than one sphere test of four."""
+    image): a third of the tiles see sky only (40 % do in truth), and the camera rays keep less than one sphere test of four."""
     rng = np.random.default_rng(5)
     cam = scenes.camera(oracle, 1024, 768)
     sc = scenes.example_scene(oracle, 3000)
-    table, reach = check_table(hip, oracle, cam, sc, rng)
+    table, reach = check_table(hip, oracle, cam, sc, rng, full_scene_jitters=3)
     sky = np.count_nonzero(table >> 31) / table.size
     left = sum(np.count_nonzero(((table >> e) & 1) == 0) for e in range(4)) / table.size
     exact = sum(np.count_nonzero(r) for r in reach[:4]) / table.size
-    assert sky > 0.25 and left < 1.0, (sky, left)
+    assert sky > 0.32 and left < 1.0, (sky, left)
     assert left < exact + 0.25, (left, exact)  # within a quarter of a test per tile of what the sampled rays reach
 
 
