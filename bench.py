@@ -290,6 +290,12 @@ def main():
 
     import hashlib
     image_sha = hashlib.sha256(image.cpu().numpy().tobytes()).hexdigest()[:16]
+    if os.environ.get("RBRT_PRIMARY_CULL") == "0" and os.environ.get("RBRT_HIP_LAB") == "1":
+        tile_pass = "off (lab knob RBRT_PRIMARY_CULL=0)"
+    else:
+        table = scene.primary_cull(cam)  # (debug hook: the table the library computes for this camera)
+        tile_pass = {"tiles": int(table.size), "background_only_tiles": int((table >> 31).sum()),
+                     "finished_by": "sky_resolve_kernel (streaming), the rest by trace_megakernel + resolve_kernel"}
     samples_per_step = W * H * spp
     if emu:
         samples_per_step = rbrt_amd.packed_pixels(W, H, 0, emu) * spp
@@ -384,6 +390,9 @@ def main():
                    if args.pipeline != 1 else "1 (no overlap between steps)",
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                    "launch_mix_timed_region": {"full_grid": mix_full, "half_grid": mix_half},
+                   # which tiles the trace kernel never sees (DESIGN.md "The tile pass"): every sample of theirs is still
+                   # produced -- by sky_resolve_kernel, inside the timed region -- and counted in `value`
+                   "tile_pass": tile_pass,
                    "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,
                    **({"EMULATION_rank0_share_of_world": emu} if emu else {}),
                    # (with the pipeline on, the resolve waits on another stream: its event pair measures that wait)
