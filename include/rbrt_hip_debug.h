@@ -17,6 +17,7 @@
  *   RBRT_WAVES_PER_CU=1..32      RBRT_PIPELINE=0..8             RBRT_LANE_PRIORITY=low|default|high
  *   RBRT_BVH_CT=<SAH traversal cost, 4.0>   RBRT_PLOC_RADIUS=1..256 (device builder's neighbour search)
  *   RBRT_BVH_DEVICE_MIN=<entries>, RBRT_BVH_DEVICE_ALGO=ploc|lbvh   RBRT_POISON_SAMPLES=1 (tests)
+ *   RBRT_PRIMARY_CULL=0|1        the tile pass (1): tiles whose camera rays reach nothing bypass the trace kernel
  */
 #ifndef RBRT_HIP_DEBUG_H
 #define RBRT_HIP_DEBUG_H
@@ -89,11 +90,12 @@ int rbrt_hip_bvh_build_device(const rbrt_mesh_t* mesh, void** nodes_out, size_t*
 int rbrt_hip_debug_scatter(const rbrt_material_t* mats, const float* in_dir, const float* p, const float* normal,
                            const uint32_t* rng_state, size_t n, float* out_dir, uint8_t* out_ok, uint32_t* out_rng_state);
 
-/* Test hook for the primary-ray culling table (DESIGN.md "Primary-ray culling"): what the library computes on the trace
+/* Test hook for the primary-ray culling table (DESIGN.md "The tile pass"): what the library computes on the trace
  * launch's stream before every launch for `cam`, one word per 8x8 tile of the image in row-major tile order
  * (n_words must be ceil(width/8) * ceil(height/8)): bit e < 24 = no camera ray of the tile can reach element e (spheres
- * only), bit 24 + m (m < 7) = none can pass the box of mesh m, bit 31 = the tile sees the background only. A set bit is
- * a promise; tests check it against the oracle's rays. Host array. */
+ * only), bit 24 + m (m < 7) = none can pass the box of mesh m, bit 31 = the tile sees the background only (every sphere
+ * out of reach, and every mesh: by its box, or by the boxes at the top of its tree). A set bit is a promise; tests check
+ * it against the oracle's rays. Host array. */
 int rbrt_hip_debug_primary_cull(rbrt_hip_scene_t* scene, const rbrt_camera_t* cam, uint32_t* out_words, size_t n_words);
 
 /* Kernel timing with HIP events recorded on the launch stream around every trace-kernel launch

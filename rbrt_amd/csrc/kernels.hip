@@ -741,12 +741,12 @@ __global__ __launch_bounds__(kBlock) void sky_resolve_kernel(const TraceParams P
 }
 
 // ---------------------------------------------------------------------------------------------
-// Primary-ray culling. Every camera ray of an 8x8 tile starts at cam.position and passes through a small rectangle
-// of the image plane (cam.rs:64-82), so which spheres and mesh boxes the tile's rays can reach at all is known before
-// a single ray is made: half of all rays are camera rays, and most of them face four sphere tests and a box test
-// whose outcome the tile already decides. This kernel writes one word per tile (TraceParams::tile_cull); the trace
-// kernel skips the tests it rules out. A skipped test is one the reference would have run and FAILED, so the image
-// does not change; the proof obligation is that the rule never skips a test that could succeed.
+// The tile pass (DESIGN.md "The tile pass"). Every camera ray of an 8x8 tile starts at cam.position and passes through
+// a small rectangle of the image plane (cam.rs:64-82), so which spheres and meshes the tile's rays can reach at all is
+// known before a single ray is made. This kernel writes one word per tile (TraceParams::tile_cull); a tile whose rays
+// can reach NOTHING sees the background only (lib.rs:68-71): tile_lists_kernel takes it off the trace kernel's work and
+// sky_resolve_kernel finishes its pixels. A test declared out of reach is one the reference would have run and FAILED,
+// so the image does not change; the proof obligation is that the rule never rules out a test that could succeed.
 //
 // Directions. The tile's exact ray directions are the unit vectors from the position to a (widened) rectangle of the
 // image plane: a convex spherical quadrilateral, inside the cone of half-angle rho (largest angle to a corner) around
