@@ -18,6 +18,8 @@
  *   RBRT_BVH_CT=<SAH traversal cost, 4.0>   RBRT_PLOC_RADIUS=1..256 (device builder's neighbour search)
  *   RBRT_BVH_DEVICE_MIN=<entries>, RBRT_BVH_DEVICE_ALGO=ploc|lbvh   RBRT_POISON_SAMPLES=1 (tests)
  *   RBRT_PRIMARY_CULL=0|1        the tile pass (1): tiles whose camera rays reach nothing bypass the trace kernel
+ *   RBRT_TILE_ORDER=0|1|2        tiles handed out: as api.cpp decides (0), first-to-last (1), last-to-first (2)
+ *   RBRT_TILE_CLASSES=0..3       work list ascending (0), or by tile class: heavy|light, light/2|heavy|light/2, light|heavy
  */
 #ifndef RBRT_HIP_DEBUG_H
 #define RBRT_HIP_DEBUG_H

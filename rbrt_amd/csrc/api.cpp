@@ -163,6 +163,8 @@ struct rbrt_hip_scene {
     uint32_t drain_mode = 1;      // RBRT_DRAIN_MODE
     uint32_t work_stripes = 16;   // RBRT_WORK_STRIPES: chunks (of 64 work items) per stripe for a launch that has the GPU to itself; 0 = contiguous shards
     uint32_t work_stripes_overlap = 0;  // RBRT_WORK_STRIPES_OVERLAP: the same for a launch issued while another is running
+    uint32_t tile_classes = 0;    // RBRT_TILE_CLASSES (order of the work list by tile class, tile_lists_kernel)
+    uint32_t tile_order = 0;      // RBRT_TILE_ORDER (0: empty_end_is_first decides; 1: first-to-last; 2: last-to-first)
     uint32_t primary_cull = 1;    // RBRT_PRIMARY_CULL (0: no tile pass, the trace kernel renders every tile)
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
@@ -637,7 +639,8 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             lab_u32("RBRT_WORK_STRIPES_OVERLAP", 0, 65536, stripes_overlap, err) && lab_u32("RBRT_DRAIN_MODE", 0, 11, s->drain_mode, err) &&
             lab_u32("RBRT_SHADE_ROUNDS", 1, kMaxShadeRounds, s->shade_rounds, err) &&
             lab_u32("RBRT_SHADE_CONT_MIN", 1, 64, s->shade_cont_min, err) && lab_u32("RBRT_PIPELINE", 0, kMaxPipeline, s->pipeline, err) &&
-            lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err) && lab_u32("RBRT_PRIMARY_CULL", 0, 1, s->primary_cull, err);
+            lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err) && lab_u32("RBRT_PRIMARY_CULL", 0, 1, s->primary_cull, err) &&
+            lab_u32("RBRT_TILE_ORDER", 0, 2, s->tile_order, err) && lab_u32("RBRT_TILE_CLASSES", 0, 3, s->tile_classes, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
         if ((stripes & (stripes - 1u)) != 0u || (stripes_overlap & (stripes_overlap - 1u)) != 0u)  // the kernel shifts
             return bail(fail(RBRT_ERR_INVALID_ARG, "lab knob RBRT_WORK_STRIPES / RBRT_WORK_STRIPES_OVERLAP must be 0 or a power of two"));
@@ -787,6 +790,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.tiles_x = tiles_x, P.tiles_y = tiles_y, P.n_tiles = n_tiles;
     P.tiles_x_magic = div_magic_of(tiles_x);
     P.tiles_reversed = empty_end_is_first(s, *cam, tiles_x, o->tile_rank, world, n_local) ? 1u : 0u;
+    if (s->tile_order != 0u) P.tiles_reversed = s->tile_order - 1u;  // (lab knob)
     P.tile_rank = o->tile_rank, P.tile_world = world, P.n_local_tiles = n_local;
     P.stack_entries = s->stack_entries;
     P.y_low_water = s->y_low_water;
@@ -878,6 +882,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.gstack = L.d_gstack;
         P.tile_cull = tile_pass ? L.d_tile_cull : nullptr;
         P.tile_lists = tile_pass ? L.d_tile_lists : nullptr;
+        P.tile_list_mode = s->tile_classes;
+        if (tile_pass && s->tile_classes != 0u) P.tiles_reversed = 0u;  // (the list is in hand-out order already)
         // (L.d_work_counter is zero: from its allocation, afterwards from the resolve kernel of the lane's last launch)
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));

@@ -148,6 +148,7 @@ struct TraceParams {
     // background-only ones, which sky_resolve_kernel finishes without the trace kernel ever seeing them.
     uint32_t* tile_cull;
     uint32_t* tile_lists;
+    uint32_t tile_list_mode;  // order of the work list (tile_lists_kernel)
 };
 
 struct ResolveParams {

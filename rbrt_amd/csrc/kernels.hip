@@ -816,8 +816,9 @@ struct CullCone {
     }
 };
 
-__global__ __launch_bounds__(kBlock) void primary_cull_kernel(const TraceParams P) {
-    const uint32_t tile = blockIdx.x * kBlock + threadIdx.x;
+constexpr int kCullBlock = 64;  // (one wave per workgroup: 12,288 tiles spread over 192 CUs instead of 48)
+__global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TraceParams P) {
+    const uint32_t tile = blockIdx.x * kCullBlock + threadIdx.x;
     if (tile >= P.n_tiles) return;
     const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const rbrt_camera_t& c = P.cam;
@@ -944,32 +945,55 @@ __global__ __launch_bounds__(kBlock) void primary_cull_kernel(const TraceParams 
 // workgroup, every thread a contiguous run of local tiles, an exclusive scan of the runs' counts in between.
 constexpr int kListBlock = 1024;
 __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParams P) {
-    __shared__ uint32_t sums[kListBlock];
+    __shared__ uint32_t sums[2][kListBlock];
     const uint32_t n = P.n_local_tiles, t = threadIdx.x;
     const uint32_t per = (n + kListBlock - 1) / kListBlock;
     const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
-    uint32_t mine = 0;  // tiles of this run that go to the trace kernel
-    for (uint32_t tl = lo; tl < hi; ++tl) mine += (P.tile_cull[tl * P.tile_world + P.tile_rank] >> 31) ? 0u : 1u;
-    sums[t] = mine;
+    // class of a tile: 2 = background only; 1 = light (no mesh box in reach, at most one sphere); 0 = heavy
+    const uint32_t el_mask = (1u << (P.n_spheres < 24u ? P.n_spheres : 24u)) - 1u, me_mask = (1u << (P.n_meshes < 7u ? P.n_meshes : 7u)) - 1u;
+    const auto tile_class = [&](uint32_t tl) -> uint32_t {
+        const uint32_t word = P.tile_cull[tl * P.tile_world + P.tile_rank];
+        if (word >> 31) return 2u;
+        if (P.tile_list_mode == 0u) return 0u;
+        const bool light = ((word >> 24) & me_mask) == me_mask && __popc(~word & el_mask) <= 1 && P.n_spheres <= 24u && P.n_meshes <= 7u;
+        return light ? 1u : 0u;
+    };
+    uint32_t mine[2] = {0u, 0u};  // heavy / light tiles of this run (both go to the trace kernel)
+    for (uint32_t tl = lo; tl < hi; ++tl) {
+        const uint32_t c = tile_class(tl);
+        if (c < 2u) ++mine[c];
+    }
+    sums[0][t] = mine[0], sums[1][t] = mine[1];
     __syncthreads();
-    for (uint32_t d = 1; d < kListBlock; d <<= 1) {  // inclusive scan
-        const uint32_t v = t >= d ? sums[t - d] : 0u;
+    for (uint32_t d = 1; d < kListBlock; d <<= 1) {  // inclusive scans
+        const uint32_t v0 = t >= d ? sums[0][t - d] : 0u, v1 = t >= d ? sums[1][t - d] : 0u;
         __syncthreads();
-        sums[t] += v;
+        sums[0][t] += v0, sums[1][t] += v1;
         __syncthreads();
     }
-    uint32_t w = sums[t] - mine;       // work tiles before this run
-    uint32_t k = lo - w;               // background-only tiles before it
+    const uint32_t n_heavy = sums[0][kListBlock - 1], n_light = sums[1][kListBlock - 1], n_work = n_heavy + n_light;
+    uint32_t r[2] = {sums[0][t] - mine[0], sums[1][t] - mine[1]};  // heavy / light tiles before this run
+    uint32_t k = lo - r[0] - r[1];                                  // background-only tiles before it
     uint32_t* const work = P.tile_lists + kTileListHeader;
     uint32_t* const sky = work + n;
+    // where the classes go in the work list (tile_list_mode; 0: one class, ascending): 1 heavy | light, 2 light/2 | heavy |
+    // light/2, 3 light | heavy -- each class ascending in itself
+    const uint32_t half = n_light / 2u;
     for (uint32_t tl = lo; tl < hi; ++tl) {
-        if (P.tile_cull[tl * P.tile_world + P.tile_rank] >> 31) sky[k++] = tl;
-        else work[w++] = tl;
+        const uint32_t c = tile_class(tl);
+        if (c == 2u) {
+            sky[k++] = tl;
+            continue;
+        }
+        uint32_t pos;
+        if (c == 0u) pos = (P.tile_list_mode == 2u ? half : P.tile_list_mode == 3u ? n_light : 0u) + r[0]++;
+        else pos = (P.tile_list_mode == 1u ? n_heavy : P.tile_list_mode == 2u && r[1] >= half ? n_heavy : 0u) + r[1]++;
+        work[pos] = tl;
     }
     if (t == kListBlock - 1) {
-        P.tile_lists[0] = sums[t];
-        P.tile_lists[1] = n - sums[t];
-        P.tile_lists[2] = 0u, P.tile_lists[3] = 0u;
+        P.tile_lists[0] = n_work;
+        P.tile_lists[1] = n - n_work;
+        P.tile_lists[2] = n_light, P.tile_lists[3] = 0u;
     }
 }
 
@@ -1153,7 +1177,7 @@ hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint3
 // The tile pass: the culling table of P.cam, then (tile_lists given) the rank's two tile lists from it.
 hipError_t launch_primary_cull(const TraceParams& P, hipStream_t stream) {
     if (P.n_tiles == 0 || !P.tile_cull) return hipSuccess;
-    hipLaunchKernelGGL(primary_cull_kernel, dim3((P.n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, P);
+    hipLaunchKernelGGL(primary_cull_kernel, dim3((P.n_tiles + kCullBlock - 1) / kCullBlock), dim3(kCullBlock), 0, stream, P);
     if (P.tile_lists) hipLaunchKernelGGL(tile_lists_kernel, dim3(1), dim3(kListBlock), 0, stream, P);
     return hipGetLastError();
 }
