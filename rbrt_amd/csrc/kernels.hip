@@ -754,7 +754,8 @@ __global__ __launch_bounds__(kBlock) void sky_resolve_kernel(const TraceParams P
 // q = (centre - position) / l. So with the OUTER radius R_out (inflated, below):
 //   forward rays miss it     when angle(c, q)  > asin(R_out / l) + rho,
 //   backward lines miss it   when angle(-c, q) > asin(R_out / l) + rho,
-//   backward lines cut DEEP  when angle(-c, q) + rho < asin(R_in / l)   (R_in: deflated; the position clearly outside).
+//   backward lines cut DEEP  when all four corners k have angle(-corner_k, q) < asin(R_in / l) (R_in: deflated; a cap of
+//                            less than a quarter turn is convex, so the corners speak for the tile; the position clearly outside).
 // sphere.rs:20-66 needs the forward condition and one of the backward ones: it looks at the LINE first (discriminant),
 // and with a discriminant of exactly zero it accepts a negative parameter (sphere.rs:41-49: the `sol > 0.0 &&` guard),
 // so a line that grazes the sphere BEHIND the camera could be a hit; one that misses it there cannot, and one that cuts
@@ -770,10 +771,16 @@ __global__ __launch_bounds__(kBlock) void sky_resolve_kernel(const TraceParams P
 // object entirely inside {f_lo > 0, f_hi > 0} or {f_lo < 0, f_hi < 0} meets none of the lines at all. Same with rows.
 //
 // Margins. The kernel's rays are float: the target point carries an absolute error of a few ulp of |img_center| and
-// |position| (target - position cancels), an angle of err / |target - position| against the exact line; the
-// discriminant b^2 - 4ac carries ~10 ulp of 4 (|l|^2 + r^2), which admits lines up to 3e-7 (|l|^2 + r^2) / r outside
-// the sphere. Radii are inflated (deflated) by 30x that plus 0.1 %, angles widened by the direction error, the pixel
-// interval by 1e-3 pixel plus the rounding of (col_off + u) - 0.5. A degenerate camera makes the quantities NaN and
+// |position| (target - position cancels), an angle of err / |target - position| against the exact line (taken as 16
+// unit roundoffs of the magnitudes involved, twice over). The sphere test with u = 2^-24, a = d.d = 1 +- 4u: l = o - c
+// carries u |l| per component, b = (2d).l at most 8u |l|, c = l.l - r r at most 6u (|l|^2 + r^2), and the discriminant
+// b b - (4a) c at most 36u |l|^2 + 48u (|l|^2 + r^2) + 4u max(b^2, 4ac) <= 90u (|l|^2 + r^2) = 5.4e-6 (|l|^2 + r^2)
+// against its exact value 4 (r^2 - m^2), m the distance of the line from the centre: a line is taken for a hit at most
+// 0.7e-6 (|l|^2 + r^2) / r outside the sphere, and a line more than that inside has a discriminant above zero. Radii are
+// inflated (deflated) by 1e-5 (|l|^2 + r^2) / r, 15x that, plus 1e-5 r + 1e-6 |l|; angles are widened by the direction
+// error, the pixel interval by 1e-3 pixel plus the rounding of (col_off + u) - 0.5. (A first version used 0.1 % of the
+// radius: a full unit for the ground sphere, which made the band of tiles whose backward lines "might graze" it six tile
+// rows high instead of two.) A degenerate camera makes the quantities NaN and
 // every comparison false: nothing is culled. Non-finite or non-positive radii and non-finite boxes (a mesh without
 // triangles has lo = +inf) are never culled: the reference's NaN panic (sphere.rs:33), reported through
 // nan_discriminants, must still be reached. BasicTriangle elements are never culled (the YAML cannot describe them).
@@ -811,8 +818,15 @@ struct CullCone {
     __device__ __forceinline__ bool misses(D3 qhat, double l, double R, double sign) const {
         return R < l && angle_between(sign * mid, qhat) > asin(R / l) + rho;
     }
+    // (a cap of less than a quarter turn is convex on the sphere: the four corners inside it put the whole tile inside)
+    D3 corner[4];
+    double widen;  // the float ray's direction error
     __device__ __forceinline__ bool backward_deep(D3 qhat, double l, double r_in) const {
-        return r_in > 0.0 && r_in < l && angle_between(-1.0 * mid, qhat) + rho < asin(r_in / l);
+        if (!(r_in > 0.0 && r_in < l)) return false;
+        const double cap = asin(r_in / l) - widen;
+        bool in = true;
+        for (uint32_t k = 0; k < 4u; ++k) in = in && angle_between(-1.0 * corner[k], qhat) < cap;
+        return in;
     }
 };
 
@@ -847,10 +861,12 @@ __global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TracePar
     cone.rho = 0.0;
     for (uint32_t k = 0; k < 4u; ++k) {
         const D3 u = unit_or_nan(a + (0.001 * (k & 1u ? cm1 : cm0)) * right - (0.001 * (k & 2u ? rm1 : rm0)) * up);
+        cone.corner[k] = u;
         const double t = angle_between(cone.mid, u);
         cone.rho = t > cone.rho || !(t == t) ? t : cone.rho;  // (a NaN sticks)
     }
     cone.rho += angle;
+    cone.widen = angle;
 
     const uint32_t n_elem = P.n_spheres + P.n_elem_tris;
     uint32_t word = 0;
@@ -863,7 +879,8 @@ __global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TracePar
             const D3 q = d3(sp.center) - pos;
             const double r = double(sp.radius), l = dlen(q);
             if (r > 0.0 && r < 1e30 && l < 1e30) {  // (false for NaN)
-                const double slack = r * 1e-3 + 1e-5 * (l * l + r * r) / r + 1e-4 * l;
+                // (the second term is the analysed one, 15x the bound in the header; the others are loose change on top)
+                const double slack = 1e-5 * r + 1e-5 * (l * l + r * r) / r + 1e-6 * l;
                 const double reach = r + slack + angle * (l + r);
                 const D3 qhat = (1.0 / l) * q;
                 out = cols.outside(q, reach) || rows.outside(q, reach) ||
