@@ -930,7 +930,7 @@ __global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TracePar
         // out of the tile's reach. Depth first, descending only where a box is in reach.
         bool mesh_free = out;
         if (!out && finite && md.n_nodes != 0u) {
-            constexpr uint32_t kCullLevels = 4;
+            constexpr uint32_t kCullLevels = 6;
             uint32_t stack[3 * kCullLevels + 4];
             uint32_t sp = 0;
             stack[sp++] = 0u;  // (node index << 3 | level)
