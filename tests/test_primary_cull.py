@@ -140,7 +140,7 @@ def test_no_camera_ray_passes_a_culled_test(hip, oracle, name):
 
 def test_the_rule_is_worth_having_on_the_bench_frame(hip, oracle):
     """Config 2's camera at full size: how much the table removes (a regression here is a performance bug, not a wrong
-    image): a third of the tiles see sky only (40 % do in truth), and the camera rays keep less than one sphere test of four."""
+    image): 37 % of the tiles see sky only (40 % do in truth), and the camera rays keep less than one sphere test of four."""
     rng = np.random.default_rng(5)
     cam = scenes.camera(oracle, 1024, 768)
     sc = scenes.example_scene(oracle, 3000)
@@ -148,7 +148,7 @@ def test_the_rule_is_worth_having_on_the_bench_frame(hip, oracle):
     sky = np.count_nonzero(table >> 31) / table.size
     left = sum(np.count_nonzero(((table >> e) & 1) == 0) for e in range(4)) / table.size
     exact = sum(np.count_nonzero(r) for r in reach[:4]) / table.size
-    assert sky > 0.32 and left < 1.0, (sky, left)
+    assert sky > 0.36 and left < 1.0, (sky, left)
     assert left < exact + 0.25, (left, exact)  # within a quarter of a test per tile of what the sampled rays reach
 
 
