@@ -824,14 +824,12 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             s->events.push_back(e);
         }
     }
-    const size_t ev0 = s->events_used;
-    for (size_t b = 0; b < n_batches; ++b) {
-        const uint32_t base = s_begin + uint32_t(b * batch);
-        const uint32_t nb = uint32_t(std::min<size_t>(batch, s_end - base));
-        // counting launches run alone on lane 0: their counters are reset and read on the caller's stream
-        rbrt_hip_scene::Lane& L = s->lanes[stats ? 0 : s->next_lane++ % depth];
-        const bool piped = depth > 1 && !stats;
-        hipStream_t ts = piped ? L.stream : stream;  // the trace launch's stream
+    // Every lane's buffers are sized here, at the first call that needs them, not when a lane first comes up in the
+    // rotation (a hipMalloc in the middle of a stream of frames).
+    const bool tile_pass = s->primary_cull != 0;
+    const size_t lists_need = size_t(kTileListHeader) + 2u * size_t(n_local);
+    for (uint32_t li = 0; li < depth; ++li) {
+        rbrt_hip_scene::Lane& L = s->lanes[li];
         if (need > L.sample_buf_bytes) {
             if (L.d_sample_buf) {
                 if (int rc = sync_lanes()) return rc;
@@ -842,8 +840,6 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             HIP_TRY(hipMalloc(&p, need));
             L.d_sample_buf = static_cast<float*>(p), L.sample_buf_bytes = need;
         }
-        const bool tile_pass = s->primary_cull != 0;
-        const size_t lists_need = size_t(kTileListHeader) + 2u * size_t(n_local);
         if (tile_pass && (n_tiles > L.tile_cull_words || lists_need > L.tile_lists_words)) {
             if (L.d_tile_cull || L.d_tile_lists) {
                 if (int rc = sync_lanes()) return rc;
@@ -860,6 +856,35 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             L.d_tile_lists = static_cast<uint32_t*>(p), L.tile_lists_words = lists_need;
             if (!L.ev_lists) HIP_TRY(hipEventCreateWithFlags(&L.ev_lists, hipEventDisableTiming));
         }
+    }
+    // The tile pass of a lane that has never had one runs now, for this camera, on the caller's stream: later, in the
+    // middle of a stream of frames, its kernels would have to wait for room beside the resident trace waves. (A lane whose
+    // lists are for another camera still redoes them at its turn.)
+    if (tile_pass) {
+        TraceParams T;
+        fill_trace_params(s, cam, o, T);
+        T.tiles_x = tiles_x, T.tiles_y = tiles_y, T.n_tiles = n_tiles;
+        T.tile_rank = o->tile_rank, T.tile_world = world, T.n_local_tiles = n_local;
+        T.tile_list_mode = s->tile_classes;
+        for (uint32_t li = 0; li < depth; ++li) {
+            rbrt_hip_scene::Lane& L = s->lanes[li];
+            if (L.tile_key_valid) continue;
+            T.tile_cull = L.d_tile_cull, T.tile_lists = L.d_tile_lists;
+            HIP_TRY(launch_primary_cull(T, stream));
+            HIP_TRY(hipEventRecord(L.ev_lists, stream));
+            std::memset(&L.tile_key, 0, sizeof(L.tile_key));
+            L.tile_key.cam = *cam, L.tile_key.rank = o->tile_rank, L.tile_key.world = world;
+            L.tile_key_valid = true;
+        }
+    }
+    const size_t ev0 = s->events_used;
+    for (size_t b = 0; b < n_batches; ++b) {
+        const uint32_t base = s_begin + uint32_t(b * batch);
+        const uint32_t nb = uint32_t(std::min<size_t>(batch, s_end - base));
+        // counting launches run alone on lane 0: their counters are reset and read on the caller's stream
+        rbrt_hip_scene::Lane& L = s->lanes[stats ? 0 : s->next_lane++ % depth];
+        const bool piped = depth > 1 && !stats;
+        hipStream_t ts = piped ? L.stream : stream;  // the trace launch's stream
         if (piped) {
             // this lane's sample buffer is free once the resolve of its previous launch has run
             if (L.in_use) HIP_TRY(hipStreamWaitEvent(L.stream, L.ev_resolved, 0));
@@ -895,6 +920,9 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             std::memset(&key, 0, sizeof(key));
             key.cam = *cam, key.rank = o->tile_rank, key.world = world;
             if (!L.tile_key_valid || std::memcmp(&key, &L.tile_key, sizeof(key)) != 0) {
+                // (behind the tile pass that wrote these buffers last: it may have run on another stream -- the first one of
+                // a lane runs on the caller's, above -- and must not land on top of this one)
+                if (L.tile_key_valid) HIP_TRY(hipStreamWaitEvent(ts, L.ev_lists, 0));
                 HIP_TRY(launch_primary_cull(P, ts));
                 HIP_TRY(hipEventRecord(L.ev_lists, ts));
                 L.tile_key = key, L.tile_key_valid = true;

@@ -960,7 +960,9 @@ __global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TracePar
 
 // The rank's tiles split by what primary_cull_kernel found, each list in ascending order (TraceParams::tile_lists): one
 // workgroup, every thread a contiguous run of local tiles, an exclusive scan of the runs' counts in between.
-constexpr int kListBlock = 1024;
+// (256 threads, 2 KB of LDS: when the camera changes in the middle of a stream of frames this kernel has to find room
+// beside resident trace waves, which hold every CU's LDS; a 1024-thread workgroup waited milliseconds for a whole free CU)
+constexpr int kListBlock = 256;
 __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParams P) {
     __shared__ uint32_t sums[2][kListBlock];
     const uint32_t n = P.n_local_tiles, t = threadIdx.x;
