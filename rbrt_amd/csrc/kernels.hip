@@ -810,22 +810,28 @@ struct CullSlab {
         return (g0 > reach && g1 > reach) || (g0 < -reach && g1 < -reach);  // (false for NaN)
     }
 };
-// The tile's ray directions: inside the cone of half-angle rho around mid (unit).
+// The tile's ray directions: inside the cone of half-angle rho around mid (unit). The angle comparisons of the header are
+// made on cosines (one square root per ball instead of an arc cosine and an arc sine): for t in [0, pi] and 0 <= a + rho
+// <= pi, t > a + rho is cos t < cos a cos rho - sin a sin rho, with sin a = R / l.
 struct CullCone {
     D3 mid;
-    double rho;
+    double cos_rho, sin_rho;  // rho < pi / 2 (else NaN: nothing is culled)
     // forward rays (sign +1) or backward extensions (sign -1) all miss the ball of radius R at q = l * qhat?
     __device__ __forceinline__ bool misses(D3 qhat, double l, double R, double sign) const {
-        return R < l && angle_between(sign * mid, qhat) > asin(R / l) + rho;
+        if (!(R < l)) return false;
+        const double sa = R / l, ca = sqrt(1.0 - sa * sa);
+        return sign * ddot(mid, qhat) < ca * cos_rho - sa * sin_rho;  // (false for NaN)
     }
     // (a cap of less than a quarter turn is convex on the sphere: the four corners inside it put the whole tile inside)
     D3 corner[4];
-    double widen;  // the float ray's direction error
+    double cos_w, sin_w;  // w: the float ray's direction error
     __device__ __forceinline__ bool backward_deep(D3 qhat, double l, double r_in) const {
         if (!(r_in > 0.0 && r_in < l)) return false;
-        const double cap = asin(r_in / l) - widen;
+        const double sa = r_in / l, ca = sqrt(1.0 - sa * sa);
+        if (!(sa > sin_w)) return false;                 // the cap asin(r_in / l) - w must be a cap
+        const double cos_cap = ca * cos_w + sa * sin_w;  // cos(asin(r_in / l) - w)
         bool in = true;
-        for (uint32_t k = 0; k < 4u; ++k) in = in && angle_between(-1.0 * corner[k], qhat) < cap;
+        for (uint32_t k = 0; k < 4u; ++k) in = in && -ddot(corner[k], qhat) > cos_cap;
         return in;
     }
 };
@@ -858,15 +864,17 @@ __global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TracePar
     const double angle = 2.0 * err / plane_dist + 1e-6;                          // (NaN or inf for a degenerate camera)
     CullCone cone;
     cone.mid = unit_or_nan(a + (0.0005 * (cm0 + cm1)) * right - (0.0005 * (rm0 + rm1)) * up);
-    cone.rho = 0.0;
+    double rho = 0.0;
     for (uint32_t k = 0; k < 4u; ++k) {
         const D3 u = unit_or_nan(a + (0.001 * (k & 1u ? cm1 : cm0)) * right - (0.001 * (k & 2u ? rm1 : rm0)) * up);
         cone.corner[k] = u;
         const double t = angle_between(cone.mid, u);
-        cone.rho = t > cone.rho || !(t == t) ? t : cone.rho;  // (a NaN sticks)
+        rho = t > rho || !(t == t) ? t : rho;  // (a NaN sticks)
     }
-    cone.rho += angle;
-    cone.widen = angle;
+    rho += angle;
+    if (!(rho < 1.5)) rho = __builtin_nan("");  // (a tile a quarter turn wide: no rule applies)
+    cone.cos_rho = cos(rho), cone.sin_rho = sin(rho);
+    cone.cos_w = cos(angle), cone.sin_w = sin(angle);
 
     const uint32_t n_elem = P.n_spheres + P.n_elem_tris;
     uint32_t word = 0;
@@ -929,7 +937,7 @@ __global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TracePar
         // every box in the top kCullLevels levels of its tree (bvh.cpp: each bounds its triangles, padded outwards) is
         // out of the tile's reach. Depth first, descending only where a box is in reach.
         bool mesh_free = out;
-        if (!out && finite && md.n_nodes != 0u) {
+        if (!out && all && finite && md.n_nodes != 0u) {  // (only where the answer matters: nothing else is in reach so far)
             constexpr uint32_t kCullLevels = 6;
             uint32_t stack[3 * kCullLevels + 4];
             uint32_t sp = 0;
