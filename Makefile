@@ -45,4 +45,8 @@ clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all host oracle clean asan tsan timers
+# the flags, for the tools that build variants of the library (tools/build_variant.sh, tools/kres.py)
+print-hipflags:
+	@echo $(HIPFLAGS)
+
+.PHONY: all host oracle clean asan tsan timers print-hipflags

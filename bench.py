@@ -13,6 +13,11 @@ de-interleaves it — so the total work per step is fixed ("scaling": "strong").
 
 The scene is resident in HBM before the timed region (upload + BVH build are setup); the timed
 region is K x [render kernels + gather + unpack], bracketed by barrier + synchronize, MAX over ranks.
+EVERY step of the timed region renders a camera the library has not seen before (the position moves by one unit in the
+last place per step): render_scene takes the camera per call (lib.rs:75-79), and the library's per-camera tile pass
+(primary_cull_kernel + tile_lists_kernel) therefore runs inside the timed region, every step. A second leg renders one
+camera over and over (a stream of frames of a fixed view, where that pass is paid once) and is reported beside it as
+`ms_per_step_same_camera`; it is not `value`.
 
 Rank 0 prints ONE JSON line with, besides the contract's fields:
   roofline     — the trace kernel's ALGORITHMIC bytes / the duration of an ISOLATED launch (a short second leg with
@@ -78,12 +83,16 @@ def parse_args():
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
     ap.add_argument("--cpu-col-stride", type=int, default=-1,
                     help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline; 1 = the whole "
-                         "frame: SURVEY 8(d) times config 2 in full, ~2 min on 256 cores; default: 1 on a host with 64 "
-                         "cores or more, else 8 -- a labelled sample)")
+                         "frame; default: the largest power-of-two fraction of the columns estimated to fit --cpu-budget-s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = every core this process may use)")
     ap.add_argument("--isolated-steps", type=int, default=8,
                     help="steps of the second, unpipelined leg that times isolated trace launches for the roofline (N = 1 only; 0 = skip)")
     ap.add_argument("--single-frames", type=int, default=5, help="blocking frames incl. D2H timed for single_frame (N = 1 only; 0 = skip)")
+    ap.add_argument("--same-camera-steps", type=int, default=-1,
+                    help="steps of the leg that renders ONE camera over and over (the tile pass cached); -1 = as many as --steps, 0 = skip")
+    ap.add_argument("--cpu-budget-s", type=float, default=120.0,
+                    help="the CPU baseline renders the largest power-of-two fraction of the image's columns estimated to fit this many seconds")
+    ap.add_argument("--init-timeout-s", type=float, default=180.0, help="N > 1: limit for the process group's rendezvous and for every collective")
     ap.add_argument("--check", action="store_true", help="also compare the sampled columns with the GPU image")
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="WORLD",
                     help="single process: time only rank 0's share of a WORLD-GPU run (its tiles, no gather); a "
@@ -117,14 +126,22 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_single_gpu:
-            dist.init_process_group("gloo")
-        else:
-            # the trace launches are persistent and hold every wave slot; the gather's copy kernels are short and
-            # on the critical path of every step: RCCL's stream gets high priority (the library's trace streams low)
-            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-            dist.init_process_group("nccl", device_id=dev)
+        tmo = datetime.timedelta(seconds=args.init_timeout_s)
+        try:
+            if args.rehearse_single_gpu:
+                dist.init_process_group("gloo", timeout=tmo)
+            else:
+                # the trace launches are persistent and hold every wave slot; the gather's copy kernels are short and
+                # on the critical path of every step: RCCL's stream gets high priority (the library's trace streams low)
+                os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+        except Exception as e:  # a bounded wait and a message, never a hang and never a restart of a process that has touched the GPU
+            sys.stderr.write(f"bench.py rank {rank}/{world}: the process group did not come up within {args.init_timeout_s:.0f} s "
+                             f"({type(e).__name__}: {e}); MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')}\n")
+            sys.stderr.flush()
+            os._exit(3)
 
     # ---- setup (untimed): stand-in asset, YAML through the C++ host, upload + BVH build ---------
     work = Path(tempfile.mkdtemp(prefix=f"rbrt_bench_r{rank}_"))
@@ -167,25 +184,49 @@ def main():
         gathered_ev = [None, None]
 
     step_no = [0]
+    cam_no = [0]
+    import numpy as np
+
+    def fresh_camera():
+        """A camera the library has not seen: the position's first component moves one unit in the last place per call
+        (every rank makes the same sequence). The image and the work are the frame's to within rounding; the library's
+        per-camera tile pass has to run again."""
+        cam_no[0] += 1
+        c = type(cam).from_buffer_copy(cam)
+        x = np.float32(cam.position[0])
+        for _ in range(cam_no[0]):
+            x = np.nextafter(x, np.float32(np.inf), dtype=np.float32)
+        c.position[0] = float(x)
+        return c
 
     if args.pipeline > 0:  # 0: leave the library's choice (automatic, or $RBRT_PIPELINE)
         scene.set_pipeline(args.pipeline)
 
-    def step():
+    phase_ev = []  # N > 1: (before render, rendered, gather begins, gathered, unpacked) per timed step, for the per-rank split
+
+    def step(new_camera=False, timed=False):
         step_no[0] += 1
         if args.vary_seed:
             opts.seed = args.seed + step_no[0]
+        c = fresh_camera() if new_camera else cam
         if world == 1:
-            scene.render_device(cam, opts, image.data_ptr(), None, stream)  # (emulation: packed tiles, fits)
+            scene.render_device(c, opts, image.data_ptr(), None, stream)  # (emulation: packed tiles, fits)
             return
         b = step_no[0] & 1
         main = torch.cuda.current_stream()
         if gathered_ev[b] is not None:
             main.wait_event(gathered_ev[b])  # the gather of two frames ago has read this buffer
-        scene.render_device(cam, opts, mine[b].data_ptr(), None, stream)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+        if evs:
+            evs[0].record(main)
+        scene.render_device(c, opts, mine[b].data_ptr(), None, stream)
         rendered[b].record(main)
+        if evs:
+            evs[1].record(main)
         xs.wait_event(rendered[b])
         with torch.cuda.stream(xs):
+            if evs:
+                evs[2].record(xs)
             if args.rehearse_single_gpu:  # gloo cannot gather device tensors: stage through the host
                 host = mine[b].cpu()
                 hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
@@ -195,12 +236,17 @@ def main():
                         gathered[b][r].copy_(hg[r], non_blocking=False)
             else:
                 dist.gather(mine[b], gathered[b], dst=0)  # RCCL over xGMI: every peer sends its tiles straight to rank 0
+            if evs:
+                evs[3].record(xs)
             if rank == 0:
                 rbrt_amd.unpack_tiles(local_rank, slots[b].data_ptr(), W, H, world, image.data_ptr(), None, xs.cuda_stream,
                                       rank_stride_pixels=slot_pixels)
             ev = torch.cuda.Event()
             ev.record(xs)
             gathered_ev[b] = ev
+            if evs:
+                evs[4].record(xs)
+                phase_ev.append(evs)
 
     def fence():
         if world > 1:
@@ -218,24 +264,65 @@ def main():
     dbg = scene.debug_counters() if os.environ.get("RBRT_BENCH_DEBUG") else None
     del scratch
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    scene.set_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    enqueue_s = time.perf_counter() - t0  # host time to issue the steps (they run asynchronously)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_single_gpu else dev)
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse_single_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    trace_ms, resolve_ms, n_launches = scene.kernel_ms()
-    mix_full, mix_half = scene.launch_mix()  # the grid of a launch depends on what was in flight when it was issued
-    scene.set_timing(False)
+        return float(t.item())
+
+    def guarded(fn):
+        """N > 1: a failed collective ends the run with a message and a non-zero exit code (the watchdog's timeout bounds the
+        wait); the process is never restarted or re-exec'ed once it has touched the GPU."""
+        try:
+            return fn()
+        except Exception as e:
+            if world == 1:
+                raise
+            sys.stderr.write(f"bench.py rank {rank}/{world}: a collective failed ({type(e).__name__}: {e}); no result line\n")
+            sys.stderr.flush()
+            os._exit(4)
+
+    # ---- the timed region: K steps, every one with a camera the library has not seen (the tile pass runs every step) ----
+    def timed_leg(n_warm, n_steps, new_camera):
+        for _ in range(n_warm):
+            step(new_camera)
+        fence()
+        scene.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(new_camera, timed=world > 1 and new_camera)
+        enq = time.perf_counter() - t0  # host time to issue the steps (they run asynchronously)
+        fence()
+        el = max_over_ranks(time.perf_counter() - t0)
+        tr, rs, nl = scene.kernel_ms()
+        mix = scene.launch_mix()  # the grid of a launch depends on what was in flight when it was issued
+        scene.set_timing(False)
+        return el, enq, tr, rs, nl, mix
+
+    elapsed, enqueue_s, trace_ms, resolve_ms, n_launches, (mix_full, mix_half) = guarded(lambda: timed_leg(args.warmup, args.steps, True))
     scene.check()  # a NaN sphere discriminant (sphere.rs:33 panics) or corrupt path state fails the run loudly
+    # per-rank split of a step (N > 1): spans on this rank's streams, means over the timed steps
+    phases = None
+    if world > 1:
+        def mean_ms(a, b):
+            return sum(e[a].elapsed_time(e[b]) for e in phase_ev) / max(1, len(phase_ev))
+        mine_ph = {"rank": rank, "render_ms": round(mean_ms(0, 1), 4), "gather_wait_ms": round(mean_ms(1, 2), 4),
+                   "gather_ms": round(mean_ms(2, 3), 4), "unpack_ms": round(mean_ms(3, 4), 4)}
+        allp = [None] * world
+        guarded(lambda: dist.all_gather_object(allp, mine_ph))
+        phases = {"per_rank": allp,
+                  "max": {k: max(p[k] for p in allp) for k in ("render_ms", "gather_wait_ms", "gather_ms", "unpack_ms")},
+                  "what": "spans between events on each rank's own streams, mean over the timed steps: render = the library's call on the "
+                          "caller's stream (trace launches on its lanes + resolve); gather_wait = side stream waiting for it; gather = "
+                          "dist.gather; unpack = rank 0's de-interleave"}
+    # ---- the same camera over and over (a stream of frames of one view: the tile pass is paid once) ----
+    same = None
+    n_same = args.steps if args.same_camera_steps < 0 else args.same_camera_steps
+    if n_same > 0:
+        s_el, _, s_tr, _, s_nl, s_mix = guarded(lambda: timed_leg(args.warmup, n_same, False))
+        same = {"steps": n_same, "ms_per_step": s_el / n_same * 1e3, "kernel_ms_pipelined": s_tr / max(1, s_nl),
+                "launch_mix": {"full_grid": s_mix[0], "half_grid": s_mix[1]}}
 
     # ---- second leg (N = 1): isolated launches. With the pipeline on, a launch's event span includes time it shares
     # with its neighbours (it is a latency, and can exceed ms_per_step); the roofline's denominator is the
@@ -280,9 +367,19 @@ def main():
             host_rgb.copy_(rgb8, non_blocking=True)
             torch.cuda.synchronize()
             ts8.append(time.perf_counter() - t0)
-        single = {"frames": args.single_frames, "ms": sum(ts8) / len(ts8) * 1e3, "ms_min": min(ts8) * 1e3,
-                  "ms_radiance": sum(ts) / len(ts) * 1e3}
+        tsn = []
+        for _ in range(args.single_frames):  # ... of a camera the library has not seen: with the tile pass
+            c = fresh_camera()
+            t0 = time.perf_counter()
+            scene.render_device(c, opts, None, rgb8.data_ptr(), stream)
+            host_rgb.copy_(rgb8, non_blocking=True)
+            torch.cuda.synchronize()
+            tsn.append(time.perf_counter() - t0)
+        single = {"frames": args.single_frames, "ms": sum(tsn) / len(tsn) * 1e3, "ms_min": min(tsn) * 1e3,
+                  "ms_same_camera": sum(ts8) / len(ts8) * 1e3, "ms_radiance": sum(ts) / len(ts) * 1e3}
 
+    # the frame whose hash is reported: the configuration's own camera, rendered last (untimed)
+    guarded(lambda: (step(False), fence()))
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -295,7 +392,10 @@ def main():
     else:
         table = scene.primary_cull(cam)  # (debug hook: the table the library computes for this camera)
         tile_pass = {"tiles": int(table.size), "background_only_tiles": int((table >> 31).sum()),
-                     "finished_by": "sky_resolve_kernel (streaming), the rest by trace_megakernel + resolve_kernel"}
+                     "finished_by": "sky_resolve_kernel (streaming), the rest by trace_megakernel + resolve_kernel",
+                     # every timed step renders a camera the library has not seen: primary_cull_kernel + tile_lists_kernel
+                     # run inside the timed region, every step (ms_per_step_same_camera: the leg where they are cached)
+                     "in_timed_region": True, "cameras_in_timed_region": args.steps}
     samples_per_step = W * H * spp
     if emu:
         samples_per_step = rbrt_amd.packed_pixels(W, H, 0, emu) * spp
@@ -381,7 +481,10 @@ def main():
     out = {
         "metric": "Mray-samples/sec (WxHxspp/s) on bunny scene; achieved HBM GB/s vs peak",
         "value": round(value, 2), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step_new_camera": round(elapsed / args.steps * 1e3, 4),  # (= ms_per_step: every timed step has a new camera)
+        "ms_per_step_same_camera": round(same["ms_per_step"], 4) if same else None,
+        "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"example_scene.yaml, {args.triangles}-triangle "
                                f"{'bunny.obj' if real_asset else 'stand-in mesh' if args.mesh == 'smooth' else 'ROUGH stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
@@ -399,13 +502,27 @@ def main():
                    "resolve_kernel_ms": round(resolve_ms / max(1, n_launches), 4) if args.pipeline == 1 else None},
         "roofline": roofline,
     }
+    if same is not None:
+        out["same_camera_leg"] = {"steps": same["steps"], "ms_per_step": round(same["ms_per_step"], 4),
+                                  "value": round(samples_per_step / (same["ms_per_step"] * 1e-3) / 1e6, 2),
+                                  "kernel_ms_pipelined": round(same["kernel_ms_pipelined"], 4), "launch_mix": same["launch_mix"],
+                                  "what": "the same frame rendered over and over: the library keeps the tile pass's lists while camera and "
+                                          "tile partition stay what they were (a fixed view, e.g. progressive refinement); NOT `value`"}
+    if phases is not None:
+        out["phases"] = phases
+        out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                             "library": ("gloo (rehearsal on one GPU through host memory)" if args.rehearse_single_gpu else
+                                         "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version())),
+                             "gather_bytes_per_rank": int(maxn * 4), "timeout_s": args.init_timeout_s}
     if single is not None:
-        out["single_frame"] = {"ms": round(single["ms"], 4), "ms_min": round(single["ms_min"], 4), "frames": single["frames"],
+        out["single_frame"] = {"ms": round(single["ms"], 4), "ms_new_camera": round(single["ms"], 4), "ms_min": round(single["ms_min"], 4),
+                               "ms_same_camera": round(single["ms_same_camera"], 4), "frames": single["frames"],
                                "value": round(samples_per_step / (single["ms"] * 1e-3) / 1e6, 2), "unit": "Mray-samples/s",
                                "ms_with_fp32_radiance_copy": round(single["ms_radiance"], 4),
-                               "what": "one blocking frame as the reference's render_scene returns it: render + quantise on the device + "
-                                       "copy of the RGB8 image to pinned host memory + synchronise (ms_with_fp32_radiance_copy: the same "
-                                       "with the 9.4 MB fp32 radiance copied instead, the figure of rounds 1-2)"}
+                               "what": "one blocking frame of a camera the library has not seen, as the reference's render_scene returns "
+                                       "it: tile pass + render + quantise on the device + copy of the RGB8 image to pinned host memory + "
+                                       "synchronise (ms_same_camera: the tile pass cached; ms_with_fp32_radiance_copy: same camera, the "
+                                       "9.4 MB fp32 radiance copied instead, the figure of rounds 1-2)"}
 
     # ---- CPU baseline (rank 0, N = 1 only): bounded sample of the same workload ---------------------
     cpu_note = ""
@@ -413,18 +530,18 @@ def main():
         from oracle import pyoracle  # the checker, used here only as the timed CPU baseline
         n_threads = args.cpu_threads or len(os.sched_getaffinity(0))  # every core this process may use
         if args.cpu_col_stride < 0:
-            # Default: the WHOLE frame where the host can do it in a few minutes (SURVEY 8(d) times config 2 in full: >= 64
-            # cores), every 8th column otherwise. A 64th of the frame is timed first; if the whole frame would take more
-            # than 5 minutes on this host (cores shared, a slow box), the largest power-of-two fraction that fits is
-            # timed instead and the line says so.
-            args.cpu_col_stride = 1 if n_threads >= 64 else 8
+            # Default: a 64th of the frame's columns is timed first; then the largest power-of-two fraction of the columns
+            # whose estimate fits --cpu-budget-s (120 s) is timed, and the line says which. (Round 3 timed the whole frame
+            # wherever 64 cores were to be had: 287 s of a 293-s run on 256 threads, 13 s short of its own limit.)
+            args.cpu_col_stride = 1
             t0 = time.perf_counter()
             pyoracle.render(cam, host_scene, abi.default_opts(spp=spp, seed=args.seed), n_threads=n_threads, want_rgb8=False, col_stride=64)
             est_full_s = (time.perf_counter() - t0) * 64.0
-            while est_full_s / args.cpu_col_stride > 300.0 and args.cpu_col_stride < 64:
+            while est_full_s / args.cpu_col_stride > args.cpu_budget_s and args.cpu_col_stride < 64:
                 args.cpu_col_stride *= 2
-            if args.cpu_col_stride > 1 and n_threads >= 64:
-                cpu_note = f"; the whole frame was estimated at {est_full_s:.0f} s on this host: a fraction is timed"
+            if args.cpu_col_stride > 1:
+                cpu_note = (f"; the whole frame was estimated at {est_full_s:.0f} s on this host: the largest power-of-two fraction of "
+                            f"the columns that fits {args.cpu_budget_s:.0f} s is timed")
         cols = len(range(0, W, args.cpu_col_stride))
         t0 = time.perf_counter()
         rad, _, cpu_rays = pyoracle.render(cam, host_scene, abi.default_opts(spp=spp, seed=args.seed),

@@ -123,6 +123,7 @@ struct rbrt_hip_scene {
         unsigned long long* d_work_counter = nullptr;
         uint32_t* d_gseq = nullptr;
         uint32_t* d_gstack = nullptr;
+        unsigned long long* d_spread_ring = nullptr;  // the drain's ring of path records (only when spreading is on)
         // the tile pass (kernels.hip primary_cull_kernel + tile_lists_kernel): which of the rank's tiles see only the
         // background. Recomputed on the lane's trace stream when the camera or the tile partition differs from `tile_key`.
         uint32_t* d_tile_cull = nullptr;   // [n_tiles]
@@ -174,6 +175,15 @@ struct rbrt_hip_scene {
     uint32_t primary_cull = 1;    // RBRT_PRIMARY_CULL (0: no tile pass, the trace kernel renders every tile)
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
+    // the end of a launch (megakernel.inl "taper" / "spread")
+    uint32_t taper_chunks = 0;    // RBRT_TAPER_CHUNKS: chunks per wave left in the launch when waves stop filling their pools (0: off)
+    uint32_t taper_live = 64;     // RBRT_TAPER_LIVE: ... beyond this many live paths
+    uint32_t spread_min = 0;      // RBRT_SPREAD_MIN: parked paths a draining wave must hold to give half away (0: off)
+    uint32_t spread_polls = 300;  // RBRT_SPREAD_POLLS: times (3.4 us apart) a wave that ran empty asks for paths before it exits
+    uint32_t spread_pollers = 128;  // RBRT_SPREAD_POLLERS: waves per XCD that may ask at a time
+    uint32_t spread_tail = 4;     // RBRT_SPREAD_TAIL: giving starts when 1/this of an XCD's waves still work (0: at once)
+    uint32_t spread_overlap = 1;  // RBRT_SPREAD_OVERLAP: 0 = launches issued while another is running do not spread
+    uint32_t spread_token = 0;    // tag of the last launch's ring records
     // stats / timing
     rbrt_hip_stats_t stats{};
     bool stats_pending = false;
@@ -281,7 +291,7 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
     while (s->lanes.size() < depth) {
         rbrt_hip_scene::Lane L;
         void* p = nullptr;
-        const size_t counter_bytes = sizeof(unsigned long long) * kWorkShards * kWorkCounterStride;
+        const size_t counter_bytes = sizeof(unsigned long long) * kWorkCounterWords;  // work counters + the spread ring's control line
         HIP_TRY(hipMalloc(&p, counter_bytes));
         s->allocs.push_back(p);
         L.d_work_counter = static_cast<unsigned long long*>(p);
@@ -293,6 +303,13 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
         s->allocs.push_back(p);
         L.d_gstack = static_cast<uint32_t*>(p);
+        if (s->spread_min != 0u) {  // (tags of an earlier life of this memory must not look like a launch's: cleared once)
+            const size_t ring_bytes = size_t(kWorkShards) * kSpreadRingRecords * kSpreadGranules * sizeof(unsigned long long);
+            HIP_TRY(hipMalloc(&p, ring_bytes));
+            s->allocs.push_back(p);
+            L.d_spread_ring = static_cast<unsigned long long*>(p);
+            HIP_TRY(hipMemset(p, 0, ring_bytes));
+        }
         // the lane is recorded before its stream and events exist, so that a failure below leaves them to
         // rbrt_hip_scene_destroy instead of leaking them (a lane without a stream is never selected: the caller
         // gets the error)
@@ -506,9 +523,14 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         mats[k].param = m.param;
         mats[k].kind = m.kind;
     };
+    // A scene WITHOUT triangle elements is tested by the kernels' sphere-only loop, where element e IS device sphere e (no
+    // element table is uploaded): the device array is therefore laid out in Scene::elements order, so that a permuted
+    // `element_order` gives every sphere its own material, object id and place in a tie (scene.rs:23-31). With triangle
+    // elements the table `elems` names the spheres by their position in the caller's array, which is kept.
     for (uint32_t i = 0; i < scene->n_spheres; ++i) {
-        for (int c = 0; c < 3; ++c) spheres[i].center[c] = scene->spheres[i].center[c];
-        spheres[i].radius = scene->spheres[i].radius;
+        const uint32_t src = scene->n_triangles == 0 ? elems[i] : i;
+        for (int c = 0; c < 3; ++c) spheres[i].center[c] = scene->spheres[src].center[c];
+        spheres[i].radius = scene->spheres[src].radius;
     }
     for (uint32_t i = 0; i < scene->n_triangles; ++i) {  // BasicTriangle::new (triangle.rs:19-28): edges and normal, f32, unfused
         const rbrt_triangle_t& t = scene->triangles[i];
@@ -646,7 +668,11 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             lab_u32("RBRT_SHADE_ROUNDS", 1, kMaxShadeRounds, s->shade_rounds, err) &&
             lab_u32("RBRT_SHADE_CONT_MIN", 1, 64, s->shade_cont_min, err) && lab_u32("RBRT_PIPELINE", 0, kMaxPipeline, s->pipeline, err) &&
             lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err) && lab_u32("RBRT_PRIMARY_CULL", 0, 1, s->primary_cull, err) &&
-            lab_u32("RBRT_TILE_ORDER", 0, 2, s->tile_order, err) && lab_u32("RBRT_TILE_CLASSES", 0, 3, s->tile_classes, err);
+            lab_u32("RBRT_TILE_ORDER", 0, 2, s->tile_order, err) && lab_u32("RBRT_TILE_CLASSES", 0, 3, s->tile_classes, err) &&
+            lab_u32("RBRT_TAPER_CHUNKS", 0, 1024, s->taper_chunks, err) && lab_u32("RBRT_TAPER_LIVE", 1, 256, s->taper_live, err) &&
+            lab_u32("RBRT_SPREAD_MIN", 0, 256, s->spread_min, err) && lab_u32("RBRT_SPREAD_POLLS", 0, 1 << 20, s->spread_polls, err) &&
+            lab_u32("RBRT_SPREAD_OVERLAP", 0, 1, s->spread_overlap, err) && lab_u32("RBRT_SPREAD_POLLERS", 0, 4096, s->spread_pollers, err) &&
+            lab_u32("RBRT_SPREAD_TAIL", 0, 64, s->spread_tail, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
         if ((stripes & (stripes - 1u)) != 0u || (stripes_overlap != kStripesAuto && (stripes_overlap & (stripes_overlap - 1u)) != 0u))  // the kernel shifts
             return bail(fail(RBRT_ERR_INVALID_ARG, "lab knob RBRT_WORK_STRIPES / RBRT_WORK_STRIPES_OVERLAP must be 0 or a power of two"));
@@ -809,6 +835,9 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.work_stripes = s->work_stripes;  // (per launch: set where the launch's size is known)
     P.shade_rounds = s->shade_rounds;
     P.shade_cont_min = s->shade_cont_min;
+    P.taper_chunks = s->taper_chunks, P.taper_live = s->taper_live;
+    P.spread_min = 0u, P.spread_polls = s->spread_polls, P.spread_token = 0u, P.spread_ctl = nullptr, P.spread_ring = nullptr;
+    P.spread_pollers = s->spread_pollers, P.spread_tail = s->spread_tail;
 
     ResolveParams R;
     std::memset(&R, 0, sizeof(R));
@@ -913,6 +942,16 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.work_counter = L.d_work_counter;
         P.gseq = L.d_gseq;
         P.gstack = L.d_gstack;
+        if (L.d_spread_ring && (s->spread_overlap != 0u || !overlapped)) {
+            // (the control line sits behind the work counters and is zeroed with them; a token is never 0 and is not used
+            // again before 2^32 - 1 launches of this scene have passed)
+            if (++s->spread_token == 0u) s->spread_token = 1u;
+            P.spread_min = s->spread_min, P.spread_token = s->spread_token;
+            P.spread_ctl = L.d_work_counter + kWorkShards * kWorkCounterStride;
+            P.spread_ring = L.d_spread_ring;
+        } else {
+            P.spread_min = 0u, P.spread_ctl = nullptr, P.spread_ring = nullptr;
+        }
         P.tile_cull = tile_pass ? L.d_tile_cull : nullptr;
         P.tile_lists = tile_pass ? L.d_tile_lists : nullptr;
         P.tile_list_mode = s->tile_classes;

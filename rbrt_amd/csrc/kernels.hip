@@ -673,8 +673,8 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) 
     const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
     // the trace launch this resolves has ended: its work counters are reset for the lane's next launch (which
     // waits for this kernel), saving a memset launch that would have to queue behind the resident megakernels
-    static_assert(kWorkShards * kWorkCounterStride <= kBlock, "one thread per counter word");
-    if (blockIdx.x == 0 && threadIdx.x < kWorkShards * kWorkCounterStride) R.work_counter[threadIdx.x] = 0ull;
+    static_assert(kWorkCounterWords <= kBlock, "one thread per counter word");
+    if (blockIdx.x == 0 && threadIdx.x < kWorkCounterWords) R.work_counter[threadIdx.x] = 0ull;  // (the spread ring's control line too)
     if (i >= npix) return;
     const uint32_t p = uint32_t(i & 63u);
     const uint32_t tile_local = R.tile_lists ? R.tile_lists[kTileListHeader + (i >> 6)] : uint32_t(i >> 6);
@@ -982,7 +982,10 @@ __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParam
         const uint32_t word = P.tile_cull[tl * P.tile_world + P.tile_rank];
         if (word >> 31) return 2u;
         if (P.tile_list_mode == 0u) return 0u;
-        const bool light = ((word >> 24) & me_mask) == me_mask && __popc(~word & el_mask) <= 1 && P.n_spheres <= 24u && P.n_meshes <= 7u;
+        // (the table's element bits are indexed by position in Scene::elements and are only ever set for spheres: with
+        // BasicTriangle elements in the scene, which are never culled, no tile is called light)
+        const bool light = ((word >> 24) & me_mask) == me_mask && __popc(~word & el_mask) <= 1 && P.n_spheres <= 24u && P.n_meshes <= 7u &&
+                           P.n_elem_tris == 0u;
         return light ? 1u : 0u;
     };
     uint32_t mine[2] = {0u, 0u};  // heavy / light tiles of this run (both go to the trace kernel)

@@ -63,16 +63,17 @@ void le32(std::vector<uint8_t>& v, uint32_t x) { le16(v, x & 0xFFFFu), le16(v, x
 
 // 24-bit uncompressed BMP (BITMAPINFOHEADER, bottom-up, BGR, rows padded to 4 bytes)
 std::vector<uint8_t> encode_bmp(const uint8_t* rgb, uint32_t w, uint32_t h) {
-    const uint32_t row = (w * 3u + 3u) & ~3u;
+    const uint64_t row = (uint64_t(w) * 3u + 3u) & ~uint64_t(3);
+    if (54u + row * h > 0xFFFFFFFFull || w > 0x7FFFFFFFu || h > 0x7FFFFFFFu) throw Error("bmp: image too large for the format's 32-bit sizes");
     std::vector<uint8_t> o = {'B', 'M'};
-    le32(o, 54u + row * h), le32(o, 0), le32(o, 54);
-    le32(o, 40), le32(o, w), le32(o, h), le16(o, 1), le16(o, 24), le32(o, 0), le32(o, row * h), le32(o, 2835), le32(o, 2835), le32(o, 0), le32(o, 0);
+    le32(o, uint32_t(54u + row * h)), le32(o, 0), le32(o, 54);
+    le32(o, 40), le32(o, w), le32(o, h), le16(o, 1), le16(o, 24), le32(o, 0), le32(o, uint32_t(row * h)), le32(o, 2835), le32(o, 2835), le32(o, 0), le32(o, 0);
     for (uint32_t y = h; y-- > 0;) {
         for (uint32_t x = 0; x < w; ++x) {
             const uint8_t* p = rgb + (size_t(y) * w + x) * 3;
             o.push_back(p[2]), o.push_back(p[1]), o.push_back(p[0]);
         }
-        for (uint32_t k = w * 3u; k < row; ++k) o.push_back(0);
+        for (uint64_t k = uint64_t(w) * 3u; k < row; ++k) o.push_back(0);
     }
     return o;
 }
@@ -86,7 +87,9 @@ std::vector<uint8_t> encode_tga(const uint8_t* rgb, uint32_t w, uint32_t h) {
 }
 // baseline TIFF: one uncompressed RGB strip, little-endian
 std::vector<uint8_t> encode_tiff(const uint8_t* rgb, uint32_t w, uint32_t h) {
-    const uint32_t n = w * h * 3u;
+    const uint64_t n64 = uint64_t(w) * h * 3u;
+    if (n64 + 256u > 0xFFFFFFFFull) throw Error("tiff: image too large for the format's 32-bit offsets");
+    const uint32_t n = uint32_t(n64);
     std::vector<uint8_t> o = {'I', 'I', 42, 0};
     le32(o, 8u + n + (n & 1u));               // IFD after the pixel data
     o.insert(o.end(), rgb, rgb + n);

@@ -158,9 +158,16 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     if (world > n_dev && !cfg.oversubscribe)
         throw Error("requested " + std::to_string(world) + " GPUs, " + std::to_string(n_dev) + " present");
     const auto device_of = [&](int rank) { return cfg.oversubscribe ? rank % n_dev : rank; };
-    const bool use_rccl = world > 1 && cfg.gather == "rccl";
-    if (use_rccl && world > n_dev)
-        throw Error("--gather rccl needs one GPU per rank (RCCL cannot put two ranks on one device); use --gather host with --oversubscribe");
+    // --gather rccl is a request, not a condition: whatever keeps RCCL from doing the gather -- the library is not
+    // there, two ranks share a device, the communicators do not come up, the exchange itself fails -- sends the ranks
+    // to the host gather in the same process (their tiles are still in their own memories), and the run says so on
+    // stderr and in --report. `rccl_note` is the reason, once there is one.
+    bool use_rccl = world > 1 && cfg.gather == "rccl";
+    std::string rccl_note;
+    if (use_rccl && world > n_dev) {
+        rccl_note = "--gather rccl needs one GPU per rank (RCCL cannot put two ranks on one device)";
+        use_rccl = false;
+    }
 
     // samples per pass: what was asked for, else passes of about 2^31 path samples each (a second or so of one GPU's
     // share), so that long renders report progress and can checkpoint; a short render is one pass
@@ -212,14 +219,27 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     }
 
     // ---- RCCL communicators (one process, one communicator per GPU) -----------------------------------------------
-    const RcclApi* rccl = use_rccl ? &RcclApi::get() : nullptr;
+    const RcclApi* rccl = nullptr;
     std::vector<ncclComm_t> comms(world, nullptr);
     if (use_rccl) {
-        std::vector<int> devs(world);
-        for (int r = 0; r < world; ++r) devs[r] = device_of(r);
-        const ncclResult_t rc = rccl->CommInitAll(comms.data(), world, devs.data());
-        if (rc != ncclSuccess) throw Error(std::string("ncclCommInitAll: ") + rccl->GetErrorString(rc));
+        try {
+            rccl = &RcclApi::get();
+            std::vector<int> devs(world);
+            for (int r = 0; r < world; ++r) devs[r] = device_of(r);
+            const ncclResult_t rc = rccl->CommInitAll(comms.data(), world, devs.data());
+            if (rc != ncclSuccess) rccl_note = std::string("ncclCommInitAll: ") + rccl->GetErrorString(rc);
+        } catch (const Error& e) {
+            rccl_note = e.what();
+        }
+        if (!rccl_note.empty()) {
+            for (ncclComm_t& cm : comms) {
+                if (cm && rccl) (void)rccl->CommAbort(cm);
+                cm = nullptr;
+            }
+            use_rccl = false;
+        }
     }
+    if (!rccl_note.empty()) std::fprintf(stderr, "warning: %s; gathering through host memory instead\n", rccl_note.c_str());
 
     // Errors: a rank records its first failure under the mutex and raises the counter. Ranks never have to agree on
     // whether to go on rendering (a failed rank keeps meeting the barriers, idle); they DO have to agree on entering
@@ -227,6 +247,7 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     std::mutex err_mutex;
     std::vector<std::string> errors(world);
     std::atomic<int> n_failed{0};
+    std::atomic<int> rccl_failed{0};  // ranks whose part of the RCCL exchange failed: not a failure of the run (host gather instead)
     std::vector<std::vector<float>> ckpt_acc(world);  // host copies of the running sums for the checkpoint writer
     Barrier barrier(world);
     float* d_slots = nullptr;  // rank 0, RCCL gather: world equal-size slots of packed tiles
@@ -235,6 +256,7 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     rep.n_gpus = world;
     rep.pass_spp = pass_spp;
     rep.gather = world > 1 ? (use_rccl ? "rccl" : "host") : "none";
+    if (!rccl_note.empty()) rep.gather = "host (rccl was asked for: " + rccl_note + ")";
     std::vector<double> t_setup(world, 0.0), t_render(world, 0.0), t_gather(world, 0.0);
 
     auto worker = [&](int rank) {
@@ -335,6 +357,30 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
         t_render[rank] = seconds_since(t_passes);
         // ---- gather ----
         const auto t_g = std::chrono::steady_clock::now();
+        // --gather host: every rank's tiles over its own PCIe link, merged on the host (also where a failed RCCL gather ends)
+        auto host_gather = [&]() {
+            if (failed || !npix) return;
+            std::vector<float> hr(npix * 3);
+            if (hip_ok(hipMemcpy(hr.data(), d_rad, hr.size() * sizeof(float), hipMemcpyDeviceToHost), "download")) {
+                const uint32_t tiles_x = (img.width + RBRT_TILE - 1) / RBRT_TILE;
+                for (size_t tl = 0; tl < npix / 64; ++tl) {  // (ranks write disjoint pixels of the shared image)
+                    const uint32_t tile = uint32_t(tl) * uint32_t(world) + uint32_t(rank);
+                    const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
+                    for (uint32_t p = 0; p < 64; ++p) {
+                        const uint32_t row = ty * RBRT_TILE + p / 8, col = tx * RBRT_TILE + p % 8;
+                        if (row >= img.height || col >= img.width) continue;
+                        const size_t src = (tl * 64 + p) * 3, dst = (size_t(row) * img.width + col) * 3;
+                        for (int k = 0; k < 3; ++k) {  // lib.rs:116-122 on the host for this path
+                            const float v = hr[src + k];
+                            img.radiance[dst + k] = v;
+                            const float q = std::sqrt(v) * 256.0f;
+                            img.rgb[dst + k] = !(q == q) || q <= 0.0f ? 0 : q >= 255.0f ? 255 : uint8_t(q);
+                        }
+                    }
+                }
+            }
+        };
+
         if (world == 1) {
             if (!failed && npix) {
                 hip_ok(hipMemcpy(img.radiance.data(), d_rad, n * sizeof(float), hipMemcpyDeviceToHost), "download");
@@ -360,8 +406,15 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
                     rc = rccl->Send(d_rad, npix * 3, ncclFloat, 0, comms[rank], stream);
                 }
                 const ncclResult_t rc2 = rccl->GroupEnd();
-                if (rc != ncclSuccess || rc2 != ncclSuccess) fail(std::string("RCCL gather: ") + rccl->GetErrorString(rc != ncclSuccess ? rc : rc2));
-                if (rank == 0 && !failed && copied) {
+                bool rccl_bad = false;  // this rank's part of the exchange failed
+                auto rccl_fail = [&](const std::string& m) {
+                    rccl_bad = true;
+                    std::lock_guard<std::mutex> lk(err_mutex);
+                    if (rccl_note.empty()) rccl_note = m;
+                    rccl_failed.fetch_add(1);
+                };
+                if (rc != ncclSuccess || rc2 != ncclSuccess) rccl_fail(std::string("RCCL gather: ") + rccl->GetErrorString(rc != ncclSuccess ? rc : rc2));
+                if (rank == 0 && !failed && !rccl_bad && copied) {
                     if (rbrt_hip_unpack_tiles_strided(dev, stream, d_slots, img.width, img.height, uint32_t(world), slot_pixels, d_img, d_rgb) != RBRT_OK)
                         fail(rbrt_hip_last_error());
                 }
@@ -374,39 +427,28 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
                         hip_ok(q, "gather");
                         break;
                     }
-                    if (n_failed.load() != 0) {
-                        fail("RCCL gather abandoned: another rank failed");
+                    if (n_failed.load() != 0 || rccl_failed.load() != 0) {
+                        if (!rccl_bad) rccl_fail("RCCL gather abandoned: another rank's part of it failed");
                         (void)rccl->CommAbort(comms[rank]);
                         comms[rank] = nullptr;
                         break;
                     }
                     std::this_thread::sleep_for(std::chrono::microseconds(50));
                 }
-                if (rank == 0 && !failed) {
+                // Did the exchange work for everyone? Again one decision between two barriers. If not, the tiles are still
+                // where they were rendered: every rank takes the host path, in this same process.
+                barrier.wait();
+                const bool fell_back = rccl_failed.load() != 0;
+                barrier.wait();
+                if (fell_back) {
+                    host_gather();
+                } else if (rank == 0 && !failed) {
                     hip_ok(hipMemcpy(img.radiance.data(), d_img, n * sizeof(float), hipMemcpyDeviceToHost), "download");
                     hip_ok(hipMemcpy(img.rgb.data(), d_rgb, n, hipMemcpyDeviceToHost), "download");
                 }
             }
-        } else if (!failed && npix) {  // --gather host: every rank's tiles over its own PCIe link, merged on the host
-            std::vector<float> hr(npix * 3);
-            if (hip_ok(hipMemcpy(hr.data(), d_rad, hr.size() * sizeof(float), hipMemcpyDeviceToHost), "download")) {
-                const uint32_t tiles_x = (img.width + RBRT_TILE - 1) / RBRT_TILE;
-                for (size_t tl = 0; tl < npix / 64; ++tl) {  // (ranks write disjoint pixels of the shared image)
-                    const uint32_t tile = uint32_t(tl) * uint32_t(world) + uint32_t(rank);
-                    const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
-                    for (uint32_t p = 0; p < 64; ++p) {
-                        const uint32_t row = ty * RBRT_TILE + p / 8, col = tx * RBRT_TILE + p % 8;
-                        if (row >= img.height || col >= img.width) continue;
-                        const size_t src = (tl * 64 + p) * 3, dst = (size_t(row) * img.width + col) * 3;
-                        for (int k = 0; k < 3; ++k) {  // lib.rs:116-122 on the host for this path
-                            const float v = hr[src + k];
-                            img.radiance[dst + k] = v;
-                            const float q = std::sqrt(v) * 256.0f;
-                            img.rgb[dst + k] = !(q == q) || q <= 0.0f ? 0 : q >= 255.0f ? 255 : uint8_t(q);
-                        }
-                    }
-                }
-            }
+        } else {
+            host_gather();
         }
         t_gather[rank] = seconds_since(t_g);
         if (d_acc) (void)hipFree(d_acc);
@@ -423,6 +465,10 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     for (auto& t : threads) t.join();
     for (ncclComm_t cm : comms)
         if (cm) (void)rccl->CommDestroy(cm);
+    if (rccl_failed.load() != 0) {
+        std::fprintf(stderr, "warning: %s; gathered through host memory instead\n", rccl_note.c_str());
+        rep.gather = "host (rccl was asked for: " + rccl_note + ")";
+    }
     for (int r = 0; r < world; ++r)
         if (!errors[r].empty()) throw Error("GPU " + std::to_string(device_of(r)) + (cfg.oversubscribe ? " (rank " + std::to_string(r) + ")" : "") + ": " + errors[r]);
     if (!cfg.checkpoint_path.empty()) std::remove(cfg.checkpoint_path.c_str());  // (only reached when the render is complete)

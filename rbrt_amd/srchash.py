@@ -11,7 +11,22 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 KERNEL_SOURCES = ("rbrt_amd/csrc/kernels.hip", "rbrt_amd/csrc/megakernel.inl", "rbrt_amd/csrc/device_types.h",
-                  "rbrt_amd/csrc/bvh.cpp", "rbrt_amd/csrc/api.cpp")
+                  "rbrt_amd/csrc/bvh.cpp", "rbrt_amd/csrc/bvh.h", "rbrt_amd/csrc/bvh_device.hip", "rbrt_amd/csrc/bvh_device.h",
+                  "rbrt_amd/csrc/api.cpp", "include/rbrt_hip.h", "include/rbrt_hip_debug.h")
+
+
+def hipflags() -> str:
+    """The compiler flags of the product library, from the one place that has them (the Makefile's HIPFLAGS; the A/B and
+    resource tools read them through `make -s print-hipflags`): a flag changes the instruction mix like a source edit."""
+    lines, on = [], False
+    for line in (ROOT / "Makefile").read_text().splitlines():
+        if line.startswith("HIPFLAGS"):
+            on = True
+        if on:
+            lines.append(line.rstrip("\\").strip())
+            if not line.rstrip().endswith("\\"):
+                break
+    return " ".join(" ".join(lines).split())
 
 
 def kernel_source_sha256() -> str:
@@ -19,4 +34,5 @@ def kernel_source_sha256() -> str:
     for rel in KERNEL_SOURCES:
         h.update(rel.encode() + b"\0")
         h.update((ROOT / rel).read_bytes())
+    h.update(b"HIPFLAGS\0" + hipflags().encode())
     return h.hexdigest()[:16]

@@ -141,6 +141,39 @@ def test_images_with_and_without_an_explicit_order(hip, oracle):
         assert np.array_equal(bits(got), bits(exp)) and np.array_equal(got8, exp8)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_mesh", [False, True])
+def test_a_permuted_order_of_spheres_alone(hip, oracle, with_mesh):
+    """A scene WITHOUT triangle elements whose `element_order` is not the identity (round-3 review: the kernels' sphere-only
+    loop takes element e for device sphere e, while the material table follows the order). Two COINCIDENT spheres of different
+    materials in front of the example scene: scene.rs:27's strict `<` keeps the element tested first, so order [1, 0, ...]
+    must show the mirror where [0, 1, ...] shows the red ball; object ids, materials and images equal the oracle's."""
+    red, mirror = abi.material(abi.MAT_LAMBERTIAN, (0.9, 0.1, 0.1)), abi.material(abi.MAT_METAL, (0.9, 0.9, 0.9), 0.0)
+    spheres = [((0.5, 1.0, -6.0), 1.0, red), ((0.5, 1.0, -6.0), 1.0, mirror)] + list(scenes.EXAMPLE_SPHERES)
+    meshes = [scenes.standin_mesh(oracle, 803, **scenes.EXAMPLE_MESH)] if with_mesh else []
+    cam = scenes.camera(oracle, 96, 72)
+    rng = np.random.default_rng(4)
+    o = np.float32([0.0, 3.0, 4.0]) + rng.normal(size=(2000, 3)).astype(np.float32) * 0.5
+    d = np.float32([0.5, 1.0, -6.0]) + rng.uniform(-4, 4, (2000, 3)).astype(np.float32) - o
+    rays = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], 1).astype(np.float32)
+    imgs = []
+    for order in (None, [1, 0, 2, 3, 4, 5], [5, 4, 1, 3, 0, 2]):
+        sc = abi.SceneData(spheres=spheres, meshes=meshes, element_order=order)
+        got, _ = hip.render_scene(cam, 6, sc, seed=2)
+        exp, _, _ = oracle.render(cam, sc, abi.default_opts(spp=6, seed=2))
+        assert np.array_equal(bits(got), bits(exp)), order
+        imgs.append(got)
+        et, eobj, etri, edist = oracle.trace_rays(sc, rays)
+        with hip.HipScene(sc) as hs:
+            t, obj, tri, dist = hs.trace_rays(rays)
+        assert np.array_equal(obj, eobj) and np.array_equal(bits(t), bits(et)) and np.array_equal(bits(dist), bits(edist)), order
+        # object ids are positions in Scene::elements: of the coincident pair, the one tested first takes every hit
+        pos = [(order or list(range(6))).index(k) for k in (0, 1)]
+        assert (obj == min(pos)).sum() > 50 and (obj == max(pos)).sum() == 0, (order, np.bincount(obj[obj >= 0]))
+    # (the second and third order both test the mirror first: the same image; the default order shows the red ball)
+    assert not np.array_equal(imgs[0], imgs[1]) and np.array_equal(bits(imgs[1]), bits(imgs[2]))
+
+
 def test_a_malformed_element_order_is_refused():
     lib = abi.load_hip()
     h = C.c_void_p()

@@ -247,6 +247,50 @@ def test_shared_traversals_do_not_change_the_image(hip, oracle, monkeypatch, env
     assert (given > 0) == sharing, (env, given)
 
 
+@pytest.mark.parametrize("env", [
+    {"RBRT_TAPER_CHUNKS": "2"},
+    {"RBRT_TAPER_CHUNKS": "16", "RBRT_TAPER_LIVE": "8", "RBRT_WAVES_PER_CU": "2"},
+    {"RBRT_SPREAD_MIN": "2", "RBRT_SPREAD_TAIL": "0", "RBRT_SPREAD_POLLS": "300", "RBRT_WAVES_PER_CU": "2"},
+    {"RBRT_SPREAD_MIN": "2", "RBRT_SPREAD_TAIL": "0", "RBRT_SPREAD_POLLS": "0"},
+    {"RBRT_SPREAD_MIN": "2", "RBRT_SPREAD_TAIL": "0", "RBRT_SPREAD_POLLERS": "1", "RBRT_WAVES_PER_CU": "2"},
+    {"RBRT_SPREAD_MIN": "24", "RBRT_SPREAD_TAIL": "2", "RBRT_SPREAD_POLLS": "64", "RBRT_WAVES_PER_CU": "1", "RBRT_SHARE_IDLE": "0"},
+    {"RBRT_SPREAD_MIN": "4", "RBRT_SPREAD_TAIL": "0", "RBRT_SPREAD_POLLS": "100", "RBRT_TAPER_CHUNKS": "4", "RBRT_TAPER_LIVE": "32",
+     "RBRT_WAVES_PER_CU": "4"},
+    {"RBRT_SPREAD_MIN": "16"},
+])
+def test_taper_and_spread_at_the_end_of_a_launch_do_not_change_the_image(hip, oracle, monkeypatch, env):
+    """The end of a launch (megakernel.inl "taper", "spread"): waves stop filling their pools when the work items run low,
+    and a wave that has run empty takes parked paths of a wave that still holds many, through a ring of records in global
+    memory. Who finishes a path cannot change the image (a path owns its RNG stream and its sample slot); a record that
+    got lost would leave its sample poisoned (conftest: NaN) and fail the check. Small grids (RBRT_WAVES_PER_CU) give every
+    wave a bulk phase and a drain on a small image; the scene has metal and diffuse chains longer than the four bounce
+    ids a path keeps in its slot, so records carry their overflow words too. Streams of frames reuse the ring."""
+    import torch
+    cam = scenes.camera(oracle, 160, 120)
+    sc = scenes.example_scene(oracle, 3000)
+    seeds = (9, 10, 11, 12)
+    exp = [oracle.render(cam, sc, abi.default_opts(spp=6, seed=sd))[0] for sd in seeds]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    outs = [torch.empty((120, 160, 3), dtype=torch.float32, device="cuda") for _ in seeds]
+    with hip.HipScene(sc) as hs:
+        for sd, out in zip(seeds, outs):  # a stream of frames: overlapping launches, the ring and its tokens reused
+            hs.render_device(cam, abi.default_opts(spp=6, seed=sd), out.data_ptr())
+        torch.cuda.synchronize()
+        for sd, out, e in zip(seeds, outs, exp):
+            assert_same_image(out.cpu().numpy(), e, f"{env} seed {sd}")
+        hs.render_device(cam, abi.default_opts(spp=6, seed=9, flags=abi.FLAG_COLLECT_STATS), outs[0].data_ptr())
+        torch.cuda.synchronize()
+        assert_same_image(outs[0].cpu().numpy(), exp[0], f"{env} (counting build)")
+        d = hs.debug_counters()
+        hs.check()
+    assert d["spread_given"] == d["spread_taken"], d  # nothing is left in the ring
+    if "RBRT_TAPER_CHUNKS" in env:
+        assert d["tapered_waves"] > 0, d
+    if env.get("RBRT_SPREAD_MIN") in ("2", "4") and env.get("RBRT_SPREAD_POLLERS") != "1":
+        assert d["spread_given"] > 0, d
+
+
 def test_streamed_and_blocking_frames_interleaved(hip, oracle):
     """The launch policy looks at what is in flight (api.cpp grid_for: half the wave slots for a launch issued while
     another is running, all of them for one that finds the GPU idle, the first launch after a pause still issued as

@@ -261,3 +261,103 @@ def test_tile_pass_switched_off_gives_the_same_image(hip, oracle, monkeypatch):
         hs.render_device(cam, abi.default_opts(spp=4, seed=3, flags=abi.FLAG_COLLECT_STATS), out.data_ptr())
         assert hs.stats()["rays"] == rays
         assert np.array_equal(out.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
+# ---- fuzz: random cameras over random scenes (round-3 review: the table's promises were checked on 8 + 3 hand-picked cameras) ----
+N_FUZZ = int(__import__("os").environ.get("RBRT_FUZZ_CAMERAS", "60"))
+
+
+def _log_uniform(rng, lo, hi):
+    return float(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+
+
+def _unit(rng):
+    v = rng.normal(size=3)
+    return v / np.linalg.norm(v)
+
+
+def fuzz_scene(oracle, rng):
+    """0-8 spheres with radii from 0.01 to 1000 (log-uniform; a ground sphere in two scenes of three), 0-3 small meshes."""
+    kinds = [abi.MAT_LAMBERTIAN, abi.MAT_METAL, abi.MAT_DIELECTRIC]
+
+    def rand_mat():
+        k = kinds[int(rng.integers(3))]
+        return abi.material(k, tuple(rng.uniform(0.05, 0.95, 3)), float(rng.uniform(0.0, 0.6) if k == abi.MAT_METAL else rng.uniform(0.3, 2.2)))
+    spheres = [((0.0, -1000.0, -5.0), 1000.0, rand_mat())] if rng.random() < 0.67 else []
+    for _ in range(int(rng.integers(0, 9))):
+        r = _log_uniform(rng, 0.01, 1000.0) if rng.random() < 0.4 else float(rng.uniform(0.2, 3.0))
+        c = rng.uniform(-8, 8, 3) + np.array([0.0, 2.0, -10.0]) + _unit(rng) * (r if r > 20.0 else 0.0)  # (a huge one is pushed away)
+        spheres.append((tuple(float(x) for x in c), r, rand_mat()))
+    meshes = []
+    for _ in range(int(rng.integers(0, 4))):
+        n = int(rng.integers(8, 500))
+        if rng.random() < 0.5:
+            tri = scenes.random_soup(rng, n, extent=float(rng.uniform(0.5, 3.0)), size=float(rng.uniform(0.05, 1.0)))
+            meshes.append(oracle.mesh_prep(tri, float(rng.uniform(0.5, 2.0)), tuple(rng.uniform(-1, 1, 3)),
+                                           tuple(rng.uniform(-4, 4, 3) + np.array([0, 1.5, -9])), rand_mat()))
+        else:
+            meshes.append(scenes.standin_mesh(oracle, n + 50, float(rng.uniform(15, 60)), tuple(rng.uniform(-5, 5, 3) + np.array([0, 0, -10])),
+                                              tuple(rng.uniform(-1, 1, 3)), rand_mat()))
+    if not spheres and not meshes:
+        spheres.append(((0.0, 1.0, -8.0), 1.0, rand_mat()))
+    return abi.SceneData(spheres=spheres, meshes=meshes)
+
+
+def fuzz_camera(oracle, rng, sc, w, h):
+    """A camera where the table's margins are thinnest: inside a sphere, ON its surface, within 1e-3 r of it either side, low
+    over the ground sphere looking along its horizon, inside or right behind a mesh's box -- or anywhere; `look_at` and `up`
+    random and not orthogonal to each other (cam.rs:30-33, 55 takes whatever it is given), focal length 4-2000 mm."""
+    mode = int(rng.integers(0, 8))
+    pos = rng.uniform(-12, 12, 3) + np.array([0.0, 3.0, -4.0])
+    look = _unit(rng)
+    if sc.spheres and mode in (1, 2, 3, 4):
+        c, r, _ = sc.spheres[int(rng.integers(len(sc.spheres)))]
+        c = np.array(c, np.float64)
+        u = _unit(rng)
+        if mode == 1:    # inside
+            pos = c + u * r * rng.uniform(0.0, 0.999)
+        elif mode == 2:  # on the surface, to float precision
+            pos = (np.asarray(c, f32) + (u * r).astype(f32)).astype(np.float64)
+        elif mode == 3:  # a thousandth of the radius off the surface, either side
+            pos = c + u * r * (1.0 + rng.choice([-1.0, 1.0]) * rng.uniform(1e-6, 1e-3))
+        else:            # just above it, looking along its horizon (a little up or down)
+            pos = c + u * r * (1.0 + _log_uniform(rng, 1e-5, 1e-1))
+            t = np.cross(u, _unit(rng))
+            look = t / np.linalg.norm(t) + u * rng.uniform(-0.05, 0.05)
+        if mode != 4 and rng.random() < 0.5:
+            look = (c - pos) / max(1e-9, np.linalg.norm(c - pos)) + _unit(rng) * rng.uniform(0.0, 1.5)  # towards the centre, roughly
+    elif sc.meshes and mode in (5, 6):
+        md = sc.meshes[int(rng.integers(len(sc.meshes)))]
+        lo, hi = md.bbox_lo.astype(np.float64), md.bbox_hi.astype(np.float64)
+        if mode == 5:    # inside the box
+            pos = lo + (hi - lo) * rng.uniform(0.0, 1.0, 3)
+        else:            # behind it: the box is at the camera's back, or grazed sideways
+            ctr, half = 0.5 * (lo + hi), 0.5 * np.linalg.norm(hi - lo)
+            u = _unit(rng)
+            pos = ctr + u * half * rng.uniform(1.0, 3.0)
+            look = u + _unit(rng) * rng.uniform(0.0, 1.2)
+    look = look / np.linalg.norm(look)
+    up = _unit(rng)
+    while abs(float(np.dot(up, look))) > 0.95:  # (not parallel: a degenerate camera is another test's subject)
+        up = _unit(rng)
+    return oracle.camera_new(tuple(float(x) for x in pos), tuple(float(x) for x in look), tuple(float(x) for x in up), h, w,
+                             _log_uniform(rng, 4.0, 2000.0))
+
+
+@pytest.mark.parametrize("k", range(N_FUZZ))
+def test_fuzzed_cameras_no_camera_ray_passes_a_culled_test(hip, oracle, k):
+    """RBRT_FUZZ_CAMERAS (default 60) random cameras over random scenes through check_table: every bit the table sets is
+    checked against the oracle's routines over the tile's rays, as for the hand-picked cameras above. Every third case also
+    renders the whole image through the tile pass and compares it with the oracle's, bit for bit."""
+    rng = np.random.default_rng(77000 + k)
+    sc = fuzz_scene(oracle, rng)
+    w, h = int(rng.integers(9, 301)), int(rng.integers(9, 201))
+    cam = fuzz_camera(oracle, rng, sc, w, h)
+    # (the camera's far limit is the render's max_dist; the reference's 2000 most of the time)
+    table, _ = check_table(hip, oracle, cam, sc, rng, full_scene_jitters=4)
+    if k % 3 == 0:
+        spp = int(rng.integers(1, 4))
+        exp, exp8, rays = oracle.render(cam, sc, abi.default_opts(spp=spp, seed=k, max_depth=12))
+        got, got8 = hip.render_scene(cam, spp, sc, seed=k, max_depth=12)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (k, w, h, int(np.count_nonzero(table >> 31)))
+        assert np.array_equal(got8, exp8)

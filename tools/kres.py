@@ -6,7 +6,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", f"-I{ROOT}/include",
+flags = subprocess.run(["make", "-s", "-C", str(ROOT), "print-hipflags"], capture_output=True, text=True, check=True).stdout.split()
+cmd = ["/opt/rocm/bin/hipcc", *flags, f"-I{ROOT}/include", "--cuda-device-only",
        "-c", str(ROOT / "rbrt_amd/csrc/kernels.hip"), "-o", "/tmp/kres.o", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
