@@ -123,22 +123,34 @@ struct rbrt_hip_scene {
         unsigned long long* d_work_counter = nullptr;
         uint32_t* d_gseq = nullptr;
         uint32_t* d_gstack = nullptr;
-        unsigned long long* d_spread_ring = nullptr;  // the drain's ring of path records (only when spreading is on)
-        // the tile pass (kernels.hip primary_cull_kernel + tile_lists_kernel): which of the rank's tiles see only the
-        // background. Recomputed on the lane's trace stream when the camera or the tile partition differs from `tile_key`.
-        uint32_t* d_tile_cull = nullptr;   // [n_tiles]
-        uint32_t* d_tile_lists = nullptr;  // [kTileListHeader + 2 * n_local]
-        size_t tile_cull_words = 0, tile_lists_words = 0;
-        hipEvent_t ev_lists = nullptr;     // recorded behind the tile pass
+        unsigned long long* d_merge_ring = nullptr;  // the drain's rings of path records (only when merging is on)
+        // The tile pass (kernels.hip primary_cull_kernel + tile_lists_kernel): which of the rank's tiles see only the
+        // background, for one camera and tile partition (`key`). A lane has TWO sets of tables: the pass for a camera the
+        // lane has not seen is issued when the CALL is made, on the scene's high-priority `prep_stream`, into the set the
+        // lane's launch in flight is not reading -- so it runs beside the other lanes' launches, one or two frames ahead of
+        // the trace launch that needs it, instead of in front of that launch on the lane's own stream with half the
+        // GPU waiting (a new camera per frame cost 3.77 ms per frame against 3.55 for a fixed one).
         struct TileKey {
             rbrt_camera_t cam;
             uint32_t rank, world;
-        } tile_key;
-        bool tile_key_valid = false;
+        };
+        struct TileSet {
+            uint32_t* d_cull = nullptr;    // [n_tiles]
+            uint32_t* d_lists = nullptr;   // [kTileListHeader + 2 * n_local]
+            hipEvent_t ev_lists = nullptr;  // recorded behind the tile pass that filled the set
+            hipEvent_t ev_free = nullptr;   // recorded behind the last reader (the resolve kernels of the launch that used it)
+            bool free_recorded = false;
+            bool key_valid = false;
+            TileKey key;
+            uint64_t last_used = 0;        // launch number (scene-wide) of the last launch that read the set
+        } tiles[2];
+        size_t tile_cull_words = 0, tile_lists_words = 0;
         hipEvent_t ev_traced = nullptr, ev_resolved = nullptr;
         bool in_use = false;  // ev_resolved has been recorded at least once
     };
     std::vector<Lane> lanes;
+    hipStream_t prep_stream = nullptr;  // high priority: the tile passes of cameras the lanes have not seen
+    uint64_t launch_no = 0;
     bool streaming_hint = false;  // the last trace launch was issued while another one was still running
     uint32_t pipeline = 0;   // RBRT_PIPELINE / rbrt_hip_scene_set_pipeline; 0 = automatic (depth_for)
     uint32_t scratch_waves = 0;
@@ -175,15 +187,12 @@ struct rbrt_hip_scene {
     uint32_t primary_cull = 1;    // RBRT_PRIMARY_CULL (0: no tile pass, the trace kernel renders every tile)
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
-    // the end of a launch (megakernel.inl "taper" / "spread")
-    uint32_t taper_chunks = 0;    // RBRT_TAPER_CHUNKS: chunks per wave left in the launch when waves stop filling their pools (0: off)
-    uint32_t taper_live = 64;     // RBRT_TAPER_LIVE: ... beyond this many live paths
-    uint32_t spread_min = 0;      // RBRT_SPREAD_MIN: parked paths a draining wave must hold to give half away (0: off)
-    uint32_t spread_polls = 300;  // RBRT_SPREAD_POLLS: times (3.4 us apart) a wave that ran empty asks for paths before it exits
-    uint32_t spread_pollers = 128;  // RBRT_SPREAD_POLLERS: waves per XCD that may ask at a time
-    uint32_t spread_tail = 4;     // RBRT_SPREAD_TAIL: giving starts when 1/this of an XCD's waves still work (0: at once)
-    uint32_t spread_overlap = 1;  // RBRT_SPREAD_OVERLAP: 0 = launches issued while another is running do not spread
-    uint32_t spread_token = 0;    // tag of the last launch's ring records
+    // the end of a launch (megakernel.inl "merging")
+    uint32_t merge_low = 0;          // RBRT_MERGE_LOW: a draining wave with fewer parked paths than this writes them out and exits (0: off)
+    uint32_t merge_take_min = 16;    // RBRT_MERGE_TAKE_MIN: free slots a wave that goes on needs to take records
+    uint32_t merge_empty_takes = 1;  // RBRT_MERGE_EMPTY_TAKES: a wave that ran empty stays when a pass's worth of records waits
+    uint32_t merge_isolated = 1;     // RBRT_MERGE_ISOLATED: 0 = a launch that has the GPU to itself does not merge
+    uint32_t merge_token = 0;        // tag of the last launch's ring records
     // stats / timing
     rbrt_hip_stats_t stats{};
     bool stats_pending = false;
@@ -291,7 +300,7 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
     while (s->lanes.size() < depth) {
         rbrt_hip_scene::Lane L;
         void* p = nullptr;
-        const size_t counter_bytes = sizeof(unsigned long long) * kWorkCounterWords;  // work counters + the spread ring's control line
+        const size_t counter_bytes = sizeof(unsigned long long) * kWorkCounterWords;  // work counters + the merge rings' control lines
         HIP_TRY(hipMalloc(&p, counter_bytes));
         s->allocs.push_back(p);
         L.d_work_counter = static_cast<unsigned long long*>(p);
@@ -303,11 +312,11 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
         s->allocs.push_back(p);
         L.d_gstack = static_cast<uint32_t*>(p);
-        if (s->spread_min != 0u) {  // (tags of an earlier life of this memory must not look like a launch's: cleared once)
-            const size_t ring_bytes = size_t(kWorkShards) * kSpreadRingRecords * kSpreadGranules * sizeof(unsigned long long);
+        if (s->merge_low != 0u) {  // (tags of an earlier life of this memory must not look like a launch's: cleared once)
+            const size_t ring_bytes = size_t(kWorkShards) * kMergeRingRecords * kMergeGranules * sizeof(unsigned long long);
             HIP_TRY(hipMalloc(&p, ring_bytes));
             s->allocs.push_back(p);
-            L.d_spread_ring = static_cast<unsigned long long*>(p);
+            L.d_merge_ring = static_cast<unsigned long long*>(p);
             HIP_TRY(hipMemset(p, 0, ring_bytes));
         }
         // the lane is recorded before its stream and events exist, so that a failure below leaves them to
@@ -669,10 +678,8 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             lab_u32("RBRT_SHADE_CONT_MIN", 1, 64, s->shade_cont_min, err) && lab_u32("RBRT_PIPELINE", 0, kMaxPipeline, s->pipeline, err) &&
             lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err) && lab_u32("RBRT_PRIMARY_CULL", 0, 1, s->primary_cull, err) &&
             lab_u32("RBRT_TILE_ORDER", 0, 2, s->tile_order, err) && lab_u32("RBRT_TILE_CLASSES", 0, 3, s->tile_classes, err) &&
-            lab_u32("RBRT_TAPER_CHUNKS", 0, 1024, s->taper_chunks, err) && lab_u32("RBRT_TAPER_LIVE", 1, 256, s->taper_live, err) &&
-            lab_u32("RBRT_SPREAD_MIN", 0, 256, s->spread_min, err) && lab_u32("RBRT_SPREAD_POLLS", 0, 1 << 20, s->spread_polls, err) &&
-            lab_u32("RBRT_SPREAD_OVERLAP", 0, 1, s->spread_overlap, err) && lab_u32("RBRT_SPREAD_POLLERS", 0, 4096, s->spread_pollers, err) &&
-            lab_u32("RBRT_SPREAD_TAIL", 0, 64, s->spread_tail, err);
+            lab_u32("RBRT_MERGE_LOW", 0, 128, s->merge_low, err) && lab_u32("RBRT_MERGE_TAKE_MIN", 1, 128, s->merge_take_min, err) &&
+            lab_u32("RBRT_MERGE_EMPTY_TAKES", 0, 1, s->merge_empty_takes, err) && lab_u32("RBRT_MERGE_ISOLATED", 0, 1, s->merge_isolated, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
         if ((stripes & (stripes - 1u)) != 0u || (stripes_overlap != kStripesAuto && (stripes_overlap & (stripes_overlap - 1u)) != 0u))  // the kernel shifts
             return bail(fail(RBRT_ERR_INVALID_ARG, "lab knob RBRT_WORK_STRIPES / RBRT_WORK_STRIPES_OVERLAP must be 0 or a power of two"));
@@ -705,10 +712,14 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
         if (L.ev_traced) (void)hipEventDestroy(L.ev_traced);
         if (L.ev_resolved) (void)hipEventDestroy(L.ev_resolved);
         if (L.d_sample_buf) (void)hipFree(L.d_sample_buf);
-        if (L.d_tile_cull) (void)hipFree(L.d_tile_cull);
-        if (L.d_tile_lists) (void)hipFree(L.d_tile_lists);
-        if (L.ev_lists) (void)hipEventDestroy(L.ev_lists);
+        for (auto& T : L.tiles) {
+            if (T.d_cull) (void)hipFree(T.d_cull);
+            if (T.d_lists) (void)hipFree(T.d_lists);
+            if (T.ev_lists) (void)hipEventDestroy(T.ev_lists);
+            if (T.ev_free) (void)hipEventDestroy(T.ev_free);
+        }
     }
+    if (s->prep_stream) (void)hipStreamDestroy(s->prep_stream);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->d_acc) (void)hipFree(s->d_acc);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
@@ -835,9 +846,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.work_stripes = s->work_stripes;  // (per launch: set where the launch's size is known)
     P.shade_rounds = s->shade_rounds;
     P.shade_cont_min = s->shade_cont_min;
-    P.taper_chunks = s->taper_chunks, P.taper_live = s->taper_live;
-    P.spread_min = 0u, P.spread_polls = s->spread_polls, P.spread_token = 0u, P.spread_ctl = nullptr, P.spread_ring = nullptr;
-    P.spread_pollers = s->spread_pollers, P.spread_tail = s->spread_tail;
+    P.merge_low = 0u, P.merge_take_min = s->merge_take_min, P.merge_empty_takes = s->merge_empty_takes;
+    P.merge_token = 0u, P.merge_ctl = nullptr, P.merge_ring = nullptr;
 
     ResolveParams R;
     std::memset(&R, 0, sizeof(R));
@@ -876,25 +886,33 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             L.d_sample_buf = static_cast<float*>(p), L.sample_buf_bytes = need;
         }
         if (tile_pass && (n_tiles > L.tile_cull_words || lists_need > L.tile_lists_words)) {
-            if (L.d_tile_cull || L.d_tile_lists) {
+            if (L.tiles[0].d_cull || L.tiles[0].d_lists) {
                 if (int rc = sync_lanes()) return rc;
-                if (L.d_tile_cull) HIP_TRY(hipFree(L.d_tile_cull));
-                L.d_tile_cull = nullptr, L.tile_cull_words = 0;
-                if (L.d_tile_lists) HIP_TRY(hipFree(L.d_tile_lists));
-                L.d_tile_lists = nullptr, L.tile_lists_words = 0;
+                if (s->prep_stream) HIP_TRY(hipStreamSynchronize(s->prep_stream));
             }
-            L.tile_key_valid = false;
-            void* p = nullptr;
-            HIP_TRY(hipMalloc(&p, size_t(n_tiles) * sizeof(uint32_t)));
-            L.d_tile_cull = static_cast<uint32_t*>(p), L.tile_cull_words = n_tiles;
-            HIP_TRY(hipMalloc(&p, lists_need * sizeof(uint32_t)));
-            L.d_tile_lists = static_cast<uint32_t*>(p), L.tile_lists_words = lists_need;
-            if (!L.ev_lists) HIP_TRY(hipEventCreateWithFlags(&L.ev_lists, hipEventDisableTiming));
+            for (auto& T : L.tiles) {
+                if (T.d_cull) HIP_TRY(hipFree(T.d_cull));
+                if (T.d_lists) HIP_TRY(hipFree(T.d_lists));
+                T.d_cull = T.d_lists = nullptr;
+                T.key_valid = false, T.free_recorded = false;
+                void* p = nullptr;
+                HIP_TRY(hipMalloc(&p, size_t(n_tiles) * sizeof(uint32_t)));
+                T.d_cull = static_cast<uint32_t*>(p);
+                HIP_TRY(hipMalloc(&p, lists_need * sizeof(uint32_t)));
+                T.d_lists = static_cast<uint32_t*>(p);
+                if (!T.ev_lists) HIP_TRY(hipEventCreateWithFlags(&T.ev_lists, hipEventDisableTiming));
+                if (!T.ev_free) HIP_TRY(hipEventCreateWithFlags(&T.ev_free, hipEventDisableTiming));
+            }
+            L.tile_cull_words = n_tiles, L.tile_lists_words = lists_need;
         }
     }
-    // The tile pass of a lane that has never had one runs now, for this camera, on the caller's stream: later, in the
-    // middle of a stream of frames, its kernels would have to wait for room beside the resident trace waves. (A lane whose
-    // lists are for another camera still redoes them at its turn.)
+    if (tile_pass && !s->prep_stream) {
+        int prio_low = 0, prio_high = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: low >= high)
+        HIP_TRY(hipStreamCreateWithPriority(&s->prep_stream, hipStreamNonBlocking, prio_high));
+    }
+    // The tile pass of a lane that has never had one runs now, for this camera, on the caller's stream (the lanes' buffers
+    // were made just above; in the middle of a stream of frames a first pass would have to find room beside resident waves).
     if (tile_pass) {
         TraceParams T;
         fill_trace_params(s, cam, o, T);
@@ -903,13 +921,14 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         T.tile_list_mode = s->tile_classes;
         for (uint32_t li = 0; li < depth; ++li) {
             rbrt_hip_scene::Lane& L = s->lanes[li];
-            if (L.tile_key_valid) continue;
-            T.tile_cull = L.d_tile_cull, T.tile_lists = L.d_tile_lists;
+            if (L.tiles[0].key_valid || L.tiles[1].key_valid) continue;
+            rbrt_hip_scene::Lane::TileSet& S = L.tiles[0];
+            T.tile_cull = S.d_cull, T.tile_lists = S.d_lists;
             HIP_TRY(launch_primary_cull(T, stream));
-            HIP_TRY(hipEventRecord(L.ev_lists, stream));
-            std::memset(&L.tile_key, 0, sizeof(L.tile_key));
-            L.tile_key.cam = *cam, L.tile_key.rank = o->tile_rank, L.tile_key.world = world;
-            L.tile_key_valid = true;
+            HIP_TRY(hipEventRecord(S.ev_lists, stream));
+            std::memset(&S.key, 0, sizeof(S.key));
+            S.key.cam = *cam, S.key.rank = o->tile_rank, S.key.world = world;
+            S.key_valid = true;
         }
     }
     const size_t ev0 = s->events_used;
@@ -942,41 +961,48 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.work_counter = L.d_work_counter;
         P.gseq = L.d_gseq;
         P.gstack = L.d_gstack;
-        if (L.d_spread_ring && (s->spread_overlap != 0u || !overlapped)) {
-            // (the control line sits behind the work counters and is zeroed with them; a token is never 0 and is not used
+        if (L.d_merge_ring && (s->merge_isolated != 0u || overlapped)) {
+            // (the control lines sit behind the work counters and are zeroed with them; a token is never 0 and is not used
             // again before 2^32 - 1 launches of this scene have passed)
-            if (++s->spread_token == 0u) s->spread_token = 1u;
-            P.spread_min = s->spread_min, P.spread_token = s->spread_token;
-            P.spread_ctl = L.d_work_counter + kWorkShards * kWorkCounterStride;
-            P.spread_ring = L.d_spread_ring;
+            if (++s->merge_token == 0u) s->merge_token = 1u;
+            P.merge_low = s->merge_low, P.merge_token = s->merge_token;
+            P.merge_ctl = L.d_work_counter + kWorkShards * kWorkCounterStride;
+            P.merge_ring = L.d_merge_ring;
         } else {
-            P.spread_min = 0u, P.spread_ctl = nullptr, P.spread_ring = nullptr;
+            P.merge_low = 0u, P.merge_ctl = nullptr, P.merge_ring = nullptr;
         }
-        P.tile_cull = tile_pass ? L.d_tile_cull : nullptr;
-        P.tile_lists = tile_pass ? L.d_tile_lists : nullptr;
+        // which of the lane's two sets of tile tables this launch reads: the one made for this camera and partition, else
+        // the one used longer ago, filled now
+        rbrt_hip_scene::Lane::TileSet* S = nullptr;
+        if (tile_pass) {
+            rbrt_hip_scene::Lane::TileKey key;
+            std::memset(&key, 0, sizeof(key));
+            key.cam = *cam, key.rank = o->tile_rank, key.world = world;
+            for (auto& C : L.tiles)
+                if (C.key_valid && std::memcmp(&key, &C.key, sizeof(key)) == 0) S = &C;
+            if (!S) {
+                S = L.tiles[0].last_used <= L.tiles[1].last_used ? &L.tiles[0] : &L.tiles[1];
+                // behind the set's last readers and behind the pass that wrote it last (whatever stream that ran on), on the
+                // prep stream: beside the launches in flight, ahead of this one
+                if (S->free_recorded) HIP_TRY(hipStreamWaitEvent(s->prep_stream, S->ev_free, 0));
+                if (S->key_valid) HIP_TRY(hipStreamWaitEvent(s->prep_stream, S->ev_lists, 0));
+                P.tile_cull = S->d_cull, P.tile_lists = S->d_lists;
+                P.tile_list_mode = s->tile_classes;
+                HIP_TRY(launch_primary_cull(P, s->prep_stream));
+                HIP_TRY(hipEventRecord(S->ev_lists, s->prep_stream));
+                S->key = key, S->key_valid = true;
+            }
+            S->last_used = ++s->launch_no;
+        }
+        P.tile_cull = S ? S->d_cull : nullptr;
+        P.tile_lists = S ? S->d_lists : nullptr;
         P.tile_list_mode = s->tile_classes;
         if (tile_pass && s->tile_classes != 0u) P.tiles_reversed = 0u;  // (the list is in hand-out order already)
         // (L.d_work_counter is zero: from its allocation, afterwards from the resolve kernel of the lane's last launch)
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
-        if (tile_pass) {
-            // The tile pass, on the trace launch's stream (inside its timed span): the lists are the lane's own -- another
-            // lane may be rendering another camera -- and are kept for as long as camera and partition stay what they were.
-            rbrt_hip_scene::Lane::TileKey key;
-            std::memset(&key, 0, sizeof(key));
-            key.cam = *cam, key.rank = o->tile_rank, key.world = world;
-            if (!L.tile_key_valid || std::memcmp(&key, &L.tile_key, sizeof(key)) != 0) {
-                // (behind the tile pass that wrote these buffers last: it may have run on another stream -- the first one of
-                // a lane runs on the caller's, above -- and must not land on top of this one)
-                if (L.tile_key_valid) HIP_TRY(hipStreamWaitEvent(ts, L.ev_lists, 0));
-                HIP_TRY(launch_primary_cull(P, ts));
-                HIP_TRY(hipEventRecord(L.ev_lists, ts));
-                L.tile_key = key, L.tile_key_valid = true;
-            } else {
-                HIP_TRY(hipStreamWaitEvent(ts, L.ev_lists, 0));  // (kept lists: made on whatever stream the lane's launch had then)
-            }
-        }
+        if (S) HIP_TRY(hipStreamWaitEvent(ts, S->ev_lists, 0));  // (the set's tables: made on the prep stream, or at the first call on the caller's)
         const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped);
         (grid < s->n_waves ? s->n_half_grid : s->n_full_grid) += 1;
         HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, s->share_idle != 0u && P.n_items < s->share_below, ts));
@@ -998,6 +1024,10 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         // trace launch it waited for wave slots that persistent trace waves hold until their launch ends (1.2 ms on
         // average for 0.05 ms of work, with the resolve queued behind it); now it runs in the slots that launch just freed.
         if (tile_pass) HIP_TRY(launch_sky_resolve(P, R, stream));
+        if (S) {  // the set's last readers have been issued: a later pass into it waits for them
+            HIP_TRY(hipEventRecord(S->ev_free, stream));
+            S->free_recorded = true;
+        }
         if (depth > 1) {  // (also after a counting launch: it used lane 0's buffers on the caller's stream)
             HIP_TRY(hipEventRecord(L.ev_resolved, stream));
             L.in_use = true;

@@ -21,14 +21,14 @@ constexpr int kLeafMax = 1 << kLeafBits;   // triangles per leaf
 constexpr int kPoolMax = 256;        // largest path pool per wave the persistent megakernel is built for
 constexpr uint32_t kWorkShards = 8;         // work-item counters (one per XCD)
 constexpr uint32_t kWorkCounterStride = 16;  // in u64: each counter on its own 128-B line
-// The drain's spread ring (megakernel.inl "spread"): control words behind the work counters (zeroed with them by the
-// resolve kernel), and a ring of path records a wave that still holds many parked paths hands to waves that ran empty.
-// One control line and one ring per XCD (giver and taker share an L2; no word is polled by more than one XCD's waves).
-constexpr uint32_t kSpreadCtlWords = 16;                                    // u64 words per XCD: one 128-B line
-constexpr uint32_t kWorkCounterWords = kWorkShards * (kWorkCounterStride + kSpreadCtlWords);  // the lane's counter block
-// u64 word 0 of a control line: (records taken << 32) | records reserved; word 1: (waves that still work << 32) | waves asking
-constexpr uint32_t kSpreadGranules = 32;   // 8-byte {tag, value} granules per record: 13 fields, status, <= 16 bounce words
-constexpr uint32_t kSpreadRingRecords = 8192;  // records per XCD's ring (8 x 2 MiB per pipeline lane); a full ring stops the giving
+// Merging the thin ends of the waves (megakernel.inl "merging"): per XCD one control line behind the work counters (zeroed
+// with them by the resolve kernel) and one ring of path records that a wave whose pool has thinned out writes before it
+// exits, for the waves that go on to take (giver and taker share an L2; no word is touched by more than one XCD's waves).
+constexpr uint32_t kMergeCtlWords = 16;                                     // u64 words per XCD: one 128-B line
+constexpr uint32_t kWorkCounterWords = kWorkShards * (kWorkCounterStride + kMergeCtlWords);  // the lane's counter block
+// u64 word 0 of a control line: (waves of the XCD still running << 32) | records reserved; word 1: records taken
+constexpr uint32_t kMergeGranules = 32;     // 8-byte {tag, value} granules per record: 13 fields, status, <= 16 bounce words
+constexpr uint32_t kMergeRingRecords = 32768;  // records per XCD's ring (8 x 8 MiB per pipeline lane); a full ring stops the giving
 constexpr uint32_t kMaxShadeRounds = 64;  // hard bound of register-resident shading rounds per pass
 constexpr int kLdsStack = 8;         // per-lane traversal stack entries kept in LDS by the megakernel; deeper
                                      // entries spill (exactly) to a per-wave global scratch
@@ -157,17 +157,13 @@ struct TraceParams {
     uint32_t* tile_cull;
     uint32_t* tile_lists;
     uint32_t tile_list_mode;  // order of the work list (tile_lists_kernel)
-    // End of a launch (megakernel.inl "taper" and "spread").
-    uint32_t taper_chunks;    // once fewer than this many 64-item chunks PER WAVE are left, a wave tops its pool up to
-    uint32_t taper_live;      // ... taper_live paths only (0 chunks: no taper)
-    uint32_t spread_min;      // a wave out of work items gives half its parked paths away while it has this many and
-                              // waves that ran empty are asking (0: no spreading)
-    uint32_t spread_polls;    // how many times (3.4 us apart) a wave that ran empty asks before it exits
-    uint32_t spread_pollers;  // at most this many waves per XCD ask at a time; the others exit when they run empty
-    uint32_t spread_tail;     // giving starts when (waves of the XCD that still work) x this <= the XCD's share of the grid (0: at once)
-    uint32_t spread_token;    // tag of this launch's records in the ring (never 0, never reused while the ring lives)
-    unsigned long long* spread_ctl;   // [kWorkShards][kSpreadCtlWords]; zero at launch
-    unsigned long long* spread_ring;  // [kWorkShards][kSpreadRingRecords][kSpreadGranules]
+    // The end of a launch (megakernel.inl "merging").
+    uint32_t merge_low;         // a wave out of work items whose pool holds fewer paths than this, all parked, writes them out and exits (0: off)
+    uint32_t merge_take_min;    // a wave that goes on takes records when it has at least this many free slots
+    uint32_t merge_empty_takes; // 1: a wave that has run empty stays when merge_low or more records are waiting (0: only the last one of its XCD does)
+    uint32_t merge_token;       // tag of this launch's records in the rings (never 0, never reused while the rings live)
+    unsigned long long* merge_ctl;   // [kWorkShards][kMergeCtlWords]; zero at launch
+    unsigned long long* merge_ring;  // [kWorkShards][kMergeRingRecords][kMergeGranules]
 };
 
 struct ResolveParams {

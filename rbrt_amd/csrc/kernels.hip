@@ -674,7 +674,7 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) 
     // the trace launch this resolves has ended: its work counters are reset for the lane's next launch (which
     // waits for this kernel), saving a memset launch that would have to queue behind the resident megakernels
     static_assert(kWorkCounterWords <= kBlock, "one thread per counter word");
-    if (blockIdx.x == 0 && threadIdx.x < kWorkCounterWords) R.work_counter[threadIdx.x] = 0ull;  // (the spread ring's control line too)
+    if (blockIdx.x == 0 && threadIdx.x < kWorkCounterWords) R.work_counter[threadIdx.x] = 0ull;  // (the merge rings' control lines too)
     if (i >= npix) return;
     const uint32_t p = uint32_t(i & 63u);
     const uint32_t tile_local = R.tile_lists ? R.tile_lists[kTileListHeader + (i >> 6)] : uint32_t(i >> 6);

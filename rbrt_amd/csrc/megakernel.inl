@@ -24,7 +24,7 @@
 //                             that just ended (per-wave accumulators in LDS, summed into DevCounters::diag[0..kNumRegions)
 //                             at the end): where a wave's LIFETIME goes, waits included (tools/region_profile.py)
 #define RBRT_REGIONS(X) X(init) X(finalise) X(census) X(refill) X(choose) X(burst_top) X(leaf_round) X(leaf_chunk) X(walk) \
-    X(burst_end) X(pass_lists) X(term) X(gen) X(scatter_load) X(round_top) X(scatter_kind) X(spheres_gate) X(gate) X(park) X(spread)
+    X(burst_end) X(pass_lists) X(term) X(gen) X(scatter_load) X(round_top) X(scatter_kind) X(spheres_gate) X(gate) X(park) X(merge)
 #define RBRT_REGION_ENUM(name) R_##name,
 enum { RBRT_REGIONS(RBRT_REGION_ENUM) kNumRegions };
 #ifndef RBRT_REGION_TIMERS
@@ -165,10 +165,6 @@ struct WorkSource {
     bool pending = false;                // wave-uniform
 
     uint32_t n_chunks = 0;               // wave-uniform: chunks of the launch (its work items / 64)
-    // wave-uniform: the launch is in its last part (the taper, megakernel "the end of a launch"): fewer than
-    // P.taper_chunks chunks per wave were left when this wave got its last one (exact with interleaved stripes, the own
-    // shard's rest x 8 with contiguous shards: an exhausted shard of one's own says nothing, cheap eighths finish early)
-    bool last_part = false;
 
     __device__ __forceinline__ void init(uint32_t n_items) {
         n_chunks = n_items >> 6;  // (a multiple of the chunk size: 64 pixel slots per tile)
@@ -208,7 +204,6 @@ struct WorkSource {
                         lo = g * kWorkChunk;
                         hi = lo + kWorkChunk;
                         n_dry = 0;
-                        if (n_chunks - g < RBRT_KARG(taper_chunks) * gridDim.x) last_part = true;
                         return true;
                     }
                 } else {
@@ -217,14 +212,12 @@ struct WorkSource {
                         lo = base + l_lo;
                         hi = lo + kWorkChunk < end ? lo + kWorkChunk : end;
                         n_dry = 0;
-                        if (((end - base - l_lo) >> 6) * kWorkShards < RBRT_KARG(taper_chunks) * gridDim.x) last_part = true;
                         return true;
                     }
                 }
             }
             shard = uni((ps + 1u) % kWorkShards);  // this shard is exhausted: move on
             n_dry = uni(n_dry + 1u);
-
             if (n_dry >= kWorkShards) {
                 lo = hi = 0;
                 return false;
@@ -345,48 +338,112 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         dg_rt0 = __builtin_amdgcn_s_memrealtime();
     }
     bool more_work = true;  // wave-uniform: the global work counter has not run out yet
-    // ---- the end of a launch (DESIGN.md section 6 "The end of a launch") ----
-    // taper:  once fewer than P.taper_chunks chunks PER WAVE are left to hand out, a wave starts new paths only while it
-    //         holds fewer than RBRT_KARG(taper_live): the last work items go to the waves whose pools have thinned out, and no wave
-    //         enters the drain with a second round of paths queued behind its 64 lanes. Wave-uniform and sticky.
-    // (both flags in one scalar word, and nothing else of this kept across the loop: every SGPR held here is one more
-    // spilled around the traversal loop)
-    uint32_t end_flags = 0;  // bit 0: taper; bit 1: this wave is not counted in SC_WORKING
-#define taper ((end_flags & 1u) != 0u)
-    // spread: the launch's last part belongs to the waves that still hold many paths while most have run empty; a path
-    //         there waits for its wave's other paths at every bounce. A wave that has run out of work items AND of paths
-    //         therefore does not simply exit: up to P.spread_pollers waves per XCD stay and ask (SC_HUNGRY), and a wave
-    //         that holds P.spread_min or more parked paths gives half of them away -- once the XCD's count of waves that
-    //         still work (SC_WORKING) has fallen below its share / P.spread_tail -- through a ring of records in global
-    //         memory. Everything is per XCD (HW_REG_XCC_ID): a control line and a ring each, so that giver and taker share
-    //         an L2 and no word is polled by more than the waves of one XCD (a single line for the whole chip, polled by
-    //         4096 waves, made the launch 3.5x longer: DESIGN.md). A record is 8-byte {tag, value} granules written and read
-    //         with agent-scope relaxed atomics (write-through stores, loads that bypass the L1: the data is its own flag, no
-    //         fences); the tag is the launch's token. Every wait is bounded. NO wave exits without having seen its XCD's
-    //         ring empty after its own last gift, so a record is always taken by someone -- at the latest by its giver.
-    //         Who finishes a path cannot change the image: a path owns its RNG stream and its sample slot.
+    // ---- merging the thin ends of the waves (DESIGN.md section 6 "The end of a launch") ----
+    // Once the work items are out, every wave's pool runs empty on its own: 110 paths, then 50, 20, 8, 3, 1 -- and every
+    // round of those costs a full pass's instructions for a handful of lanes (measured: 7 lanes per shading pass in the
+    // drain against 50 before it; 48 % of all wave lifetime). So a wave whose pool has thinned out below P.merge_low
+    // paths, all of them parked, WRITES THEM OUT as records and EXITS, and the waves that go on take the records into
+    // their free slots: the paths that are left keep sharing full passes, and the wave slots go to the next launch.
+    // Per XCD (HW_REG_XCC_ID: giver and taker share an L2, nothing is polled chip-wide) there is a control line and a
+    // ring of records in global memory. Word A of the line = (waves of the XCD still running << 32) | records
+    // reserved, word B = records taken. A giver reserves its records AND leaves the count of running waves with ONE
+    // atomic add on word A, so the wave that finds itself the last one running (its own decrement returns 1) sees every
+    // reservation ever made and takes what is left: no record can be stranded, and nobody ever waits for anybody --
+    // the only wait is a taker's bounded spin on a record whose giver is still writing it. A record is 8-byte
+    // {tag, value} granules written and read with agent-scope relaxed atomics (write-through stores, loads that bypass
+    // the L1: the data is its own flag, no fences); the tag is the launch's token.
+    // Who finishes a path cannot change the image: a path owns its RNG stream and its sample slot.
     typedef __attribute__((address_space(1))) unsigned long long gu64;
-#define spread_on (SHAREK && RBRT_KARG(spread_min) != 0u) /* (api.cpp: rings and control lines exist whenever spread_min != 0) */
-    uint32_t dg_sp_given = 0, dg_sp_taken = 0, dg_sp_polls = 0, dg_sp_rounds = 0;
+#define merge_on (SHAREK && RBRT_KARG(merge_low) != 0u) /* (api.cpp: rings and control lines exist whenever merge_low != 0) */
+    uint32_t dg_mg_given = 0, dg_mg_taken = 0, dg_mg_exits = 0, dg_mg_takes = 0;
+    uint32_t no_give = 0;  // wave-uniform: this wave found itself the last one running once; it keeps what it has
     auto xcd_now = [&]() -> uint32_t {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
         return xcc % kWorkShards;
     };
-    // this XCD's control line as two 64-bit words: [0] = (head << 32 | tail), [1] = (working << 32 | hungry)
-    auto sctl64 = [&]() -> gu64* {
-        return (gu64*)karg_ptr<unsigned long long, offsetof(TraceParams, spread_ctl)>() + xcd_now() * kSpreadCtlWords;
+    auto mctl = [&]() -> gu64* {  // this XCD's control line: [0] = word A, [1] = word B
+        return (gu64*)karg_ptr<unsigned long long, offsetof(TraceParams, merge_ctl)>() + xcd_now() * kMergeCtlWords;
     };
-    auto sring = [&]() -> gu64* {
-        return (gu64*)karg_ptr<unsigned long long, offsetof(TraceParams, spread_ring)>() +
-               size_t(xcd_now()) * kSpreadRingRecords * kSpreadGranules;
+    auto mring = [&]() -> gu64* {
+        return (gu64*)karg_ptr<unsigned long long, offsetof(TraceParams, merge_ring)>() + size_t(xcd_now()) * kMergeRingRecords * kMergeGranules;
     };
-    auto sload64 = [&](gu64* w) -> unsigned long long {  // (every lane the same word: one request; the value through SGPRs)
+    auto mload = [&](gu64* w) -> unsigned long long {  // (every lane the same word: one request; the value through SGPRs)
         const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return (unsigned long long)WorkSource::uni(uint32_t(v)) | ((unsigned long long)WorkSource::uni(uint32_t(v >> 32)) << 32);
     };
-    constexpr unsigned long long kOneWorking = 1ull << 32, kOneHungry = 1ull, kOneHead = 1ull << 32;
-    if (spread_on && lane == 0) __hip_atomic_fetch_add(sctl64() + 1, kOneWorking, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto madd = [&](gu64* w, unsigned long long d) -> unsigned long long {  // lane 0 adds; the old value to every lane
+        unsigned long long old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(w, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (unsigned long long)WorkSource::uni(uint32_t(old)) | ((unsigned long long)WorkSource::uni(uint32_t(old >> 32)) << 32);
+    };
+    constexpr unsigned long long kOneWave = 1ull << 32;
+    // Records [first, first + n) of this XCD's ring into n EMPTY slots of the pool (the caller knows there are that many).
+    auto take_records = [&](uint32_t first, uint32_t n) {
+        uint32_t lane_here = lane;  // (opaque: addresses derived from it are made here, not carried -- spilled -- through the kernel)
+        asm volatile("" : "+v"(lane_here));
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < kPoolPad; g += 64) {  // the first n empty slots, in slot order
+            const bool m = status[g + lane_here] == ST_EMPTY;
+            const uint64_t mask = wballot(m);
+            const uint32_t r = c + lane_rank(mask);
+            if (m && r < n) list[r] = uint8_t(g + lane_here);
+            c += uint32_t(__popcll(mask));
+        }
+        __syncthreads();
+        if (lane_here < n) {
+            const uint32_t slot = list[lane_here];
+            gu64* const rec = mring() + size_t(first + lane_here) * kMergeGranules;
+            const uint32_t token = RBRT_KARG(merge_token);
+            bool lost = false;
+            auto granule = [&](uint32_t k) -> uint32_t {  // (reserved before the head could reach it: its giver is writing it)
+                for (uint32_t spins = 0;; ++spins) {
+                    const unsigned long long x = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (uint32_t(x >> 32) == token) return uint32_t(x);
+                    if (spins >= (1u << 22)) {
+                        lost = true;
+                        return 0u;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            };
+#pragma unroll
+            for (uint32_t f = 0; f < uint32_t(kFields); ++f) POOL(f, slot) = granule(f);
+            const uint32_t st = granule(uint32_t(kFields));
+            const uint32_t nw = ((POOL(F_META, slot) >> 7) & 127u) >> 2;
+            for (uint32_t j = 0; j < nw && j < uint32_t(kSeqWords); ++j) gseq[size_t(slot) * kSeqWords + j] = granule(uint32_t(kFields) + 1u + j);
+            if (lost || st - ST_TRAV > ST_DIEL - ST_TRAV) {  // never seen; the render call fails loudly (api.cpp)
+                atomicAdd(&P.counters->diag[57], 1ull);
+            } else {
+                status[slot] = uint8_t(st);
+            }
+        }
+        if (STATS) dg_mg_taken += n, ++dg_mg_takes;
+        __syncthreads();
+    };
+    // Claims up to `room` records of this XCD's ring whose reservations `tail` covers: the first one's number and how many (0: none).
+    auto claim_records = [&](uint32_t tail, uint32_t room, uint32_t& first) -> uint32_t {
+        gu64* const ctl = mctl();
+        const uint32_t tl = tail < kMergeRingRecords ? tail : kMergeRingRecords;
+        for (uint32_t tries = 0; tries < 64u; ++tries) {
+            const uint32_t head = uint32_t(mload(ctl + 1));
+            if (head >= tl) return 0u;
+            uint32_t n = tl - head;
+            n = n < room ? n : room;
+            n = n < 64u ? n : 64u;
+            unsigned long long seen = head;
+            if (lane == 0)
+                __hip_atomic_compare_exchange_strong(ctl + 1, &seen, (unsigned long long)(head + n), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+            if (WorkSource::uni(uint32_t(seen)) == head) {  // (unchanged: the exchange took place)
+                first = head;
+                return n;
+            }
+        }
+        return 0u;  // (64 other takers in a row: leave it to them)
+    };
+    if (merge_on) (void)madd(mctl(), kOneWave);
     const float eps = P.min_dist;
 
     // ---- per-lane traversal state; lives in registers across shading passes ----
@@ -487,61 +544,66 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 #endif
         uint32_t n_active = uint32_t(__popcll(wballot(t_active != 0u)));
 
-        // ---- spread, the giving side (drain only) ----
-        if (spread_on && !more_work) {
-            const uint32_t n_parked = cnt[ST_TRAV] + cnt[ST_TERM] + cnt[ST_LAMB] + cnt[ST_METAL] + cnt[ST_DIEL];
-            if (n_parked >= RBRT_KARG(spread_min)) {
-                RBRT_MARK(spread);
-                gu64* const ctl = sctl64();
-                const unsigned long long hw = sload64(ctl + 1);
-                const uint32_t hungry = uint32_t(hw), working = uint32_t(hw >> 32);
-                // (the tail of the launch: few waves of this XCD still work; 0: no such condition)
-                const uint32_t tail_div = RBRT_KARG(spread_tail);
-                if (hungry != 0u && (tail_div == 0u || working * tail_div * kWorkShards <= gridDim.x)) {
-                    const unsigned long long th = sload64(ctl);
-                    const uint32_t tail = uint32_t(th), head = uint32_t(th >> 32);
-                    const uint32_t tl = tail < kSpreadRingRecords ? tail : kSpreadRingRecords;
-                    const uint32_t backlog = tl > head ? tl - head : 0u;  // records nobody has taken yet
-                    if (tail < kSpreadRingRecords && backlog < hungry * 64u) {
-                        uint32_t give = n_parked >> 1;
-                        if (give > hungry * 64u - backlog) give = hungry * 64u - backlog;
-                        uint32_t base = 0;
-                        if (lane == 0) base = uint32_t(__hip_atomic_fetch_add(ctl, (unsigned long long)give, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        base = WorkSource::uni(base);
-                        // (a reservation beyond the ring's end is not used: the paths stay here)
-                        const uint32_t n_fit = base >= kSpreadRingRecords ? 0u : (give < kSpreadRingRecords - base ? give : kSpreadRingRecords - base);
-                        gu64* const ring = sring();
-                        uint32_t seen = 0;
-                        // (an opaque copy of the lane number: addresses derived from it are made here, not at the top of
-                        // the kernel and carried -- spilled -- through everything else)
-                        uint32_t lane_here = lane;
-                        asm volatile("" : "+v"(lane_here));
+        // ---- merging (drain only): take records into free slots; a pool that has thinned out is written out whole ----
+        if (merge_on && !more_work) {
+            const uint32_t live = uint32_t(POOLN) - cnt[ST_EMPTY];
+            const uint32_t parked = cnt[ST_TRAV] + cnt[ST_TERM] + cnt[ST_LAMB] + cnt[ST_METAL] + cnt[ST_DIEL];
+            const uint32_t low = RBRT_KARG(merge_low);
+            if (live != 0u && (live >= low || no_give != 0u) && uint32_t(POOLN) - live >= RBRT_KARG(merge_take_min)) {
+                RBRT_MARK(merge);
+                uint32_t first = 0;
+                const uint32_t n = claim_records(uint32_t(mload(mctl())), uint32_t(POOLN) - live, first);
+                if (n != 0u) {
+                    take_records(first, n);
+                    continue;  // (count again)
+                }
+            } else if (live != 0u && live < low && live == parked && n_active == 0u && no_give == 0u) {
+                RBRT_MARK(merge);
+                gu64* const ctl = mctl();
+                const unsigned long long a = mload(ctl);
+                if (uint32_t(a) + live <= kMergeRingRecords && uint32_t(a >> 32) > 1u) {  // room in the ring, and somebody else is running
+                    // reserve `live` records and leave the running waves, in one step
+                    const unsigned long long old = madd(ctl, (unsigned long long)live - kOneWave);
+                    const uint32_t base = uint32_t(old);
+                    const uint32_t n_fit = base >= kMergeRingRecords ? 0u : (live < kMergeRingRecords - base ? live : kMergeRingRecords - base);
+                    gu64* const ring = mring();
+                    uint32_t lane_here = lane;  // (opaque, as in take_records)
+                    asm volatile("" : "+v"(lane_here));
+                    uint32_t seen = 0;
 #pragma unroll
-                        for (uint32_t g = 0; g < kPoolPad; g += 64) {  // every second parked slot, in slot order
-                            const uint32_t slot = g + lane_here;
-                            const uint32_t st = status[slot];
-                            const bool parked = st - ST_TRAV <= ST_DIEL - ST_TRAV;
-                            const uint64_t m = wballot(parked);
-                            const uint32_t r = seen + lane_rank(m);
-                            if (parked && (r & 1u) != 0u && (r >> 1) < n_fit) {
-                                gu64* const rec = ring + size_t(base + (r >> 1)) * kSpreadGranules;
-                                const unsigned long long tag = (unsigned long long)RBRT_KARG(spread_token) << 32;
+                    for (uint32_t g = 0; g < kPoolPad; g += 64) {
+                        const uint32_t slot = g + lane_here;
+                        const uint32_t st = status[slot];
+                        const bool has = st - ST_TRAV <= ST_DIEL - ST_TRAV;
+                        const uint64_t m = wballot(has);
+                        const uint32_t r = seen + lane_rank(m);
+                        if (has && r < n_fit) {
+                            gu64* const rec = ring + size_t(base + r) * kMergeGranules;
+                            const unsigned long long tag = (unsigned long long)RBRT_KARG(merge_token) << 32;
 #pragma unroll
-                                for (uint32_t f = 0; f < uint32_t(kFields); ++f)
-                                    __hip_atomic_store(rec + f, tag | POOL(f, slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store(rec + kFields, tag | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                const uint32_t nw = ((POOL(F_META, slot) >> 7) & 127u) >> 2;  // full words of bounce ids in gseq
-                                for (uint32_t j = 0; j < nw; ++j)
-                                    __hip_atomic_store(rec + kFields + 1u + j, tag | gseq[size_t(slot) * kSeqWords + j], __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
-                                status[slot] = ST_EMPTY;
-                            }
-                            seen += uint32_t(__popcll(m));
+                            for (uint32_t f = 0; f < uint32_t(kFields); ++f)
+                                __hip_atomic_store(rec + f, tag | POOL(f, slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(rec + kFields, tag | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const uint32_t nw = ((POOL(F_META, slot) >> 7) & 127u) >> 2;  // full words of bounce ids in gseq
+                            for (uint32_t j = 0; j < nw; ++j)
+                                __hip_atomic_store(rec + kFields + 1u + j, tag | gseq[size_t(slot) * kSeqWords + j], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                            status[slot] = ST_EMPTY;
                         }
-                        if (STATS) dg_sp_given += n_fit, ++dg_sp_rounds;
-                        __syncthreads();
-                        if (n_fit != 0u) continue;  // (count again)
+                        seen += uint32_t(__popcll(m));
                     }
+                    if (STATS) dg_mg_given += n_fit;
+                    __syncthreads();
+                    if (n_fit == live && uint32_t(old >> 32) > 1u) {  // everything is out and another wave of the XCD runs on: done
+                        if (STATS) ++dg_mg_exits;
+                        no_give = 2u;  // (left the count of running waves already)
+                        break;
+                    }
+                    // the last one running after all (a race with another wave's exit), or the ring's end: back among the
+                    // running waves, keeping from now on whatever it has; its own records come back through the ring
+                    (void)madd(ctl, kOneWave);
+                    no_give = 1u;
+                    continue;
                 }
             }
         }
@@ -620,89 +682,32 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         RBRT_MARK(choose);
         // ---- pick the shading kind with the most waiting slots ----
         // A TERM pass also starts new paths in empty slots while work is left.
-        uint32_t n_gen_slots = more_work ? cnt[ST_EMPTY] : 0u;
-        if (taper) {  // new paths only up to RBRT_KARG(taper_live) live ones
-            const uint32_t live = uint32_t(POOLN) - cnt[ST_EMPTY];
-            const uint32_t room = live < RBRT_KARG(taper_live) ? RBRT_KARG(taper_live) - live : 0u;
-            if (n_gen_slots > room) n_gen_slots = room;
-        }
+        const uint32_t n_gen_slots = more_work ? cnt[ST_EMPTY] : 0u;
         uint32_t kind = ST_TERM, best = cnt[ST_TERM] + n_gen_slots;
         if (cnt[ST_LAMB] > best) kind = ST_LAMB, best = cnt[ST_LAMB];
         if (cnt[ST_METAL] > best) kind = ST_METAL, best = cnt[ST_METAL];
         if (cnt[ST_DIEL] > best) kind = ST_DIEL, best = cnt[ST_DIEL];
         if (best == 0 && n_active == 0) {  // nothing waits, nothing runs, no work left
-            if (!spread_on) break;
-            // ---- spread, the taking side: the pool is empty (every slot ST_EMPTY, no lane traverses) ----
-            RBRT_MARK(spread);
-            gu64* const ctl = sctl64();
-            if ((end_flags & 2u) == 0u) {
-                end_flags = WorkSource::uni(end_flags | 2u);
-                if (lane == 0) __hip_atomic_fetch_sub(ctl + 1, kOneWorking, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!merge_on) break;
+            // ---- merging, at the exit: the pool is empty. Leave the running waves; the one that finds itself the LAST of
+            // its XCD has every reservation ever made in the word its decrement returned, and takes what is left ----
+            RBRT_MARK(merge);
+            gu64* const ctl = mctl();
+            const unsigned long long old = madd(ctl, 0ull - kOneWave);
+            const uint32_t tail = uint32_t(old) < kMergeRingRecords ? uint32_t(old) : kMergeRingRecords;
+            const uint32_t head = uint32_t(mload(ctl + 1));
+            const bool last = uint32_t(old >> 32) == 1u;
+            // (not the last: the others go on and will take what there is -- unless this wave is asked to stay useful and a
+            // pass's worth of records is waiting)
+            if (head >= tail || (!last && (RBRT_KARG(merge_empty_takes) == 0u || tail - head < RBRT_KARG(merge_low)))) {
+                no_give = 2u;
+                break;
             }
-            // one of the XCD's askers, if there is room among them; otherwise one look at the ring and out
-            uint32_t before = 0;
-            if (lane == 0) before = uint32_t(__hip_atomic_fetch_add(ctl + 1, kOneHungry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const bool asker = WorkSource::uni(before) < RBRT_KARG(spread_pollers);
-            if (!asker && lane == 0) __hip_atomic_fetch_sub(ctl + 1, kOneHungry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t got = 0, first = 0;
-            for (uint32_t polls = 0, tries = 0;; ++tries) {  // (leaves only behind a look that found the ring empty, or with records)
-                if (STATS) ++dg_sp_polls;
-                const unsigned long long th = sload64(ctl);
-                const uint32_t tail = uint32_t(th), head = uint32_t(th >> 32);
-                const uint32_t tl = tail < kSpreadRingRecords ? tail : kSpreadRingRecords;
-                if (head < tl) {
-                    const uint32_t n = tl - head < 64u ? tl - head : 64u;
-                    unsigned long long seen_th = th;
-                    if (lane == 0)
-                        __hip_atomic_compare_exchange_strong(ctl, &seen_th, th + n * kOneHead, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT);
-                    if (WorkSource::uni(uint32_t(seen_th)) == tail && WorkSource::uni(uint32_t(seen_th >> 32)) == head) {  // (unchanged: the exchange took place)
-                        got = n, first = head;
-                        break;
-                    }
-                    if (tries < (1u << 20)) continue;  // (someone else moved the line: look again at once)
-                    break;
-                }
-                if (!asker || polls >= RBRT_KARG(spread_polls)) break;
-                if (uint32_t(sload64(ctl + 1) >> 32) == 0u) break;  // nobody of this XCD works any more: nothing will come
-                ++polls;
-                __builtin_amdgcn_s_sleep(127);
-            }
-            if (asker && lane == 0) __hip_atomic_fetch_sub(ctl + 1, kOneHungry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (got == 0u) break;
-            end_flags = WorkSource::uni(end_flags & ~2u);
-            if (lane == 0) __hip_atomic_fetch_add(ctl + 1, kOneWorking, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t lane_here = lane;  // (opaque, as on the giving side)
-            asm volatile("" : "+v"(lane_here));
-            if (lane_here < got) {  // record first + lane into slot `lane`
-                gu64* const rec = sring() + size_t(first + lane_here) * kSpreadGranules;
-                const uint32_t token = RBRT_KARG(spread_token);
-                bool lost = false;
-                auto granule = [&](uint32_t k) -> uint32_t {  // (its giver reserved it before the head could reach it: it is on its way)
-                    for (uint32_t spins = 0;; ++spins) {
-                        const unsigned long long x = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (uint32_t(x >> 32) == token) return uint32_t(x);
-                        if (spins >= (1u << 22)) {
-                            lost = true;
-                            return 0u;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                };
-#pragma unroll
-                for (uint32_t f = 0; f < uint32_t(kFields); ++f) POOL(f, lane_here) = granule(f);
-                const uint32_t st = granule(uint32_t(kFields));
-                const uint32_t nw = ((POOL(F_META, lane_here) >> 7) & 127u) >> 2;
-                for (uint32_t j = 0; j < nw && j < uint32_t(kSeqWords); ++j) gseq[size_t(lane_here) * kSeqWords + j] = granule(uint32_t(kFields) + 1u + j);
-                if (lost || st - ST_TRAV > ST_DIEL - ST_TRAV) {  // never seen; the render call fails loudly (api.cpp)
-                    atomicAdd(&P.counters->diag[57], 1ull);
-                } else {
-                    status[lane_here] = uint8_t(st);
-                }
-            }
-            if (STATS) dg_sp_taken += got;
-            __syncthreads();
-            continue;
+            (void)madd(ctl, kOneWave);
+            uint32_t first = 0;
+            const uint32_t n = claim_records(tail, uint32_t(POOLN), first);
+            if (n != 0u) take_records(first, n);
+            continue;  // (with records, or to look again: as long as the ring is not empty somebody has to)
         }
 
         // Traverse while the lanes are well filled; shade when they are not (that is what parks new
@@ -963,13 +968,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             c0 += uint32_t(__popcll(mask));
         }
         const uint32_t n_main = c0 < 64u ? c0 : 64u;
-        // taper: how many lanes of a TERM pass may start a new path (kept in an LDS word until the pass needs it -- the leaf
-        // rounds' queue is idle during a shading pass --, not in an SGPR across the pass)
-        if (taper) {
-            const uint32_t live_after = uint32_t(POOLN) - cnt[ST_EMPTY] - (kind == ST_TERM ? n_main : 0u);
-            const uint32_t allowed_new = live_after < RBRT_KARG(taper_live) ? RBRT_KARG(taper_live) - live_after : 0u;
-            if (lane == 0) tq[0] = allowed_new;
-        }
         if (kind == ST_TERM && n_gen_slots != 0 && n_main < 64u) {
 #pragma unroll
             for (uint32_t g = 0; g < kPoolPad; g += 64) {
@@ -979,13 +977,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 c1 += uint32_t(__popcll(mask));
             }
         }
-        uint32_t n_gen = c1 < 64u - n_main ? c1 : 64u - n_main;
+        const uint32_t n_gen = c1 < 64u - n_main ? c1 : 64u - n_main;
         __syncthreads();
-        if (taper) {
-            const uint32_t allowed_new = WorkSource::uni(tq[0]);
-            const uint32_t left = allowed_new > n_main ? allowed_new - n_main : 0u;
-            if (n_gen > left) n_gen = left;
-        }
         const bool is_main = lane < n_main;
         const bool is_gen = !is_main && lane < n_main + n_gen;
         if (STATS) dg_lanes[kind] += n_main + n_gen;
@@ -1043,7 +1036,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     atomicAdd(&P.counters->diag[57], 1ull);
                 }
                 if (STATS) ++n_samples_done;
-                need_new = !taper || lane < tq[0];  // (the slot of a lane that may not is left empty)
+                need_new = true;
             }
         RBRT_MARK(gen);
             // ---- new paths (cam.rs:64-82); work items come from the sharded global counters ----
@@ -1057,8 +1050,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     // drain_mode bit 3: a wave whose launch has run out of work items issues ahead of the bulk waves of
                     // other launches on its SIMD: the drain is a chain of dependent rounds, the bulk fills the gaps
                     if (!more_work && (P.drain_mode & 8u)) __builtin_amdgcn_s_setprio(2);
-                    if (STATS && lane == 0 && work.last_part && !taper) atomicAdd(&P.counters->diag[56], 1ull);
-                    if (work.last_part) end_flags = WorkSource::uni(end_flags | 1u);
                     if (STATS && !more_work) dg_rt_workout = __builtin_amdgcn_s_memrealtime();
 #if RBRT_REGION_TIMERS
                     if (!more_work) rt_wall_workout = __builtin_amdgcn_s_memrealtime();
@@ -1277,8 +1268,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (STATS) dg_t_shade += __builtin_amdgcn_s_memtime() - dg_tk;
     }
 #undef POOL
-#undef taper
-#undef spread_on
+#undef merge_on
 #if RBRT_REGION_TIMERS
     rt_tick(R_init);
     if (lane < uint32_t(kNumRegions)) atomicAdd(&P.counters->diag[lane], (unsigned long long)rt_acc[lane]);
@@ -1338,10 +1328,10 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             atomicAdd(&P.counters->diag[16], dg_t_trav);
             atomicAdd(&P.counters->diag[17], dg_t_shade);
             atomicAdd(&P.counters->diag[18], (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
-            atomicAdd(&P.counters->diag[30], (unsigned long long)dg_sp_given);
-            atomicAdd(&P.counters->diag[31], (unsigned long long)dg_sp_taken);
-            atomicAdd(&P.counters->diag[49], (unsigned long long)dg_sp_polls);
-            atomicAdd(&P.counters->diag[55], (unsigned long long)dg_sp_rounds);
+            atomicAdd(&P.counters->diag[30], (unsigned long long)dg_mg_given);
+            atomicAdd(&P.counters->diag[31], (unsigned long long)dg_mg_taken);
+            atomicAdd(&P.counters->diag[49], (unsigned long long)dg_mg_exits);
+            atomicAdd(&P.counters->diag[55], (unsigned long long)dg_mg_takes);
             atomicAdd(&P.counters->diag[59], (unsigned long long)dg_share_given);
             atomicAdd(&P.counters->diag[60], (unsigned long long)dg_share_rounds);
             atomicAdd(&P.counters->diag[62], (unsigned long long)dg_sph_tails);

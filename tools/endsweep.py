@@ -5,7 +5,7 @@ rbrt_hip_scene_create), so a variant is a fresh HipScene of the same host scene.
   frame   pipelined ms per step / isolated launch ms (HIP events) / one blocking frame with the RGB8 copy
   eighth  rank 0's share of an 8-GPU run: pipelined ms per step / isolated launch ms
 
-    python3 tools/endsweep.py --rounds 3 "-" "RBRT_TAPER_CHUNKS=2" "RBRT_SPREAD_MIN=24 RBRT_SPREAD_POLLS=64"
+    python3 tools/endsweep.py --rounds 3 "-" "RBRT_MERGE_LOW=24" "RBRT_MERGE_LOW=32 RBRT_MERGE_TAKE_MIN=8"
 
 Pseudo-knobs handled here: PIPE=n (rbrt_hip_scene_set_pipeline(n) for the pipelined leg), DEPTH=n (opts.max_depth = n:
 diagnosis only, it changes the image), STATS=1 (print the counting build's end-of-launch counters once).
@@ -86,8 +86,8 @@ def main():
                     scene.render_device(cam, so, img.data_ptr(), None, stream)
                     torch.cuda.synchronize()
                     d = scene.debug_counters()
-                    print(f"stats [{v}] w{w}:", {k: d[k] for k in ("spread_given", "spread_taken", "spread_polls", "spread_rounds", "tapered_waves",
-                                                                 "drain_slowest", "drain_sum", "shared_entries_given", "path_len_hist")}, flush=True)
+                    print(f"stats [{v}] w{w}:", {k: d[k] for k in ("merge_given", "merge_taken", "merge_exits", "merge_takes",
+                                                                 "passes_term", "passes_lamb", "passes_metal", "passes_diel", "slots_term", "slots_lamb", "drain_slowest", "drain_sum", "shared_entries_given", "path_len_hist")}, flush=True)
                 scene.set_pipeline(pseudo.get("PIPE", 0))
                 for _ in range(3):
                     scene.render_device(cam, opts, img.data_ptr(), None, stream)

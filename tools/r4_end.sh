@@ -3,7 +3,7 @@
 set -o pipefail
 TAG=$1; shift
 O=gpurun_out/r4; mkdir -p $O
-timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -k "${KEXPR:-taper or shared or pipelined or cfg1 or streamed}" > $O/pytest_$TAG.log 2>&1
+timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -k "${KEXPR:-merging or shared or pipelined or cfg1 or streamed}" > $O/pytest_$TAG.log 2>&1
 rc=$?; tail -3 $O/pytest_$TAG.log; echo "pytest rc=$rc"
 if [ $rc -ne 0 ]; then exit $rc; fi
 if [ -n "$BASELIB" ]; then
