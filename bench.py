@@ -60,6 +60,7 @@ CLOCK_GHZ = 2.4
 # kernel's static VALU mix (tools/static_cost.py: 62 % full-rate, 35 % of the 3.1 kind, 2 % transcendental) applied to the
 # counted instructions gives the AGGREGATE issue bound reported as roofline.issue_mix -- the bound this kernel runs
 # against (calibration: 100 extra v_add_f32 per traversal step cost 0.47 ms = 2.15 cycles each).
+INT_FULL_FRAC = 0.58  # of the binary's integer VALU instructions, those that issue at the full rate (add / sub / xor / and / or / shifts)
 ISSUE_COST = {"valu_mean": 0.62 * 2.0 + 0.355 * 3.1 + 0.025 * 6.1, "salu": 2.0, "lds": 6.0, "vmem": 4.0}
 
 
@@ -81,6 +82,14 @@ def parse_args():
                     help="which stand-in takes bunny.obj's place: the smooth blob (headline) or the rough one (uneven triangle "
                          "sizes, concavities, thin parts; rbrt_amd/standin.py) -- brackets the headline's sensitivity to geometry")
     ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
+    ap.add_argument("--config", choices=("2", "2r", "4", "4v"), default="2",
+                    help="BASELINE configuration: 2 = the headline (69,451-triangle stand-in); 2r = the same with the ROUGH stand-in; "
+                         "4 = the 871,414-triangle stand-in at the example scene's scale 45, where the reference's |a| >= 1e-3 rule "
+                         "(triangle.rs:198-200) rejects every triangle of so fine a mesh: the mesh is traversed and never hit; 4v = the "
+                         "same mesh at scale 450 (translation 50, -18, -145: the placement of the committed golden windows), where it is "
+                         "VISIBLE: the deep-BVH stress test (GPU-built tree, LDS stack overflow figures in roofline.lds_stack)")
+    ap.add_argument("--mesh-scale", type=float, default=None, help="overrides the scene file's mesh scale")
+    ap.add_argument("--mesh-translation", default=None, help="x,y,z: overrides the scene file's mesh translation")
     ap.add_argument("--cpu-col-stride", type=int, default=-1,
                     help="the CPU baseline renders every n-th image column (0 = skip the CPU baseline; 1 = the whole "
                          "frame; default: the largest power-of-two fraction of the columns estimated to fit --cpu-budget-s)")
@@ -105,6 +114,13 @@ def parse_args():
 
 def main():
     args = parse_args()
+    if args.config == "2r":
+        args.mesh = "rough"
+    elif args.config in ("4", "4v"):
+        args.triangles = 871414
+        if args.config == "4v":
+            args.mesh_scale = 450.0 if args.mesh_scale is None else args.mesh_scale
+            args.mesh_translation = args.mesh_translation or "50,-18,-145"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,6 +164,15 @@ def main():
     real_asset = Path("bunny.obj").exists() and args.triangles == standin.BUNNY_TRIANGLES and args.mesh == "smooth"
     obj = Path("bunny.obj").resolve() if real_asset else standin.ensure_obj(work / "bunny.obj", args.triangles, args.mesh)
     yaml_text = Path(args.scene).read_text().replace("obj_filepath: bunny.obj", f"obj_filepath: {obj}")
+    if args.mesh_scale is not None or args.mesh_translation:
+        import yaml
+        doc = yaml.safe_load(yaml_text)
+        for mb in doc.get("mesh_blueprints") or []:
+            if args.mesh_scale is not None:
+                mb["scale"] = float(args.mesh_scale)
+            if args.mesh_translation:
+                mb["translation"] = dict(zip("xyz", (float(v) for v in args.mesh_translation.split(","))))
+        yaml_text = "---\n" + yaml.safe_dump(doc, sort_keys=False)
     (work / "scene.yaml").write_text(yaml_text)
     devnull = os.open(os.devnull, os.O_WRONLY)  # the host prints the reference's progress lines
     saved = os.dup(1)
@@ -261,7 +286,9 @@ def main():
     scene.render_device(cam, stats_opts, scratch.data_ptr(), None, stream)
     torch.cuda.synchronize()
     st = scene.stats()
-    dbg = scene.debug_counters() if os.environ.get("RBRT_BENCH_DEBUG") else None
+    dbg_all = scene.debug_counters()
+    sinfo = scene.info()
+    dbg = dbg_all if os.environ.get("RBRT_BENCH_DEBUG") else None
     del scratch
 
     def max_over_ranks(x):
@@ -421,7 +448,17 @@ def main():
                 "kernel": "trace_megakernel", "kernel_ms": round(kernel_ms, 4), "kernel_ms_from": kernel_ms_from,
                 "kernel_ms_pipelined": round(pipelined_kernel_ms, 4), "launches_timed": n_launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "counters": {k: st[k] for k in ("rays", "mesh_gate_pass", "nodes_visited", "tris_tested", "mesh_hits")}}
+                "counters": {k: st[k] for k in ("rays", "mesh_gate_pass", "nodes_visited", "tris_tested", "mesh_hits")},
+                "per_sample": {"rays": round(st["rays"] / max(1, st["samples"]), 3), "nodes_visited": round(st["nodes_visited"] / max(1, st["samples"]), 3),
+                               "tris_tested": round(st["tris_tested"] / max(1, st["samples"]), 3),
+                               "nodes_per_traversal": round(st["nodes_visited"] / max(1, st["mesh_gate_pass"]), 2)},
+                # the per-lane traversal stack: kLdsStack entries in LDS, deeper ones exactly in a per-wave global scratch
+                "lds_stack": {"entries_in_lds": int(os.environ.get("RBRT_LDS_STACK", "8")) if os.environ.get("RBRT_HIP_LAB") == "1" else 8,
+                              "tree_stack_need": sinfo.get("bvh_stack_need"),
+                              "pushes_beyond_lds": dbg_all["stack_pushes_beyond_lds"],
+                              "pushes_beyond_lds_per_traversal": round(dbg_all["stack_pushes_beyond_lds"] / max(1, st["mesh_gate_pass"]), 5),
+                              "deepest_stack": dbg_all["stack_deepest"], "bvh_builder": "device" if sinfo.get("n_meshes_device_built") else "host",
+                              "bvh_nodes": sinfo.get("n_nodes")}}
     if iso is not None:
         roofline["isolated_leg"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in iso.items()}
     # The two figures that describe the kernel as it really runs come from rocprofv3 PMC passes (their own runs of
@@ -468,15 +505,29 @@ def main():
                                           "one_wave_cycles_per_inst": VALU_CYCLES_ONE_WAVE,
                                           "valu_lane_utilisation": rec.get("valu_lane_utilisation"), "source": src}
                 if rec.get("sq_insts_salu") and rec.get("sq_insts_lds") is not None:
-                    cyc = (rec["sq_insts_valu"] * ISSUE_COST["valu_mean"] + rec["sq_insts_salu"] * ISSUE_COST["salu"] +
+                    valu_mean, mix_from = ISSUE_COST["valu_mean"], "static mix of the binary (tools/static_cost.py): 62 % full-rate, 35.5 % other, 2.5 % transcendental"
+                    vm = rec.get("valu_mix")
+                    if vm and rec["sq_insts_valu"]:
+                        # the EXECUTED mix (rocprofv3 SQ_INSTS_VALU_* in the same summary): f32 add / mul / fma issue at the full
+                        # rate, transcendentals at 6.1 cycles, the integer classes at the full rate for INT_FULL_FRAC of them (the
+                        # share of add / xor / and / or / shift among the binary's integer instructions), everything else 3.1
+                        full = vm.get("add_f32", 0) + vm.get("mul_f32", 0) + vm.get("fma_f32", 0) + INT_FULL_FRAC * vm.get("int32", 0)
+                        trans = vm.get("trans_f32", 0)
+                        other = rec["sq_insts_valu"] - full - trans
+                        valu_mean = (full * 2.0 + other * 3.1 + trans * 6.1) / rec["sq_insts_valu"]
+                        mix_from = (f"executed mix (SQ_INSTS_VALU_*): {full / rec['sq_insts_valu']:.3f} full-rate, {other / rec['sq_insts_valu']:.3f} other, "
+                                    f"{trans / rec['sq_insts_valu']:.3f} transcendental")
+                    cyc = (rec["sq_insts_valu"] * valu_mean + rec["sq_insts_salu"] * ISSUE_COST["salu"] +
                            rec.get("sq_insts_lds", 0) * ISSUE_COST["lds"] + rec.get("sq_insts_vmem_rd", 0) * ISSUE_COST["vmem"])
                     mix_ms = cyc / 1024.0 / CLOCK_GHZ / 1e9 * 1e3
                     roofline["issue_mix"] = {"bound_ms": round(mix_ms, 3), "frac": round(mix_ms / kernel_ms, 4),
-                                             "cycles_per_class": {k: round(v, 3) for k, v in ISSUE_COST.items()},
+                                             "cycles_per_class": {**{k: round(v, 3) for k, v in ISSUE_COST.items()}, "valu_mean": round(valu_mean, 3)},
+                                             "valu_mix_from": mix_from,
                                              "insts": {"valu": rec["sq_insts_valu"], "salu": rec["sq_insts_salu"], "lds": rec.get("sq_insts_lds"),
                                                        "vmem_rd": rec.get("sq_insts_vmem_rd")},
                                              "what": "SIMD issue cycles of ALL instruction classes at their measured costs (profiles/r03_valu_rate.txt) "
-                                                     "/ 1024 SIMDs / 2.4 GHz: the bound that binds (the tree is served from L1/L2)"}
+                                                     "/ 1024 SIMDs / 2.4 GHz: the bound that binds (the tree is served from L1/L2); a model "
+                                                     "good to about one digit -- read it as ~0.8, not as three figures"}
 
     out = {
         "metric": "Mray-samples/sec (WxHxspp/s) on bunny scene; achieved HBM GB/s vs peak",
@@ -487,7 +538,10 @@ def main():
         "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"example_scene.yaml, {args.triangles}-triangle "
-                               f"{'bunny.obj' if real_asset else 'stand-in mesh' if args.mesh == 'smooth' else 'ROUGH stand-in mesh'}, {W}x{H}, {spp} spp, seed {args.seed}",
+                               f"{'bunny.obj' if real_asset else 'stand-in mesh' if args.mesh == 'smooth' else 'ROUGH stand-in mesh'}"
+                               f"{'' if args.mesh_scale is None else f' at scale {args.mesh_scale:g} (translation {args.mesh_translation})'}, "
+                               f"{W}x{H}, {spp} spp, seed {args.seed}",
+                   "baseline_config": args.config,
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
                    "pipeline": (f"{args.pipeline or 'auto: 3'} trace launches in flight, half-size grids while they overlap (consecutive steps overlap)")
                    if args.pipeline != 1 else "1 (no overlap between steps)",

@@ -19,7 +19,10 @@
  *   RBRT_BVH_DEVICE_MIN=<entries>, RBRT_BVH_DEVICE_ALGO=ploc|lbvh   RBRT_POISON_SAMPLES=1 (tests)
  *   RBRT_PRIMARY_CULL=0|1        the tile pass (1): tiles whose camera rays reach nothing bypass the trace kernel
  *   RBRT_TILE_ORDER=0|1|2        tiles handed out: as api.cpp decides (0), first-to-last (1), last-to-first (2)
- *   RBRT_TILE_CLASSES=0..3       work list ascending (0), or by tile class: heavy|light, light/2|heavy|light/2, light|heavy
+ *   RBRT_TILE_CLASSES=0..4       overrides the rule by launch kind: work list ascending (0), or by tile class: heavy|light,
+ *                                light/2|heavy|light/2, light|heavy, or (4) row-major order with its last light tiles moved to the end
+ *   RBRT_TILE_ISOLATED_MODE=0..4 the list mode of a launch that has the GPU to itself (4); a launch of a stream uses 0
+ *   RBRT_TILE_TAIL_DIV=1..1024   mode 4: the share of the work list (1/n, 8) that is handed out last, from light tiles
  */
 #ifndef RBRT_HIP_DEBUG_H
 #define RBRT_HIP_DEBUG_H

@@ -148,7 +148,7 @@ class HipScene:
                                     trav_steps=(int(buf[50]) >> 16) & 0xFFFF, passes=int(buf[50]) & 0xFFFF),
                  drain_sum=dict(rounds=int(buf[51]), trav_steps=int(buf[52]), passes=int(buf[53]),
                                 lane_steps=int(buf[54])),
-                 merge_given=int(buf[30]), merge_taken=int(buf[31]), merge_exits=int(buf[49]), merge_takes=int(buf[55]),
+                 stack_pushes_beyond_lds=int(buf[30]), stack_deepest=int(buf[31]),
                  shared_entries_given=int(buf[59]), share_rounds=int(buf[60]), traversals_ending_at_root=int(buf[61]),
                  sphere_tail_runs=int(buf[62]), sphere_tail_lanes=int(buf[63]))
         return d

@@ -118,12 +118,22 @@ struct rbrt_hip_scene {
     // caller's stream.
     struct Lane {
         hipStream_t stream = nullptr;  // null: the caller's stream (pipeline == 1)
-        float* d_sample_buf = nullptr;
-        size_t sample_buf_bytes = 0;
-        unsigned long long* d_work_counter = nullptr;
+        // ONE sample buffer + work counters per lane, and the lane's next launch waits for the resolve of its previous one.
+        // (Round 4 gave every lane a second set, taken in turn, so that the next launch could start the moment the previous
+        // one ended instead of 90-120 us later -- resolve and background kernel on the caller's stream, a cross-stream hop
+        // each way, profiles/r04_trace_eighths.txt. It was SLOWER: pipelined frame 3.60 -> 3.83 ms. The new launch's waves
+        // take every slot the old one frees before the resolve is even runnable, and the resolve -- 20 us of work -- then
+        // waits hundreds of microseconds for waves of the OTHER launch to exit, with every later resolve queued behind
+        // it on the caller's stream. The gap is the window the short kernels run in.)
+        struct Buf {
+            float* d_sample_buf = nullptr;
+            size_t sample_buf_bytes = 0;
+            unsigned long long* d_work_counter = nullptr;
+            hipEvent_t ev_resolved = nullptr;
+            bool in_use = false;  // ev_resolved has been recorded at least once
+        } bufs[1];
         uint32_t* d_gseq = nullptr;
         uint32_t* d_gstack = nullptr;
-        unsigned long long* d_merge_ring = nullptr;  // the drain's rings of path records (only when merging is on)
         // The tile pass (kernels.hip primary_cull_kernel + tile_lists_kernel): which of the rank's tiles see only the
         // background, for one camera and tile partition (`key`). A lane has TWO sets of tables: the pass for a camera the
         // lane has not seen is issued when the CALL is made, on the scene's high-priority `prep_stream`, into the set the
@@ -133,6 +143,7 @@ struct rbrt_hip_scene {
         struct TileKey {
             rbrt_camera_t cam;
             uint32_t rank, world;
+            uint32_t list_mode;  // the order of the work list (tile_lists_kernel): by the kind of launch, list_mode_for()
         };
         struct TileSet {
             uint32_t* d_cull = nullptr;    // [n_tiles]
@@ -145,8 +156,8 @@ struct rbrt_hip_scene {
             uint64_t last_used = 0;        // launch number (scene-wide) of the last launch that read the set
         } tiles[2];
         size_t tile_cull_words = 0, tile_lists_words = 0;
-        hipEvent_t ev_traced = nullptr, ev_resolved = nullptr;
-        bool in_use = false;  // ev_resolved has been recorded at least once
+        hipEvent_t ev_traced = nullptr;
+        bool in_use = false;  // ev_traced has been recorded at least once
     };
     std::vector<Lane> lanes;
     hipStream_t prep_stream = nullptr;  // high priority: the tile passes of cameras the lanes have not seen
@@ -183,16 +194,14 @@ struct rbrt_hip_scene {
     // -2.7 %, an eighth -2.8 %, a 512x384 frame -2.5 %
     uint32_t work_stripes_overlap = kStripesAuto;
     uint32_t tile_classes = 0;    // RBRT_TILE_CLASSES (order of the work list by tile class, tile_lists_kernel)
+    bool tile_classes_set = false;  // ... given: it overrides the rule of list_mode_for()
+    bool trace_launches = false;    // RBRT_TRACE_LAUNCHES=1 (lab): one stderr line per trace launch and per tile pass
+    uint32_t isolated_list_mode = 4;  // RBRT_TILE_ISOLATED_MODE: the list mode of a launch that has the GPU to itself
+    uint32_t tile_tail_div = 8;       // RBRT_TILE_TAIL_DIV (mode 4)
     uint32_t tile_order = 0;      // RBRT_TILE_ORDER (0: empty_end_is_first decides; 1: first-to-last; 2: last-to-first)
     uint32_t primary_cull = 1;    // RBRT_PRIMARY_CULL (0: no tile pass, the trace kernel renders every tile)
     uint32_t shade_rounds = 1;    // RBRT_SHADE_ROUNDS (rounds while work items are left; unbounded afterwards)
     uint32_t shade_cont_min = 8;  // RBRT_SHADE_CONT_MIN
-    // the end of a launch (megakernel.inl "merging")
-    uint32_t merge_low = 0;          // RBRT_MERGE_LOW: a draining wave with fewer parked paths than this writes them out and exits (0: off)
-    uint32_t merge_take_min = 16;    // RBRT_MERGE_TAKE_MIN: free slots a wave that goes on needs to take records
-    uint32_t merge_empty_takes = 1;  // RBRT_MERGE_EMPTY_TAKES: a wave that ran empty stays when a pass's worth of records waits
-    uint32_t merge_isolated = 1;     // RBRT_MERGE_ISOLATED: 0 = a launch that has the GPU to itself does not merge
-    uint32_t merge_token = 0;        // tag of the last launch's ring records
     // stats / timing
     rbrt_hip_stats_t stats{};
     bool stats_pending = false;
@@ -294,17 +303,32 @@ uint32_t grid_for(const rbrt_hip_scene* s, bool overlapped) {
     return half < s->n_waves ? half : s->n_waves;
 }
 
+// In which order a launch's tiles are handed out (tile_lists_kernel's modes), by what KIND of launch it is -- a rule, not a
+// setting made on one frame (measured on five workloads, DESIGN.md section 6 "In which order the work list is handed out"):
+// a launch that has the GPU to itself (a blocking caller) ends with every wave finishing what it holds and nothing behind
+// it, so its HEAVY tiles -- a mesh box or more than one sphere in reach -- go out first and the launch drains on light
+// ones (mode 1: isolated launch of the 871k mesh 6.36 -> 5.00 ms, the rough stand-in 6.31 -> 6.11, an eighth 1.21 -> 1.11;
+// the example frame, whose row-major order happens to end on its thin horizon band, 4.04 -> 4.17); a launch issued into
+// a stream of launches keeps the image's row-major order (mode 0: within 1.5 % of the best order on all five, and the
+// best on three -- the next launch's bulk fills whatever the drain leaves).
+uint32_t list_mode_for(const rbrt_hip_scene* s, bool overlapped) {
+    if (s->tile_classes_set) return s->tile_classes;
+    return overlapped ? 0u : s->isolated_list_mode;
+}
+
 // Brings s->lanes to `depth` entries (streams, events, counters and per-wave scratch of each lane).
 int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
     const size_t had = s->lanes.size();
     while (s->lanes.size() < depth) {
         rbrt_hip_scene::Lane L;
         void* p = nullptr;
-        const size_t counter_bytes = sizeof(unsigned long long) * kWorkCounterWords;  // work counters + the merge rings' control lines
-        HIP_TRY(hipMalloc(&p, counter_bytes));
-        s->allocs.push_back(p);
-        L.d_work_counter = static_cast<unsigned long long*>(p);
-        HIP_TRY(hipMemset(p, 0, counter_bytes));
+        const size_t counter_bytes = sizeof(unsigned long long) * kWorkShards * kWorkCounterStride;
+        for (auto& B : L.bufs) {
+            HIP_TRY(hipMalloc(&p, counter_bytes));
+            s->allocs.push_back(p);
+            B.d_work_counter = static_cast<unsigned long long*>(p);
+            HIP_TRY(hipMemset(p, 0, counter_bytes));
+        }
         HIP_TRY(hipMalloc(&p, megakernel_gseq_bytes(s->scratch_waves)));
         s->allocs.push_back(p);
         L.d_gseq = static_cast<uint32_t*>(p);
@@ -312,13 +336,6 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
         s->allocs.push_back(p);
         L.d_gstack = static_cast<uint32_t*>(p);
-        if (s->merge_low != 0u) {  // (tags of an earlier life of this memory must not look like a launch's: cleared once)
-            const size_t ring_bytes = size_t(kWorkShards) * kMergeRingRecords * kMergeGranules * sizeof(unsigned long long);
-            HIP_TRY(hipMalloc(&p, ring_bytes));
-            s->allocs.push_back(p);
-            L.d_merge_ring = static_cast<unsigned long long*>(p);
-            HIP_TRY(hipMemset(p, 0, ring_bytes));
-        }
         // the lane is recorded before its stream and events exist, so that a failure below leaves them to
         // rbrt_hip_scene_destroy instead of leaking them (a lane without a stream is never selected: the caller
         // gets the error)
@@ -332,11 +349,13 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         if (const char* pe = lab_env("RBRT_LANE_PRIORITY")) prio_low = !std::strcmp(pe, "default") ? 0 : !std::strcmp(pe, "high") ? prio_high : prio_low;
         hipError_t e = hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, prio_low);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_traced, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_resolved, hipEventDisableTiming);
+        for (auto& B : R.bufs)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&B.ev_resolved, hipEventDisableTiming);
         if (e != hipSuccess) {
             if (R.stream) (void)hipStreamDestroy(R.stream);
             if (R.ev_traced) (void)hipEventDestroy(R.ev_traced);
-            if (R.ev_resolved) (void)hipEventDestroy(R.ev_resolved);
+            for (auto& B : R.bufs)
+                if (B.ev_resolved) (void)hipEventDestroy(B.ev_resolved);
             s->lanes.pop_back();
             return fail(RBRT_ERR_HIP, std::string("pipeline lane: ") + hipGetErrorString(e));
         }
@@ -677,10 +696,11 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             lab_u32("RBRT_SHADE_ROUNDS", 1, kMaxShadeRounds, s->shade_rounds, err) &&
             lab_u32("RBRT_SHADE_CONT_MIN", 1, 64, s->shade_cont_min, err) && lab_u32("RBRT_PIPELINE", 0, kMaxPipeline, s->pipeline, err) &&
             lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err) && lab_u32("RBRT_PRIMARY_CULL", 0, 1, s->primary_cull, err) &&
-            lab_u32("RBRT_TILE_ORDER", 0, 2, s->tile_order, err) && lab_u32("RBRT_TILE_CLASSES", 0, 3, s->tile_classes, err) &&
-            lab_u32("RBRT_MERGE_LOW", 0, 128, s->merge_low, err) && lab_u32("RBRT_MERGE_TAKE_MIN", 1, 128, s->merge_take_min, err) &&
-            lab_u32("RBRT_MERGE_EMPTY_TAKES", 0, 1, s->merge_empty_takes, err) && lab_u32("RBRT_MERGE_ISOLATED", 0, 1, s->merge_isolated, err);
+            lab_u32("RBRT_TILE_ORDER", 0, 2, s->tile_order, err) && lab_u32("RBRT_TILE_CLASSES", 0, 4, s->tile_classes, err) &&
+            lab_u32("RBRT_TILE_ISOLATED_MODE", 0, 4, s->isolated_list_mode, err) && lab_u32("RBRT_TILE_TAIL_DIV", 1, 1024, s->tile_tail_div, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
+        s->tile_classes_set = lab_env("RBRT_TILE_CLASSES") != nullptr;
+        s->trace_launches = lab_env("RBRT_TRACE_LAUNCHES") != nullptr;
         if ((stripes & (stripes - 1u)) != 0u || (stripes_overlap != kStripesAuto && (stripes_overlap & (stripes_overlap - 1u)) != 0u))  // the kernel shifts
             return bail(fail(RBRT_ERR_INVALID_ARG, "lab knob RBRT_WORK_STRIPES / RBRT_WORK_STRIPES_OVERLAP must be 0 or a power of two"));
         s->work_stripes = stripes, s->work_stripes_overlap = stripes_overlap;
@@ -710,8 +730,10 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     for (auto& L : s->lanes) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
         if (L.ev_traced) (void)hipEventDestroy(L.ev_traced);
-        if (L.ev_resolved) (void)hipEventDestroy(L.ev_resolved);
-        if (L.d_sample_buf) (void)hipFree(L.d_sample_buf);
+        for (auto& B : L.bufs) {
+            if (B.ev_resolved) (void)hipEventDestroy(B.ev_resolved);
+            if (B.d_sample_buf) (void)hipFree(B.d_sample_buf);
+        }
         for (auto& T : L.tiles) {
             if (T.d_cull) (void)hipFree(T.d_cull);
             if (T.d_lists) (void)hipFree(T.d_lists);
@@ -834,6 +856,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.tiles_x_magic = div_magic_of(tiles_x);
     P.tiles_reversed = empty_end_is_first(s, *cam, tiles_x, o->tile_rank, world, n_local) ? 1u : 0u;
     if (s->tile_order != 0u) P.tiles_reversed = s->tile_order - 1u;  // (lab knob)
+    const uint32_t rowmajor_reversed = P.tiles_reversed;  // (a launch whose list is in class order resets it; the next batch may not)
     P.tile_rank = o->tile_rank, P.tile_world = world, P.n_local_tiles = n_local;
     P.stack_entries = s->stack_entries;
     P.y_low_water = s->y_low_water;
@@ -846,8 +869,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     P.work_stripes = s->work_stripes;  // (per launch: set where the launch's size is known)
     P.shade_rounds = s->shade_rounds;
     P.shade_cont_min = s->shade_cont_min;
-    P.merge_low = 0u, P.merge_take_min = s->merge_take_min, P.merge_empty_takes = s->merge_empty_takes;
-    P.merge_token = 0u, P.merge_ctl = nullptr, P.merge_ring = nullptr;
+    P.tile_tail_div = s->tile_tail_div;
 
     ResolveParams R;
     std::memset(&R, 0, sizeof(R));
@@ -875,15 +897,16 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     const size_t lists_need = size_t(kTileListHeader) + 2u * size_t(n_local);
     for (uint32_t li = 0; li < depth; ++li) {
         rbrt_hip_scene::Lane& L = s->lanes[li];
-        if (need > L.sample_buf_bytes) {
-            if (L.d_sample_buf) {
+        for (auto& B : L.bufs) {
+            if (need <= B.sample_buf_bytes) continue;
+            if (B.d_sample_buf) {
                 if (int rc = sync_lanes()) return rc;
-                HIP_TRY(hipFree(L.d_sample_buf));
-                L.d_sample_buf = nullptr, L.sample_buf_bytes = 0;
+                HIP_TRY(hipFree(B.d_sample_buf));
+                B.d_sample_buf = nullptr, B.sample_buf_bytes = 0;
             }
             void* p = nullptr;
             HIP_TRY(hipMalloc(&p, need));
-            L.d_sample_buf = static_cast<float*>(p), L.sample_buf_bytes = need;
+            B.d_sample_buf = static_cast<float*>(p), B.sample_buf_bytes = need;
         }
         if (tile_pass && (n_tiles > L.tile_cull_words || lists_need > L.tile_lists_words)) {
             if (L.tiles[0].d_cull || L.tiles[0].d_lists) {
@@ -918,7 +941,9 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         fill_trace_params(s, cam, o, T);
         T.tiles_x = tiles_x, T.tiles_y = tiles_y, T.n_tiles = n_tiles;
         T.tile_rank = o->tile_rank, T.tile_world = world, T.n_local_tiles = n_local;
-        T.tile_list_mode = s->tile_classes;
+        T.tile_list_mode = list_mode_for(s, true);  // (what the launches of a stream use; an isolated launch makes its own list)
+        T.tile_tail_div = s->tile_tail_div;
+        T.tiles_reversed = P.tiles_reversed;
         for (uint32_t li = 0; li < depth; ++li) {
             rbrt_hip_scene::Lane& L = s->lanes[li];
             if (L.tiles[0].key_valid || L.tiles[1].key_valid) continue;
@@ -927,8 +952,21 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             HIP_TRY(launch_primary_cull(T, stream));
             HIP_TRY(hipEventRecord(S.ev_lists, stream));
             std::memset(&S.key, 0, sizeof(S.key));
-            S.key.cam = *cam, S.key.rank = o->tile_rank, S.key.world = world;
+            S.key.cam = *cam, S.key.rank = o->tile_rank, S.key.world = world, S.key.list_mode = T.tile_list_mode;
             S.key_valid = true;
+            // (the lane this call's first launch takes: if that launch finds the GPU idle it wants the isolated launch's list
+            // as well -- made here too, it does not have to wait for the prep stream while the launches behind it pile up)
+            const uint32_t iso_mode = list_mode_for(s, false);
+            if (li == s->next_lane % depth && iso_mode != T.tile_list_mode) {
+                rbrt_hip_scene::Lane::TileSet& S1 = L.tiles[1];
+                TraceParams T1 = T;
+                T1.tile_list_mode = iso_mode;
+                T1.tile_cull = S1.d_cull, T1.tile_lists = S1.d_lists;
+                HIP_TRY(launch_primary_cull(T1, stream));
+                HIP_TRY(hipEventRecord(S1.ev_lists, stream));
+                S1.key = S.key, S1.key.list_mode = iso_mode;
+                S1.key_valid = true;
+            }
         }
     }
     const size_t ev0 = s->events_used;
@@ -939,9 +977,10 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         rbrt_hip_scene::Lane& L = s->lanes[stats ? 0 : s->next_lane++ % depth];
         const bool piped = depth > 1 && !stats;
         hipStream_t ts = piped ? L.stream : stream;  // the trace launch's stream
+        rbrt_hip_scene::Lane::Buf& B = L.bufs[0];
         if (piped) {
-            // this lane's sample buffer is free once the resolve of its previous launch has run
-            if (L.in_use) HIP_TRY(hipStreamWaitEvent(L.stream, L.ev_resolved, 0));
+            // the lane's sample buffer and counters are free once the resolve of its previous launch has run
+            if (B.in_use) HIP_TRY(hipStreamWaitEvent(L.stream, B.ev_resolved, 0));
         } else if (depth > 1) {
             if (int rc = sync_lanes()) return rc;  // a counting launch: nothing else in flight
         }
@@ -957,27 +996,18 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.work_stripes = !overlapped ? s->work_stripes
                          : s->work_stripes_overlap != kStripesAuto ? s->work_stripes_overlap
                          : P.n_items < 20000000ull ? 4u : 0u;
-        P.sample_buf = L.d_sample_buf;
-        P.work_counter = L.d_work_counter;
+        P.sample_buf = B.d_sample_buf;
+        P.work_counter = B.d_work_counter;
         P.gseq = L.d_gseq;
         P.gstack = L.d_gstack;
-        if (L.d_merge_ring && (s->merge_isolated != 0u || overlapped)) {
-            // (the control lines sit behind the work counters and are zeroed with them; a token is never 0 and is not used
-            // again before 2^32 - 1 launches of this scene have passed)
-            if (++s->merge_token == 0u) s->merge_token = 1u;
-            P.merge_low = s->merge_low, P.merge_token = s->merge_token;
-            P.merge_ctl = L.d_work_counter + kWorkShards * kWorkCounterStride;
-            P.merge_ring = L.d_merge_ring;
-        } else {
-            P.merge_low = 0u, P.merge_ctl = nullptr, P.merge_ring = nullptr;
-        }
         // which of the lane's two sets of tile tables this launch reads: the one made for this camera and partition, else
         // the one used longer ago, filled now
         rbrt_hip_scene::Lane::TileSet* S = nullptr;
         if (tile_pass) {
             rbrt_hip_scene::Lane::TileKey key;
             std::memset(&key, 0, sizeof(key));
-            key.cam = *cam, key.rank = o->tile_rank, key.world = world;
+            const uint32_t list_mode = list_mode_for(s, overlapped && !stats);
+            key.cam = *cam, key.rank = o->tile_rank, key.world = world, key.list_mode = list_mode;
             for (auto& C : L.tiles)
                 if (C.key_valid && std::memcmp(&key, &C.key, sizeof(key)) == 0) S = &C;
             if (!S) {
@@ -987,28 +1017,35 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
                 if (S->free_recorded) HIP_TRY(hipStreamWaitEvent(s->prep_stream, S->ev_free, 0));
                 if (S->key_valid) HIP_TRY(hipStreamWaitEvent(s->prep_stream, S->ev_lists, 0));
                 P.tile_cull = S->d_cull, P.tile_lists = S->d_lists;
-                P.tile_list_mode = s->tile_classes;
+                P.tile_list_mode = list_mode;
+                P.tiles_reversed = rowmajor_reversed;  // (mode 4 builds its list in the direction row-major order is handed out in)
                 HIP_TRY(launch_primary_cull(P, s->prep_stream));
                 HIP_TRY(hipEventRecord(S->ev_lists, s->prep_stream));
                 S->key = key, S->key_valid = true;
+                if (s->trace_launches) std::fprintf(stderr, "[rbrt_hip] tile pass on the prep stream: lane %u set %d list_mode %u\n",
+                                                    unsigned(&L - s->lanes.data()), int(S - L.tiles), list_mode);
             }
             S->last_used = ++s->launch_no;
+            if (s->trace_launches)
+                std::fprintf(stderr, "[rbrt_hip] launch %llu lane %u %s grid list_mode %u set %d\n", (unsigned long long)s->launch_no,
+                             unsigned(&L - s->lanes.data()), overlapped ? "half" : "full", S->key.list_mode, int(S - L.tiles));
         }
         P.tile_cull = S ? S->d_cull : nullptr;
         P.tile_lists = S ? S->d_lists : nullptr;
-        P.tile_list_mode = s->tile_classes;
-        if (tile_pass && s->tile_classes != 0u) P.tiles_reversed = 0u;  // (the list is in hand-out order already)
-        // (L.d_work_counter is zero: from its allocation, afterwards from the resolve kernel of the lane's last launch)
+        P.tile_list_mode = S ? S->key.list_mode : 0u;
+        if (S && S->key.list_mode != 0u) P.tiles_reversed = 0u;  // (the list is in hand-out order already)
+        else if (S) P.tiles_reversed = rowmajor_reversed;
+        // (B.d_work_counter is zero: from its allocation, afterwards from the resolve kernel of the launch that used the set last)
         // RBRT_POISON_SAMPLES=1 (tests): a (pixel, sample) the kernel fails to write shows up as NaN in the image
-        if (s->poison_samples) HIP_TRY(hipMemsetAsync(L.d_sample_buf, 0xFF, L.sample_buf_bytes, ts));
+        if (s->poison_samples) HIP_TRY(hipMemsetAsync(B.d_sample_buf, 0xFF, B.sample_buf_bytes, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
         if (S) HIP_TRY(hipStreamWaitEvent(ts, S->ev_lists, 0));  // (the set's tables: made on the prep stream, or at the first call on the caller's)
         const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped);
         (grid < s->n_waves ? s->n_half_grid : s->n_full_grid) += 1;
         HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, s->share_idle != 0u && P.n_items < s->share_below, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
-        R.sample_buf = L.d_sample_buf;
-        R.work_counter = L.d_work_counter;
+        R.sample_buf = B.d_sample_buf;
+        R.work_counter = B.d_work_counter;
         R.batch = nb;
         R.first_batch = base == 0;
         R.last_batch = base + nb == o->spp;
@@ -1016,6 +1053,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         R.counters = stats ? s->d_counters : nullptr;
         if (piped) {
             HIP_TRY(hipEventRecord(L.ev_traced, ts));
+            L.in_use = true;
             HIP_TRY(hipStreamWaitEvent(stream, L.ev_traced, 0));
         }
         HIP_TRY(launch_resolve(R, stream));
@@ -1029,8 +1067,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             S->free_recorded = true;
         }
         if (depth > 1) {  // (also after a counting launch: it used lane 0's buffers on the caller's stream)
-            HIP_TRY(hipEventRecord(L.ev_resolved, stream));
-            L.in_use = true;
+            HIP_TRY(hipEventRecord(B.ev_resolved, stream));
+            B.in_use = true;
         }
         if (timing) {
             HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 2], stream));

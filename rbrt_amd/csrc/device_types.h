@@ -8,7 +8,17 @@ namespace rbrt {
 
 // Compile-time limits.
 constexpr uint32_t kTileListHeader = 4;  // words ahead of the lists in TraceParams::tile_lists
-constexpr int kBlock = 256;          // threads per workgroup of the simple kernels (resolve, unpack, trace_rays)
+constexpr int kBlock = 256;          // threads per workgroup of the test hooks' kernels
+// Threads per workgroup of the short kernels that run BESIDE resident trace launches (resolve, sky_resolve, unpack, the tile
+// pass): ONE wave. The persistent trace waves hold every wave slot and all of every CU's LDS until they exit, one by one; a
+// 256-thread workgroup needs FOUR free slots on one CU at once, and a kernel on a higher-priority stream whose workgroups do
+// not fit makes the dispatcher keep what frees up for it instead of handing it to the next trace launch's waves. Round 4's
+// kernel trace (profiles/r04_trace_frames.txt): the resolve -- 50 us of work -- took 3.0-3.4 ms in EVERY frame of a stream,
+// its lane waiting for it all the while. A one-wave workgroup runs in any slot a trace wave leaves.
+#ifndef RBRT_SMALL_BLOCK
+#define RBRT_SMALL_BLOCK 64
+#endif
+constexpr int kSmallBlock = RBRT_SMALL_BLOCK;
 constexpr int kMaxBvhDepth = 20;     // deepest 4-wide node (root = 0) the builder may create
 constexpr int kStackMax = 3 * (kMaxBvhDepth + 1) + 1;  // a visit defers at most 3 children per level
 constexpr int kMaxPathDepth = 64;    // opts.max_depth limit (reference: 50, lib.rs:99)
@@ -21,14 +31,6 @@ constexpr int kLeafMax = 1 << kLeafBits;   // triangles per leaf
 constexpr int kPoolMax = 256;        // largest path pool per wave the persistent megakernel is built for
 constexpr uint32_t kWorkShards = 8;         // work-item counters (one per XCD)
 constexpr uint32_t kWorkCounterStride = 16;  // in u64: each counter on its own 128-B line
-// Merging the thin ends of the waves (megakernel.inl "merging"): per XCD one control line behind the work counters (zeroed
-// with them by the resolve kernel) and one ring of path records that a wave whose pool has thinned out writes before it
-// exits, for the waves that go on to take (giver and taker share an L2; no word is touched by more than one XCD's waves).
-constexpr uint32_t kMergeCtlWords = 16;                                     // u64 words per XCD: one 128-B line
-constexpr uint32_t kWorkCounterWords = kWorkShards * (kWorkCounterStride + kMergeCtlWords);  // the lane's counter block
-// u64 word 0 of a control line: (waves of the XCD still running << 32) | records reserved; word 1: records taken
-constexpr uint32_t kMergeGranules = 32;     // 8-byte {tag, value} granules per record: 13 fields, status, <= 16 bounce words
-constexpr uint32_t kMergeRingRecords = 32768;  // records per XCD's ring (8 x 8 MiB per pipeline lane); a full ring stops the giving
 constexpr uint32_t kMaxShadeRounds = 64;  // hard bound of register-resident shading rounds per pass
 constexpr int kLdsStack = 8;         // per-lane traversal stack entries kept in LDS by the megakernel; deeper
                                      // entries spill (exactly) to a per-wave global scratch
@@ -157,13 +159,7 @@ struct TraceParams {
     uint32_t* tile_cull;
     uint32_t* tile_lists;
     uint32_t tile_list_mode;  // order of the work list (tile_lists_kernel)
-    // The end of a launch (megakernel.inl "merging").
-    uint32_t merge_low;         // a wave out of work items whose pool holds fewer paths than this, all parked, writes them out and exits (0: off)
-    uint32_t merge_take_min;    // a wave that goes on takes records when it has at least this many free slots
-    uint32_t merge_empty_takes; // 1: a wave that has run empty stays when merge_low or more records are waiting (0: only the last one of its XCD does)
-    uint32_t merge_token;       // tag of this launch's records in the rings (never 0, never reused while the rings live)
-    unsigned long long* merge_ctl;   // [kWorkShards][kMergeCtlWords]; zero at launch
-    unsigned long long* merge_ring;  // [kWorkShards][kMergeRingRecords][kMergeGranules]
+    uint32_t tile_tail_div;   // mode 4: the last n_work / this light tiles of the row-major order are handed out at the very end
 };
 
 struct ResolveParams {

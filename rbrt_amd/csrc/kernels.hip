@@ -338,6 +338,7 @@ constexpr uint32_t kMissKey = 0xFFFFFFFFu;
 // empty box (lo = +inf, hi = -inf: its entry parameter is +inf or NaN on every axis, its exit parameter -inf or
 // NaN) and misses unless all six are NaN, i.e. unless the ray itself is degenerate -- those rays never get here
 // (ray_is_traversable below).
+template <bool SLOT_BITS = true>
 __device__ __forceinline__ uint32_t child_key(float nx, float ny, float nz, float fx, float fy, float fz, V3 inv, V3 nodn,
                                               V3 nodf, float eps, float best_t, uint32_t slot) {
     const float tnx = __builtin_fmaf(nx, inv.x, nodn.x);
@@ -348,7 +349,9 @@ __device__ __forceinline__ uint32_t child_key(float nx, float ny, float nz, floa
     const float tfz = __builtin_fmaf(fz, inv.z, nodf.z);
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), eps);
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), best_t);
-    return tn <= tf ? ((__float_as_uint(tn) & ~3u) | slot) : kMissKey;
+    // (tn >= eps > 0: the integer order of its bits is its order; a caller that sorts the links along with the keys has no
+    // use for the slot number in the low bits)
+    return tn <= tf ? (SLOT_BITS ? ((__float_as_uint(tn) & ~3u) | slot) : __float_as_uint(tn)) : kMissKey;
 }
 // A ray the slab arithmetic above can be trusted with: finite origin, finite non-zero direction. Anything else gets
 // no mesh hit at all, which is what the reference's ordered compares give it (triangle.rs:190-241: every NaN compare
@@ -366,7 +369,7 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {
 
 // Fetch one 128-B node (8 x dwordx4 by this lane) and test its four children; k[] comes back sorted by
 // entry distance (misses last) -- or, with SORTED = false, in slot order --, links = the four child links.
-template <bool SORTED = true>
+template <bool SORTED = true, bool SLOT_BITS = true>
 __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull& rc, float eps, float best_t,
                                             uint32_t k[4], f32x4& links) {
     const char* nb = reinterpret_cast<const char*>(node);
@@ -383,10 +386,10 @@ __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull&
     // which only makes the test more permissive)
     const V3 pt = mk(pad * __builtin_fabsf(rc.inv.x), pad * __builtin_fabsf(rc.inv.y), pad * __builtin_fabsf(rc.inv.z));
     const V3 nodn = rc.nod - pt, nodf = rc.nod + pt;
-    k[0] = child_key(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, rc.inv, nodn, nodf, eps, best_t, 0u);
-    k[1] = child_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, rc.inv, nodn, nodf, eps, best_t, 1u);
-    k[2] = child_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, rc.inv, nodn, nodf, eps, best_t, 2u);
-    k[3] = child_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, rc.inv, nodn, nodf, eps, best_t, 3u);
+    k[0] = child_key<SLOT_BITS>(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, rc.inv, nodn, nodf, eps, best_t, 0u);
+    k[1] = child_key<SLOT_BITS>(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, rc.inv, nodn, nodf, eps, best_t, 1u);
+    k[2] = child_key<SLOT_BITS>(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, rc.inv, nodn, nodf, eps, best_t, 2u);
+    k[3] = child_key<SLOT_BITS>(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, rc.inv, nodn, nodf, eps, best_t, 3u);
     if (SORTED) {
         cswap(k[0], k[1]);
         cswap(k[2], k[3]);
@@ -394,6 +397,33 @@ __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull&
         cswap(k[1], k[3]);
         cswap(k[1], k[2]);
     }
+}
+// The same visit with the child LINKS sorted along with the keys (round 4). Sorting the keys alone costs two
+// instructions per compare-exchange (v_min_u32 + v_max_u32), but every link then has to be picked out of four registers
+// by the slot number in its key's low bits: and + 3 x (v_cmp, v_cndmask) = 7 VALU instructions and, with the compares
+// writing VCC right ahead of the selects that read it, three s_nop each -- 28 + 12 per visit for the four links. A
+// compare-exchange that carries the link along is one compare and four selects: 25 for the five exchanges, against
+// 10 + 28, and five VCC hazards instead of twelve. Which child is walked first cannot change what is found (the tree only
+// culls; the result cell keeps the lexicographic (t, index) minimum), so equal keys may come out in either order.
+#ifndef RBRT_PAIR_SORT
+#define RBRT_PAIR_SORT 1
+#endif
+__device__ __forceinline__ void cswap_pair(uint32_t& ka, uint32_t& kb, int32_t& la, int32_t& lb) {
+    const bool sw = kb < ka;
+    const uint32_t k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int32_t l0 = sw ? lb : la, l1 = sw ? la : lb;
+    ka = k0, kb = k1, la = l0, lb = l1;
+}
+__device__ __forceinline__ void node4_visit_sorted(const BvhNode4* node, const RayCull& rc, float eps, float best_t,
+                                                   uint32_t k[4], int32_t l[4]) {
+    f32x4 links;
+    node4_visit<false, false>(node, rc, eps, best_t, k, links);
+    l[0] = __float_as_int(links.x), l[1] = __float_as_int(links.y), l[2] = __float_as_int(links.z), l[3] = __float_as_int(links.w);
+    cswap_pair(k[0], k[1], l[0], l[1]);
+    cswap_pair(k[2], k[3], l[2], l[3]);
+    cswap_pair(k[0], k[2], l[0], l[2]);
+    cswap_pair(k[1], k[3], l[1], l[3]);
+    cswap_pair(k[1], k[2], l[1], l[2]);
 }
 __device__ __forceinline__ int32_t link_of(const f32x4& links, uint32_t key) {
     const uint32_t s = key & 3u;
@@ -667,14 +697,14 @@ __device__ __forceinline__ void resolve_store(const ResolveParams& R, size_t j, 
 // Sequential per-pixel sum over the samples of this batch (lib.rs:95-100 adds them in sample
 // order; keeping that order keeps the mean bit-identical), then on the last batch the multiply by
 // 1/spp (lib.rs:101) and the optional quantisation.
-__global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) {
+__global__ __launch_bounds__(kSmallBlock) void resolve_kernel(const ResolveParams R) {
     // (with a tile pass the launch rendered the tiles of the work list only; the grid covers all of the rank's)
     const size_t npix = size_t(R.tile_lists ? R.tile_lists[0] : R.n_local_tiles) * 64u;
-    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t i = size_t(blockIdx.x) * kSmallBlock + threadIdx.x;
     // the trace launch this resolves has ended: its work counters are reset for the lane's next launch (which
     // waits for this kernel), saving a memset launch that would have to queue behind the resident megakernels
-    static_assert(kWorkCounterWords <= kBlock, "one thread per counter word");
-    if (blockIdx.x == 0 && threadIdx.x < kWorkCounterWords) R.work_counter[threadIdx.x] = 0ull;  // (the merge rings' control lines too)
+    if (blockIdx.x == 0)
+        for (uint32_t w = threadIdx.x; w < kWorkShards * kWorkCounterStride; w += kSmallBlock) R.work_counter[w] = 0ull;
     if (i >= npix) return;
     const uint32_t p = uint32_t(i & 63u);
     const uint32_t tile_local = R.tile_lists ? R.tile_lists[kTileListHeader + (i >> 6)] : uint32_t(i >> 6);
@@ -704,8 +734,8 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const ResolveParams R) 
 // pixel is one camera ray that hits nothing (cam.rs:64-82, lib.rs:68-71), so its batch is generated, summed in sample
 // order and stored right here -- the same streams, the same arithmetic, the same order as the trace kernel followed by
 // resolve_kernel would produce -- and the trace kernel never sees these tiles. One thread per pixel.
-__global__ __launch_bounds__(kBlock) void sky_resolve_kernel(const TraceParams P, const ResolveParams R) {
-    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kSmallBlock) void sky_resolve_kernel(const TraceParams P, const ResolveParams R) {
+    const size_t i = size_t(blockIdx.x) * kSmallBlock + threadIdx.x;
     if (i >= size_t(R.tile_lists[1]) * 64u) return;
     const uint32_t p = uint32_t(i & 63u);
     const uint32_t tile_local = R.tile_lists[kTileListHeader + R.n_local_tiles + (i >> 6)];
@@ -778,7 +808,8 @@ __global__ __launch_bounds__(kBlock) void sky_resolve_kernel(const TraceParams P
 // against its exact value 4 (r^2 - m^2), m the distance of the line from the centre: a line is taken for a hit at most
 // 0.7e-6 (|l|^2 + r^2) / r outside the sphere, and a line more than that inside has a discriminant above zero. Radii are
 // inflated (deflated) by 1e-5 (|l|^2 + r^2) / r, 15x that, plus 1e-5 r + 1e-6 |l|; angles are widened by the direction
-// error, the pixel interval by 1e-3 pixel plus the rounding of (col_off + u) - 0.5. (A first version used 0.1 % of the
+// error, the pixel interval by 1e-3 pixel plus the rounding of (col_off + u) - 0.5. The mesh boxes' slack is derived where
+// it is used (16 u of the farthest corner for the box test itself; the traversal's own pad for the boxes of the tree). (A first version used 0.1 % of the
 // radius: a full unit for the ground sphere, which made the band of tiles whose backward lines "might graze" it six tile
 // rows high instead of two.) A degenerate camera makes the quantities NaN and
 // every comparison false: nothing is culled. Non-finite or non-positive radii and non-finite boxes (a mesh without
@@ -836,10 +867,20 @@ struct CullCone {
     }
 };
 
-constexpr int kCullBlock = 64;  // (one wave per workgroup: 12,288 tiles spread over 192 CUs instead of 48)
-__global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TraceParams P) {
-    const uint32_t tile = blockIdx.x * kCullBlock + threadIdx.x;
-    if (tile >= P.n_tiles) return;
+// FOUR lanes per tile (round 4). The kernel's time was the longest walk over the top of a mesh's tree -- a tile at the
+// mesh's silhouette tests the four child boxes of some twenty nodes one after the other, in double precision, a chain of
+// ~40,000 dependent operations: 0.12 ms for 12,288 tiles, in front of every frame with a new camera. The four lanes of a
+// tile compute the same prologue and the same sphere bits (cheap, redundant) and share the walk: every lane pops the same
+// node and tests ONE of its four children, a wave vote brings the quad's four answers to each of its lanes, and every
+// lane pushes the same entries on its own copy of the stack (no LDS, no hand-over).
+constexpr int kCullBlock = 64;       // one wave per workgroup: the launch spreads over the CUs
+constexpr uint32_t kCullLanes = 4;   // lanes per tile
+// (at most 128 VGPRs, like a trace wave: a wave of this kernel then fits the slot ONE exiting trace wave leaves on its SIMD;
+// at 140 it needed two of them to have left)
+__global__ __launch_bounds__(kCullBlock, 4) void primary_cull_kernel(const TraceParams P) {
+    const uint32_t tile = (blockIdx.x * kCullBlock + threadIdx.x) / kCullLanes;
+    const uint32_t quad_lane = threadIdx.x % kCullLanes, quad_shift = threadIdx.x & ~(kCullLanes - 1u);
+    if (tile >= P.n_tiles) return;  // (whole quads: the votes below count active lanes only)
     const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const rbrt_camera_t& c = P.cam;
     const uint32_t W = c.img_width_pix, H = c.img_height_pix;
@@ -928,14 +969,30 @@ __global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TracePar
             finite = finite && l < 1e30;
             far = l > far ? l : far;
         }
-        // aabbox.rs:28-58 in float: six quotients and their min / max, a few ulp of the largest magnitude; the triangle
-        // test (triangle.rs:134-262) likewise admits rays a few ulp outside a triangle: the same slack for both
-        const double slack = 1e-4 * far;
+        // The mesh's own box, aabbox.rs:28-58 in float (u = 2^-24). Per axis the two quotients t = (plane - o) / d carry one
+        // rounding of the difference and one of the division: t~ = t (1 + e), |e| <= 2u + u^2. If the float test passes
+        // (t_max >= 0, t_min <= t_max) there is an s >= 0 with, on every axis, min(t~lo, t~hi) <= s <= max(t~lo, t~hi); the
+        // point o + s d of the float ray then has every coordinate within 2u |plane - o| + u |plane - o| <= 3u far of the
+        // interval [lo, hi] (o + t d = plane exactly for the exact t): it lies within 3 sqrt(3) u far = 3.1e-7 far of the
+        // box, on the forward half of the ray. (A zero direction component makes the quotients +-inf or NaN; fmin / fmax
+        // skip a NaN, and an axis whose line runs outside its slab gives t_min = +inf or t_max = -inf: a miss, as in
+        // geometry.) The slack is 16 u far, three times that bound; the angle between the float ray and the exact
+        // line of its pixel is added on top by box_unreachable (angle * far). Round 3 had a chosen 1e-4 far here.
+        const double slack = 16.0 * (1.0 / 16777216.0) * far;
         const bool out = finite && box_unreachable(d3(md.bbox_lo), d3(md.bbox_hi), slack, far);
         if (out) word |= 1u << (24u + m);
         // A ray may pass the mesh's box and still have no triangle to hit: the tile is free of the mesh as well when
-        // every box in the top kCullLevels levels of its tree (bvh.cpp: each bounds its triangles, padded outwards) is
-        // out of the tile's reach. Depth first, descending only where a box is in reach.
+        // every box in the top kCullLevels levels of its tree is out of the tile's reach. Depth first, descending only where
+        // a box is in reach. "Reach" for a tree box is what the TRAVERSAL grows it by (the header of this file's BVH section,
+        // make_cull): a triangle the float Moller-Trumbore test accepts has its point within 18 u (K |d| + 1) S of the exact
+        // triangle, K = |e1||e2| / eps -- the |a| >= eps rule bounds the amplification, and for a large triangle met at a
+        // grazing angle that is far more than a few ulp -- so every child box is grown by the pad the trace kernel itself
+        // would use for a ray from this position, 64 u (S + |o|_inf) (max|e1||e2| of the child's subtree * |d| / eps + 1)
+        // with |d| <= 1.001: a camera ray that takes a triangle passes inside every ancestor's grown box, so a tile none
+        // of whose rays enters a grown box of some level takes no triangle below it.
+        const D3 mc = d3(md.center) - pos;
+        const double o_inf = fmax(fmax(fabs(pos.x), fabs(pos.y)), fabs(pos.z));
+        const double pad_base = 64.0 * (1.0 / 16777216.0) * (dlen(mc) + double(md.radius) + o_inf);
         bool mesh_free = out;
         if (!out && all && finite && md.n_nodes != 0u) {  // (only where the answer matters: nothing else is in reach so far)
             constexpr uint32_t kCullLevels = 6;
@@ -943,36 +1000,45 @@ __global__ __launch_bounds__(kCullBlock) void primary_cull_kernel(const TracePar
             uint32_t sp = 0;
             stack[sp++] = 0u;  // (node index << 3 | level)
             mesh_free = true;
-            while (sp != 0u && mesh_free) {
+            while (sp != 0u && mesh_free) {  // (uniform over the tile's four lanes: they hold the same stack)
                 const uint32_t e = stack[--sp];
                 const BvhNode4& nd = md.nodes[e >> 3];
-                for (uint32_t c = 0; c < 4u && mesh_free; ++c) {
-                    const int32_t link = nd.child[c];
-                    if (link == kNoChild) continue;
+                // this lane's child: 0 = no box or out of reach, 1 = in reach and to be opened, 2 = in reach and not to be
+                // opened (a leaf, the level limit, a full stack, a box this rule does not understand): the mesh stays
+                const uint32_t c = quad_lane;
+                const int32_t link = nd.child[c];
+                uint32_t state = 0u;
+                if (link != kNoChild) {
                     const D3 lo = D3{double(nd.lo_x[c]), double(nd.lo_y[c]), double(nd.lo_z[c])};
                     const D3 hi = D3{double(nd.hi_x[c]), double(nd.hi_y[c]), double(nd.hi_z[c])};
-                    if (!(dlen(lo - pos) < 1e30 && dlen(hi - pos) < 1e30)) {
-                        mesh_free = false;  // (not a box this rule understands)
-                    } else if (!box_unreachable(lo, hi, slack, far)) {
-                        if (link >= 0 && (e & 7u) + 1u < kCullLevels && sp < 3u * kCullLevels + 4u) stack[sp++] = (uint32_t(link) << 3) | ((e & 7u) + 1u);
-                        else mesh_free = false;
-                    }
+                    if (!(dlen(lo - pos) < 1e30 && dlen(hi - pos) < 1e30)) state = 2u;
+                    else if (!box_unreachable(lo, hi, pad_base * (double(nd.max_e12[c]) * 1.001 * double(P.eps_frac) + 1.0), far))
+                        state = (link >= 0 && (e & 7u) + 1u < kCullLevels) ? 1u : 2u;
+                }
+                const uint32_t open = uint32_t(__builtin_amdgcn_ballot_w64(state == 1u) >> quad_shift) & 15u;
+                const uint32_t stay = uint32_t(__builtin_amdgcn_ballot_w64(state == 2u) >> quad_shift) & 15u;
+                if (stay != 0u) mesh_free = false;
+                for (uint32_t k = 0; k < 4u && mesh_free; ++k) {
+                    if (!((open >> k) & 1u)) continue;
+                    if (sp < 3u * kCullLevels + 4u) stack[sp++] = (uint32_t(nd.child[k]) << 3) | ((e & 7u) + 1u);
+                    else mesh_free = false;
                 }
             }
         }
         if (!mesh_free) all = false;
     }
     if (all) word |= 1u << 31;
-    P.tile_cull[tile] = word;
+    if (quad_lane == 0u) P.tile_cull[tile] = word;
 }
 
 // The rank's tiles split by what primary_cull_kernel found, each list in ascending order (TraceParams::tile_lists): one
 // workgroup, every thread a contiguous run of local tiles, an exclusive scan of the runs' counts in between.
-// (256 threads, 2 KB of LDS: when the camera changes in the middle of a stream of frames this kernel has to find room
-// beside resident trace waves, which hold every CU's LDS; a 1024-thread workgroup waited milliseconds for a whole free CU)
-constexpr int kListBlock = 256;
+// (ONE wave and no LDS -- the scan is made of wave shuffles: when the camera changes in the middle of a stream of frames this
+// kernel has to find room beside resident trace waves, which hold every wave slot and all of every CU's LDS. A 1024-thread
+// workgroup waited milliseconds for a whole free CU (round 3), the 256-thread one with its 2 KB of LDS that followed still
+// needed four free slots on one CU at once (round 4's trace: up to 3 ms).)
+constexpr int kListBlock = 64;
 __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParams P) {
-    __shared__ uint32_t sums[2][kListBlock];
     const uint32_t n = P.n_local_tiles, t = threadIdx.x;
     const uint32_t per = (n + kListBlock - 1) / kListBlock;
     const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
@@ -993,22 +1059,26 @@ __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParam
         const uint32_t c = tile_class(tl);
         if (c < 2u) ++mine[c];
     }
-    sums[0][t] = mine[0], sums[1][t] = mine[1];
-    __syncthreads();
-    for (uint32_t d = 1; d < kListBlock; d <<= 1) {  // inclusive scans
-        const uint32_t v0 = t >= d ? sums[0][t - d] : 0u, v1 = t >= d ? sums[1][t - d] : 0u;
-        __syncthreads();
-        sums[0][t] += v0, sums[1][t] += v1;
-        __syncthreads();
+    uint32_t incl[2] = {mine[0], mine[1]};
+    for (uint32_t d = 1; d < kListBlock; d <<= 1) {  // inclusive scans over the wave
+        const uint32_t v0 = uint32_t(__shfl_up(int(incl[0]), d, 64)), v1 = uint32_t(__shfl_up(int(incl[1]), d, 64));
+        if (t >= d) incl[0] += v0, incl[1] += v1;
     }
-    const uint32_t n_heavy = sums[0][kListBlock - 1], n_light = sums[1][kListBlock - 1], n_work = n_heavy + n_light;
-    uint32_t r[2] = {sums[0][t] - mine[0], sums[1][t] - mine[1]};  // heavy / light tiles before this run
+    const uint32_t n_heavy = uint32_t(__shfl(int(incl[0]), kListBlock - 1, 64)), n_light = uint32_t(__shfl(int(incl[1]), kListBlock - 1, 64));
+    const uint32_t n_work = n_heavy + n_light;
+    uint32_t r[2] = {incl[0] - mine[0], incl[1] - mine[1]};  // heavy / light tiles before this run
     uint32_t k = lo - r[0] - r[1];                                  // background-only tiles before it
     uint32_t* const work = P.tile_lists + kTileListHeader;
     uint32_t* const sky = work + n;
     // where the classes go in the work list (tile_list_mode; 0: one class, ascending): 1 heavy | light, 2 light/2 | heavy |
-    // light/2, 3 light | heavy -- each class ascending in itself
+    // light/2, 3 light | heavy -- each class ascending in itself; 4: the image's row-major order in the direction it is handed
+    // out in (P.tiles_reversed: from the last tile down), except that the LAST n_work / tile_tail_div light tiles of that
+    // order are taken out of it and handed out at the very end: the bulk of the launch keeps row-major order's mix of
+    // traversal-heavy and shading-heavy work in every wave, and the launch drains on light tiles whatever the image
     const uint32_t half = n_light / 2u;
+    uint32_t n_tail = n_work / (P.tile_tail_div != 0u ? P.tile_tail_div : 8u);
+    n_tail = n_tail < n_light ? n_tail : n_light;
+    const uint32_t n_front_light = n_light - n_tail;  // light tiles that stay in row-major order
     for (uint32_t tl = lo; tl < hi; ++tl) {
         const uint32_t c = tile_class(tl);
         if (c == 2u) {
@@ -1016,8 +1086,19 @@ __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParam
             continue;
         }
         uint32_t pos;
-        if (c == 0u) pos = (P.tile_list_mode == 2u ? half : P.tile_list_mode == 3u ? n_light : 0u) + r[0]++;
-        else pos = (P.tile_list_mode == 1u ? n_heavy : P.tile_list_mode == 2u && r[1] >= half ? n_heavy : 0u) + r[1]++;
+        if (P.tile_list_mode == 4u) {
+            // ranks in hand-out order: heavy and light tiles handed out BEFORE this one
+            const bool rev = P.tiles_reversed != 0u;
+            const uint32_t h = c == 0u ? (rev ? n_heavy - 1u - r[0] : r[0]) : (rev ? n_heavy - r[0] : r[0]);
+            const uint32_t l = c == 1u ? (rev ? n_light - 1u - r[1] : r[1]) : (rev ? n_light - r[1] : r[1]);
+            if (c == 1u && l >= n_front_light) pos = (n_work - n_tail) + (l - n_front_light);
+            else pos = h + (l < n_front_light ? l : n_front_light);
+            ++r[c];
+        } else if (c == 0u) {
+            pos = (P.tile_list_mode == 2u ? half : P.tile_list_mode == 3u ? n_light : 0u) + r[0]++;
+        } else {
+            pos = (P.tile_list_mode == 1u ? n_heavy : P.tile_list_mode == 2u && r[1] >= half ? n_heavy : 0u) + r[1]++;
+        }
         work[pos] = tl;
     }
     if (t == kListBlock - 1) {
@@ -1033,11 +1114,11 @@ __host__ __device__ inline uint32_t local_tiles_of(uint32_t n_tiles, uint32_t ra
 
 // Gathered per-rank packed tiles -> row-major image (rank r's block starts after the blocks of
 // ranks < r; inside a block tiles are in ascending global tile order).
-__global__ __launch_bounds__(kBlock) void unpack_kernel(const float* __restrict__ gathered, uint32_t width,
+__global__ __launch_bounds__(kSmallBlock) void unpack_kernel(const float* __restrict__ gathered, uint32_t width,
                                                         uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
                                                         uint32_t world, size_t rank_stride_pixels, float* out_radiance,
                                                         uint8_t* out_rgb8) {
-    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t i = size_t(blockIdx.x) * kSmallBlock + threadIdx.x;
     if (i >= size_t(width) * height) return;
     const uint32_t row = uint32_t(i / width), col = uint32_t(i - size_t(row) * width);
     const uint32_t tile = (row / RBRT_TILE) * tiles_x + col / RBRT_TILE;
@@ -1207,7 +1288,8 @@ hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint3
 // The tile pass: the culling table of P.cam, then (tile_lists given) the rank's two tile lists from it.
 hipError_t launch_primary_cull(const TraceParams& P, hipStream_t stream) {
     if (P.n_tiles == 0 || !P.tile_cull) return hipSuccess;
-    hipLaunchKernelGGL(primary_cull_kernel, dim3((P.n_tiles + kCullBlock - 1) / kCullBlock), dim3(kCullBlock), 0, stream, P);
+    const size_t cull_threads = size_t(P.n_tiles) * kCullLanes;
+    hipLaunchKernelGGL(primary_cull_kernel, dim3(uint32_t((cull_threads + kCullBlock - 1) / kCullBlock)), dim3(kCullBlock), 0, stream, P);
     if (P.tile_lists) hipLaunchKernelGGL(tile_lists_kernel, dim3(1), dim3(kListBlock), 0, stream, P);
     return hipGetLastError();
 }
@@ -1215,14 +1297,14 @@ hipError_t launch_primary_cull(const TraceParams& P, hipStream_t stream) {
 hipError_t launch_sky_resolve(const TraceParams& P, const ResolveParams& R, hipStream_t stream) {
     const size_t npix = size_t(R.n_local_tiles) * 64u;  // (an upper bound: the list's length is known on the device)
     if (npix == 0 || !R.tile_lists) return hipSuccess;
-    hipLaunchKernelGGL(sky_resolve_kernel, dim3(uint32_t((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, P, R);
+    hipLaunchKernelGGL(sky_resolve_kernel, dim3(uint32_t((npix + kSmallBlock - 1) / kSmallBlock)), dim3(kSmallBlock), 0, stream, P, R);
     return hipGetLastError();
 }
 
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream) {
     const size_t npix = size_t(R.n_local_tiles) * 64u;
     if (npix == 0) return hipSuccess;
-    hipLaunchKernelGGL(resolve_kernel, dim3(uint32_t((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, R);
+    hipLaunchKernelGGL(resolve_kernel, dim3(uint32_t((npix + kSmallBlock - 1) / kSmallBlock)), dim3(kSmallBlock), 0, stream, R);
     return hipGetLastError();
 }
 
@@ -1231,7 +1313,7 @@ hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height,
     const uint32_t tiles_x = (width + RBRT_TILE - 1) / RBRT_TILE, tiles_y = (height + RBRT_TILE - 1) / RBRT_TILE;
     const size_t n = size_t(width) * height;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(unpack_kernel, dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, gathered,
+    hipLaunchKernelGGL(unpack_kernel, dim3(uint32_t((n + kSmallBlock - 1) / kSmallBlock)), dim3(kSmallBlock), 0, stream, gathered,
                        width, height, tiles_x, tiles_x * tiles_y, world, rank_stride_pixels, out_radiance, out_rgb8);
     return hipGetLastError();
 }

@@ -24,7 +24,7 @@
 //                             that just ended (per-wave accumulators in LDS, summed into DevCounters::diag[0..kNumRegions)
 //                             at the end): where a wave's LIFETIME goes, waits included (tools/region_profile.py)
 #define RBRT_REGIONS(X) X(init) X(finalise) X(census) X(refill) X(choose) X(burst_top) X(leaf_round) X(leaf_chunk) X(walk) \
-    X(burst_end) X(pass_lists) X(term) X(gen) X(scatter_load) X(round_top) X(scatter_kind) X(spheres_gate) X(gate) X(park) X(merge)
+    X(burst_end) X(pass_lists) X(term) X(gen) X(scatter_load) X(round_top) X(scatter_kind) X(spheres_gate) X(gate) X(park)
 #define RBRT_REGION_ENUM(name) R_##name,
 enum { RBRT_REGIONS(RBRT_REGION_ENUM) kNumRegions };
 #ifndef RBRT_REGION_TIMERS
@@ -127,23 +127,6 @@ __device__ __forceinline__ uint32_t next_gated_mesh(const SceneLds& sc, uint32_t
 __device__ __forceinline__ uint32_t classify(const SceneLds& sc, int32_t obj, uint32_t depth) {
     if (obj < 0 || depth == 0) return ST_TERM;  // lib.rs:54,68
     return ST_LAMB + sc.mat[uint32_t(obj) * kMatDw + 4];
-}
-
-// A kernel argument read WHERE IT IS USED. The compiler loads every argument it sees used into SGPRs at the top of the
-// kernel and keeps it there; for a word that only the end of a launch looks at, that is one more SGPR spilled around the
-// traversal loop. The volatile asm pins the scalar load to its place (TraceParams is the kernel's only argument: offset 0).
-#define RBRT_KARG(field) karg_u32<offsetof(TraceParams, field)>()
-template <uint32_t BYTE_OFFSET>
-__device__ __forceinline__ uint32_t karg_u32() {
-    uint32_t v;
-    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(BYTE_OFFSET));
-    return v;
-}
-template <class T, uint32_t BYTE_OFFSET>
-__device__ __forceinline__ T* karg_ptr() {
-    unsigned long long v;
-    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(BYTE_OFFSET));
-    return reinterpret_cast<T*>(v);
 }
 
 // Work items (tile, sample, pixel) are handed out in chunks of 64 from kWorkShards global counters. A wave starts
@@ -338,112 +321,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         dg_rt0 = __builtin_amdgcn_s_memrealtime();
     }
     bool more_work = true;  // wave-uniform: the global work counter has not run out yet
-    // ---- merging the thin ends of the waves (DESIGN.md section 6 "The end of a launch") ----
-    // Once the work items are out, every wave's pool runs empty on its own: 110 paths, then 50, 20, 8, 3, 1 -- and every
-    // round of those costs a full pass's instructions for a handful of lanes (measured: 7 lanes per shading pass in the
-    // drain against 50 before it; 48 % of all wave lifetime). So a wave whose pool has thinned out below P.merge_low
-    // paths, all of them parked, WRITES THEM OUT as records and EXITS, and the waves that go on take the records into
-    // their free slots: the paths that are left keep sharing full passes, and the wave slots go to the next launch.
-    // Per XCD (HW_REG_XCC_ID: giver and taker share an L2, nothing is polled chip-wide) there is a control line and a
-    // ring of records in global memory. Word A of the line = (waves of the XCD still running << 32) | records
-    // reserved, word B = records taken. A giver reserves its records AND leaves the count of running waves with ONE
-    // atomic add on word A, so the wave that finds itself the last one running (its own decrement returns 1) sees every
-    // reservation ever made and takes what is left: no record can be stranded, and nobody ever waits for anybody --
-    // the only wait is a taker's bounded spin on a record whose giver is still writing it. A record is 8-byte
-    // {tag, value} granules written and read with agent-scope relaxed atomics (write-through stores, loads that bypass
-    // the L1: the data is its own flag, no fences); the tag is the launch's token.
-    // Who finishes a path cannot change the image: a path owns its RNG stream and its sample slot.
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
-#define merge_on (SHAREK && RBRT_KARG(merge_low) != 0u) /* (api.cpp: rings and control lines exist whenever merge_low != 0) */
-    uint32_t dg_mg_given = 0, dg_mg_taken = 0, dg_mg_exits = 0, dg_mg_takes = 0;
-    uint32_t no_give = 0;  // wave-uniform: this wave found itself the last one running once; it keeps what it has
-    auto xcd_now = [&]() -> uint32_t {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-        return xcc % kWorkShards;
-    };
-    auto mctl = [&]() -> gu64* {  // this XCD's control line: [0] = word A, [1] = word B
-        return (gu64*)karg_ptr<unsigned long long, offsetof(TraceParams, merge_ctl)>() + xcd_now() * kMergeCtlWords;
-    };
-    auto mring = [&]() -> gu64* {
-        return (gu64*)karg_ptr<unsigned long long, offsetof(TraceParams, merge_ring)>() + size_t(xcd_now()) * kMergeRingRecords * kMergeGranules;
-    };
-    auto mload = [&](gu64* w) -> unsigned long long {  // (every lane the same word: one request; the value through SGPRs)
-        const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (unsigned long long)WorkSource::uni(uint32_t(v)) | ((unsigned long long)WorkSource::uni(uint32_t(v >> 32)) << 32);
-    };
-    auto madd = [&](gu64* w, unsigned long long d) -> unsigned long long {  // lane 0 adds; the old value to every lane
-        unsigned long long old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(w, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (unsigned long long)WorkSource::uni(uint32_t(old)) | ((unsigned long long)WorkSource::uni(uint32_t(old >> 32)) << 32);
-    };
-    constexpr unsigned long long kOneWave = 1ull << 32;
-    // Records [first, first + n) of this XCD's ring into n EMPTY slots of the pool (the caller knows there are that many).
-    auto take_records = [&](uint32_t first, uint32_t n) {
-        uint32_t lane_here = lane;  // (opaque: addresses derived from it are made here, not carried -- spilled -- through the kernel)
-        asm volatile("" : "+v"(lane_here));
-        uint32_t c = 0;
-#pragma unroll
-        for (uint32_t g = 0; g < kPoolPad; g += 64) {  // the first n empty slots, in slot order
-            const bool m = status[g + lane_here] == ST_EMPTY;
-            const uint64_t mask = wballot(m);
-            const uint32_t r = c + lane_rank(mask);
-            if (m && r < n) list[r] = uint8_t(g + lane_here);
-            c += uint32_t(__popcll(mask));
-        }
-        __syncthreads();
-        if (lane_here < n) {
-            const uint32_t slot = list[lane_here];
-            gu64* const rec = mring() + size_t(first + lane_here) * kMergeGranules;
-            const uint32_t token = RBRT_KARG(merge_token);
-            bool lost = false;
-            auto granule = [&](uint32_t k) -> uint32_t {  // (reserved before the head could reach it: its giver is writing it)
-                for (uint32_t spins = 0;; ++spins) {
-                    const unsigned long long x = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (uint32_t(x >> 32) == token) return uint32_t(x);
-                    if (spins >= (1u << 22)) {
-                        lost = true;
-                        return 0u;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            };
-#pragma unroll
-            for (uint32_t f = 0; f < uint32_t(kFields); ++f) POOL(f, slot) = granule(f);
-            const uint32_t st = granule(uint32_t(kFields));
-            const uint32_t nw = ((POOL(F_META, slot) >> 7) & 127u) >> 2;
-            for (uint32_t j = 0; j < nw && j < uint32_t(kSeqWords); ++j) gseq[size_t(slot) * kSeqWords + j] = granule(uint32_t(kFields) + 1u + j);
-            if (lost || st - ST_TRAV > ST_DIEL - ST_TRAV) {  // never seen; the render call fails loudly (api.cpp)
-                atomicAdd(&P.counters->diag[57], 1ull);
-            } else {
-                status[slot] = uint8_t(st);
-            }
-        }
-        if (STATS) dg_mg_taken += n, ++dg_mg_takes;
-        __syncthreads();
-    };
-    // Claims up to `room` records of this XCD's ring whose reservations `tail` covers: the first one's number and how many (0: none).
-    auto claim_records = [&](uint32_t tail, uint32_t room, uint32_t& first) -> uint32_t {
-        gu64* const ctl = mctl();
-        const uint32_t tl = tail < kMergeRingRecords ? tail : kMergeRingRecords;
-        for (uint32_t tries = 0; tries < 64u; ++tries) {
-            const uint32_t head = uint32_t(mload(ctl + 1));
-            if (head >= tl) return 0u;
-            uint32_t n = tl - head;
-            n = n < room ? n : room;
-            n = n < 64u ? n : 64u;
-            unsigned long long seen = head;
-            if (lane == 0)
-                __hip_atomic_compare_exchange_strong(ctl + 1, &seen, (unsigned long long)(head + n), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-            if (WorkSource::uni(uint32_t(seen)) == head) {  // (unchanged: the exchange took place)
-                first = head;
-                return n;
-            }
-        }
-        return 0u;  // (64 other takers in a row: leave it to them)
-    };
-    if (merge_on) (void)madd(mctl(), kOneWave);
     const float eps = P.min_dist;
 
     // ---- per-lane traversal state; lives in registers across shading passes ----
@@ -471,12 +348,16 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     // pointer, i.e. a flat_store / flat_load plus a dozen address instructions on the hottest path of the kernel)
     typedef volatile __attribute__((address_space(3))) uint32_t lds_u32;
     lds_u32* const stack_lds = (lds_u32*)stack;
+    uint32_t dg_stack_spills = 0, dg_stack_deepest = 0;  // (counting build, per lane: pushes beyond the LDS part; the deepest stack)
     auto push = [&](int32_t v) {
-        if (__builtin_expect(t_sp < n_lds_stack, 1))
+        if (__builtin_expect(t_sp < n_lds_stack, 1)) {
             stack_lds[t_sp * 64u] = uint32_t(v);
-        else
+        } else {
             gstack[(t_sp - n_lds_stack) * 64u] = uint32_t(v);
+            if (STATS) ++dg_stack_spills;
+        }
         ++t_sp;
+        if (STATS) dg_stack_deepest = dg_stack_deepest > t_sp ? dg_stack_deepest : t_sp;
     };
     auto stack_at = [&](uint32_t i) -> int32_t {
         if (__builtin_expect(i < n_lds_stack, 1)) return int32_t(stack_lds[i * 64u]);
@@ -543,70 +424,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         }
 #endif
         uint32_t n_active = uint32_t(__popcll(wballot(t_active != 0u)));
-
-        // ---- merging (drain only): take records into free slots; a pool that has thinned out is written out whole ----
-        if (merge_on && !more_work) {
-            const uint32_t live = uint32_t(POOLN) - cnt[ST_EMPTY];
-            const uint32_t parked = cnt[ST_TRAV] + cnt[ST_TERM] + cnt[ST_LAMB] + cnt[ST_METAL] + cnt[ST_DIEL];
-            const uint32_t low = RBRT_KARG(merge_low);
-            if (live != 0u && (live >= low || no_give != 0u) && uint32_t(POOLN) - live >= RBRT_KARG(merge_take_min)) {
-                RBRT_MARK(merge);
-                uint32_t first = 0;
-                const uint32_t n = claim_records(uint32_t(mload(mctl())), uint32_t(POOLN) - live, first);
-                if (n != 0u) {
-                    take_records(first, n);
-                    continue;  // (count again)
-                }
-            } else if (live != 0u && live < low && live == parked && n_active == 0u && no_give == 0u) {
-                RBRT_MARK(merge);
-                gu64* const ctl = mctl();
-                const unsigned long long a = mload(ctl);
-                if (uint32_t(a) + live <= kMergeRingRecords && uint32_t(a >> 32) > 1u) {  // room in the ring, and somebody else is running
-                    // reserve `live` records and leave the running waves, in one step
-                    const unsigned long long old = madd(ctl, (unsigned long long)live - kOneWave);
-                    const uint32_t base = uint32_t(old);
-                    const uint32_t n_fit = base >= kMergeRingRecords ? 0u : (live < kMergeRingRecords - base ? live : kMergeRingRecords - base);
-                    gu64* const ring = mring();
-                    uint32_t lane_here = lane;  // (opaque, as in take_records)
-                    asm volatile("" : "+v"(lane_here));
-                    uint32_t seen = 0;
-#pragma unroll
-                    for (uint32_t g = 0; g < kPoolPad; g += 64) {
-                        const uint32_t slot = g + lane_here;
-                        const uint32_t st = status[slot];
-                        const bool has = st - ST_TRAV <= ST_DIEL - ST_TRAV;
-                        const uint64_t m = wballot(has);
-                        const uint32_t r = seen + lane_rank(m);
-                        if (has && r < n_fit) {
-                            gu64* const rec = ring + size_t(base + r) * kMergeGranules;
-                            const unsigned long long tag = (unsigned long long)RBRT_KARG(merge_token) << 32;
-#pragma unroll
-                            for (uint32_t f = 0; f < uint32_t(kFields); ++f)
-                                __hip_atomic_store(rec + f, tag | POOL(f, slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(rec + kFields, tag | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const uint32_t nw = ((POOL(F_META, slot) >> 7) & 127u) >> 2;  // full words of bounce ids in gseq
-                            for (uint32_t j = 0; j < nw; ++j)
-                                __hip_atomic_store(rec + kFields + 1u + j, tag | gseq[size_t(slot) * kSeqWords + j], __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                            status[slot] = ST_EMPTY;
-                        }
-                        seen += uint32_t(__popcll(m));
-                    }
-                    if (STATS) dg_mg_given += n_fit;
-                    __syncthreads();
-                    if (n_fit == live && uint32_t(old >> 32) > 1u) {  // everything is out and another wave of the XCD runs on: done
-                        if (STATS) ++dg_mg_exits;
-                        no_give = 2u;  // (left the count of running waves already)
-                        break;
-                    }
-                    // the last one running after all (a race with another wave's exit), or the ring's end: back among the
-                    // running waves, keeping from now on whatever it has; its own records come back through the ring
-                    (void)madd(ctl, kOneWave);
-                    no_give = 1u;
-                    continue;
-                }
-            }
-        }
 
         RBRT_MARK(refill);
         // ---- idle lanes take parked rays (in batches: only when enough lanes are idle) ----
@@ -687,28 +504,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (cnt[ST_LAMB] > best) kind = ST_LAMB, best = cnt[ST_LAMB];
         if (cnt[ST_METAL] > best) kind = ST_METAL, best = cnt[ST_METAL];
         if (cnt[ST_DIEL] > best) kind = ST_DIEL, best = cnt[ST_DIEL];
-        if (best == 0 && n_active == 0) {  // nothing waits, nothing runs, no work left
-            if (!merge_on) break;
-            // ---- merging, at the exit: the pool is empty. Leave the running waves; the one that finds itself the LAST of
-            // its XCD has every reservation ever made in the word its decrement returned, and takes what is left ----
-            RBRT_MARK(merge);
-            gu64* const ctl = mctl();
-            const unsigned long long old = madd(ctl, 0ull - kOneWave);
-            const uint32_t tail = uint32_t(old) < kMergeRingRecords ? uint32_t(old) : kMergeRingRecords;
-            const uint32_t head = uint32_t(mload(ctl + 1));
-            const bool last = uint32_t(old >> 32) == 1u;
-            // (not the last: the others go on and will take what there is -- unless this wave is asked to stay useful and a
-            // pass's worth of records is waiting)
-            if (head >= tail || (!last && (RBRT_KARG(merge_empty_takes) == 0u || tail - head < RBRT_KARG(merge_low)))) {
-                no_give = 2u;
-                break;
-            }
-            (void)madd(ctl, kOneWave);
-            uint32_t first = 0;
-            const uint32_t n = claim_records(tail, uint32_t(POOLN), first);
-            if (n != 0u) take_records(first, n);
-            continue;  // (with records, or to look again: as long as the ring is not empty somebody has to)
-        }
+        if (best == 0 && n_active == 0) break;  // nothing waits, nothing runs, no work left
 
         // Traverse while the lanes are well filled; shade when they are not (that is what parks new
         // rays) or when shading work has piled up to a full wave.
@@ -894,6 +690,20 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
 #endif
                 if (can_walk) {
                     uint32_t k[4];
+#if RBRT_PUSH_ORDER == 0 && RBRT_PAIR_SORT
+                    int32_t sl[4];
+                    node4_visit_sorted(t_nodes + t_cur, t_rc, eps, t_best, k, sl);
+                    if (STATS) ++lc.nodes;
+                    if (STATS && t_cur == 0 && k[0] == kMissKey) ++dg_root_only;  // a traversal that ends at the root
+                    if (k[0] != kMissKey) {  // farthest first, so that the nearest is popped first
+                        if (k[3] != kMissKey) push(sl[3]);
+                        if (k[2] != kMissKey) push(sl[2]);
+                        if (k[1] != kMissKey) push(sl[1]);
+                        t_cur = sl[0];
+                    } else {
+                        t_cur = t_sp != 0 ? pop() : kNoChild;
+                    }
+#else
                     f32x4 links;
                     node4_visit<RBRT_PUSH_ORDER == 0>(t_nodes + t_cur, t_rc, eps, t_best, k, links);
                     if (STATS) ++lc.nodes;
@@ -920,6 +730,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     } else {
                         t_cur = t_sp != 0 ? pop() : kNoChild;
                     }
+#endif
 #endif
                 }
                 if (t_active && t_cur == kNoChild && t_pend == kNoChild) {
@@ -1268,7 +1079,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (STATS) dg_t_shade += __builtin_amdgcn_s_memtime() - dg_tk;
     }
 #undef POOL
-#undef merge_on
 #if RBRT_REGION_TIMERS
     rt_tick(R_init);
     if (lane < uint32_t(kNumRegions)) atomicAdd(&P.counters->diag[lane], (unsigned long long)rt_acc[lane]);
@@ -1305,6 +1115,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         atomicAdd(&P.counters->mesh_hits, (unsigned long long)lc.mesh_hits);
         atomicAdd(&P.counters->samples, (unsigned long long)n_samples_done);
         atomicAdd(&P.counters->diag[61], (unsigned long long)dg_root_only);  // (per lane, like the counters above)
+        if (dg_stack_spills != 0u) atomicAdd(&P.counters->diag[30], (unsigned long long)dg_stack_spills);
+        atomicMax(&P.counters->diag[31], (unsigned long long)dg_stack_deepest);
         if (lane == 0) {
             for (uint32_t k = 0; k < kNumStatus; ++k) {
                 atomicAdd(&P.counters->diag[k], (unsigned long long)dg_pass[k]);
@@ -1328,10 +1140,6 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
             atomicAdd(&P.counters->diag[16], dg_t_trav);
             atomicAdd(&P.counters->diag[17], dg_t_shade);
             atomicAdd(&P.counters->diag[18], (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
-            atomicAdd(&P.counters->diag[30], (unsigned long long)dg_mg_given);
-            atomicAdd(&P.counters->diag[31], (unsigned long long)dg_mg_taken);
-            atomicAdd(&P.counters->diag[49], (unsigned long long)dg_mg_exits);
-            atomicAdd(&P.counters->diag[55], (unsigned long long)dg_mg_takes);
             atomicAdd(&P.counters->diag[59], (unsigned long long)dg_share_given);
             atomicAdd(&P.counters->diag[60], (unsigned long long)dg_share_rounds);
             atomicAdd(&P.counters->diag[62], (unsigned long long)dg_sph_tails);

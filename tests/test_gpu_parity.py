@@ -247,47 +247,6 @@ def test_shared_traversals_do_not_change_the_image(hip, oracle, monkeypatch, env
     assert (given > 0) == sharing, (env, given)
 
 
-@pytest.mark.parametrize("env", [
-    {"RBRT_MERGE_LOW": "24"},
-    {"RBRT_MERGE_LOW": "24", "RBRT_WAVES_PER_CU": "2"},
-    {"RBRT_MERGE_LOW": "128", "RBRT_MERGE_TAKE_MIN": "1", "RBRT_WAVES_PER_CU": "2"},
-    {"RBRT_MERGE_LOW": "8", "RBRT_MERGE_TAKE_MIN": "64", "RBRT_MERGE_EMPTY_TAKES": "0", "RBRT_WAVES_PER_CU": "4"},
-    {"RBRT_MERGE_LOW": "48", "RBRT_MERGE_ISOLATED": "0", "RBRT_WAVES_PER_CU": "1", "RBRT_SHARE_IDLE": "0"},
-    {"RBRT_MERGE_LOW": "32", "RBRT_POOL": "256", "RBRT_WAVES_PER_CU": "2"},
-])
-def test_merging_the_thin_ends_of_the_waves_does_not_change_the_image(hip, oracle, monkeypatch, env):
-    """The end of a launch (megakernel.inl "merging"): a wave whose pool has thinned out writes its paths out as records in
-    global memory and exits; the waves that go on take them into their free slots. Who finishes a path cannot change the
-    image (a path owns its RNG stream and its sample slot); a record that got lost would leave its sample poisoned
-    (conftest: NaN) and fail the check, one taken twice would be caught by the counters. Small grids (RBRT_WAVES_PER_CU)
-    give every wave a bulk phase and a drain on a small image; the scene has metal and diffuse chains longer than the four
-    bounce ids a path keeps in its slot, so records carry their overflow words too. A stream of frames reuses the rings
-    with a new token per launch."""
-    import torch
-    cam = scenes.camera(oracle, 160, 120)
-    sc = scenes.example_scene(oracle, 3000)
-    seeds = (9, 10, 11, 12)
-    exp = [oracle.render(cam, sc, abi.default_opts(spp=6, seed=sd))[0] for sd in seeds]
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    outs = [torch.empty((120, 160, 3), dtype=torch.float32, device="cuda") for _ in seeds]
-    with hip.HipScene(sc) as hs:
-        for sd, out in zip(seeds, outs):  # a stream of frames: overlapping launches, the rings and their tokens reused
-            hs.render_device(cam, abi.default_opts(spp=6, seed=sd), out.data_ptr())
-        torch.cuda.synchronize()
-        for sd, out, e in zip(seeds, outs, exp):
-            assert_same_image(out.cpu().numpy(), e, f"{env} seed {sd}")
-        hs.render_device(cam, abi.default_opts(spp=6, seed=9, flags=abi.FLAG_COLLECT_STATS), outs[0].data_ptr())
-        torch.cuda.synchronize()
-        assert_same_image(outs[0].cpu().numpy(), exp[0], f"{env} (counting build)")
-        d = hs.debug_counters()
-        assert hs.stats()["samples"] == 160 * 120 * 6
-        hs.check()
-    assert d["merge_given"] == d["merge_taken"], d  # nothing is left in the rings, nothing was taken twice
-    if env.get("RBRT_MERGE_ISOLATED") != "0":       # (the counting launch runs alone)
-        assert d["merge_given"] > 0 and d["merge_exits"] > 0, d
-
-
 def test_streamed_and_blocking_frames_interleaved(hip, oracle):
     """The launch policy looks at what is in flight (api.cpp grid_for: half the wave slots for a launch issued while
     another is running, all of them for one that finds the GPU idle, the first launch after a pause still issued as

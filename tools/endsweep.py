@@ -5,7 +5,7 @@ rbrt_hip_scene_create), so a variant is a fresh HipScene of the same host scene.
   frame   pipelined ms per step / isolated launch ms (HIP events) / one blocking frame with the RGB8 copy
   eighth  rank 0's share of an 8-GPU run: pipelined ms per step / isolated launch ms
 
-    python3 tools/endsweep.py --rounds 3 "-" "RBRT_MERGE_LOW=24" "RBRT_MERGE_LOW=32 RBRT_MERGE_TAKE_MIN=8"
+    python3 tools/endsweep.py --rounds 3 "-" "RBRT_Y_LOW=32" "RBRT_SHARE_IDLE=8 PIPE=4"
 
 Pseudo-knobs handled here: PIPE=n (rbrt_hip_scene_set_pipeline(n) for the pipelined leg), DEPTH=n (opts.max_depth = n:
 diagnosis only, it changes the image), STATS=1 (print the counting build's end-of-launch counters once).
@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--iso", type=int, default=6)
     ap.add_argument("--triangles", type=int, default=69451)
     ap.add_argument("--mesh", default="smooth")
+    ap.add_argument("--mesh-scale", type=float, default=None)
+    ap.add_argument("--mesh-translation", default=None, help="x,y,z")
+    ap.add_argument("--scene", default=str(ROOT / "scenes" / "example_scene.yaml"))
+    ap.add_argument("--new-camera", type=int, default=0, help="1: every frame of the pipelined leg has a camera the library has not seen")
     ap.add_argument("--worlds", default="1,8", help="tile_world values to time (rank 0's share)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=768)
@@ -44,7 +48,17 @@ def main():
     from rbrt_amd import abi, standin
     work = Path(tempfile.mkdtemp(prefix="rbrt_sweep_"))
     obj = standin.ensure_obj(work / "bunny.obj", args.triangles, args.mesh)
-    (work / "scene.yaml").write_text((ROOT / "scenes" / "example_scene.yaml").read_text().replace("obj_filepath: bunny.obj", f"obj_filepath: {obj}"))
+    text = Path(args.scene).read_text().replace("obj_filepath: bunny.obj", f"obj_filepath: {obj}")
+    if args.mesh_scale is not None or args.mesh_translation:
+        import yaml
+        doc = yaml.safe_load(text)
+        for mb in doc.get("mesh_blueprints") or []:
+            if args.mesh_scale is not None:
+                mb["scale"] = float(args.mesh_scale)
+            if args.mesh_translation:
+                mb["translation"] = dict(zip("xyz", (float(v) for v in args.mesh_translation.split(","))))
+        text = "---\n" + yaml.safe_dump(doc, sort_keys=False)
+    (work / "scene.yaml").write_text(text)
     devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(1)
     os.dup2(devnull, 1)
     try:
@@ -53,6 +67,17 @@ def main():
         os.dup2(saved, 1)
     cam = hs.camera
     W, H = args.width, args.height
+    import numpy as np
+    cam_no = [0]
+
+    def next_cam():
+        if not args.new_camera:
+            return cam
+        cam_no[0] += 1
+        c = type(cam).from_buffer_copy(cam)
+        c.position[0] = float(np.float32(cam.position[0]) + np.float32(cam_no[0] % 4096) * np.spacing(np.float32(cam.position[0])))
+        return c
+
     stream = torch.cuda.current_stream().cuda_stream
     img = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
@@ -60,6 +85,7 @@ def main():
     worlds = [int(x) for x in args.worlds.split(",")]
     res = {v: {w: {"step": [], "iso": [], "single": []} for w in worlds} for v in args.variants}
     shas = {}
+    mixes = {}
     knob_names = set()
     for v in args.variants:
         if v != "-":
@@ -86,17 +112,22 @@ def main():
                     scene.render_device(cam, so, img.data_ptr(), None, stream)
                     torch.cuda.synchronize()
                     d = scene.debug_counters()
-                    print(f"stats [{v}] w{w}:", {k: d[k] for k in ("merge_given", "merge_taken", "merge_exits", "merge_takes",
-                                                                 "passes_term", "passes_lamb", "passes_metal", "passes_diel", "slots_term", "slots_lamb", "drain_slowest", "drain_sum", "shared_entries_given", "path_len_hist")}, flush=True)
+                    print(f"stats [{v}] w{w}:", {k: d[k] for k in ("passes_term", "passes_lamb", "passes_metal", "passes_diel", "slots_term", "slots_lamb", "drain_slowest", "drain_sum", "shared_entries_given", "path_len_hist")}, flush=True)
                 scene.set_pipeline(pseudo.get("PIPE", 0))
                 for _ in range(3):
-                    scene.render_device(cam, opts, img.data_ptr(), None, stream)
+                    scene.render_device(next_cam(), opts, img.data_ptr(), None, stream)
                 torch.cuda.synchronize()
+                scene.set_timing(True)  # (resets the launch mix: how many launches of the timed loop took the full grid / half of it)
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
-                    scene.render_device(cam, opts, img.data_ptr(), None, stream)
+                    scene.render_device(next_cam(), opts, img.data_ptr(), None, stream)
                 torch.cuda.synchronize()
                 res[v][w]["step"].append((time.perf_counter() - t0) / args.steps * 1e3)
+                mixes.setdefault((v, w), []).append(scene.launch_mix())
+                scene.set_timing(False)
+                if args.new_camera:  # (the frame whose hash is printed: the scene's own camera)
+                    scene.render_device(cam, opts, img.data_ptr(), None, stream)
+                    torch.cuda.synchronize()
                 if w == 1 and v not in shas:
                     shas[v] = hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:16]
                 # blocking frames with the RGB8 copy (what render_scene returns)
@@ -128,7 +159,7 @@ def main():
     for v in args.variants:
         line = "  ".join(f"w{w}: step {statistics.median(res[v][w]['step']):.3f} ({min(res[v][w]['step']):.3f}) iso {statistics.median(res[v][w]['iso']):.3f} "
                          f"({min(res[v][w]['iso']):.3f}) single {statistics.median(res[v][w]['single']):.3f}" for w in worlds)
-        print(f"{v:60s} {line}  sha {shas.get(v)}")
+        print(f"{v:60s} {line}  sha {shas.get(v)}  full/half grids {[mixes[(v, w)][-1] for w in worlds]}")
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 REGIONS = ("init finalise census refill choose burst_top leaf_round leaf_chunk walk burst_end pass_lists term gen scatter_load "
-           "round_top scatter_kind spheres_gate gate park merge").split()
+           "round_top scatter_kind spheres_gate gate park").split()
 
 
 def main():
@@ -81,7 +81,7 @@ def main():
     groups = {"scheduling": ("finalise", "census", "refill", "choose", "pass_lists"),
               "traversal": ("burst_top", "walk", "burst_end"), "leaf rounds": ("leaf_round", "leaf_chunk"),
               "terminate + generate": ("term", "gen"), "scatter": ("scatter_load", "round_top", "scatter_kind"),
-              "spheres + gate": ("spheres_gate", "gate"), "park": ("park",), "init": ("init",), "merge": ("merge",)}
+              "spheres + gate": ("spheres_gate", "gate"), "park": ("park",), "init": ("init",)}
     for name, c in zip(REGIONS, d):
         print(f"{name:14s} {c / total * 100:6.2f} %   {c / max(1, waves) / 1e3:10.1f} k cycles per wave")
     waves_per = waves // max(1, n)

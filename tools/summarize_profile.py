@@ -46,13 +46,13 @@ for f in glob.glob(str(SRC / "*" / "*" / "*counter_collection.csv")):
     d = Path(f).parent.parent.name
     if d not in newest or Path(f).stat().st_mtime > Path(newest[d]).stat().st_mtime:
         newest[d] = f
-for f in newest.values():
+for pass_name, f in newest.items():
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "trace_megakernel" not in k or not re.search(r"<\d+, false", k):  # (the build without counters)
             continue
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        ndisp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
+        ndisp[(k, r["Counter_Name"])].add((pass_name, r["Dispatch_Id"]))  # (a counter collected in two passes: averaged over both)
         meta[k] = {"VGPR": r["VGPR_Count"], "SGPR": r["SGPR_Count"], "LDS_Block_Size": r["LDS_Block_Size"],
                    "Grid_Size": r["Grid_Size"], "Workgroup_Size": r["Workgroup_Size"]}
 res = {}
@@ -97,6 +97,16 @@ for k, d in res.items():
             rec["sq_lds_bank_conflict"] = c.get("SQ_LDS_BANK_CONFLICT")
             for name in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
                          "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAVES", "GRBM_GUI_ACTIVE"):
+                if name in c:
+                    rec[name.lower()] = c[name]
+            # the executed VALU instructions by class (the counters name f32 add / mul / fma, transcendental, 32- and 64-bit
+            # integer and conversions; compares, selects, min / max, moves and lane operations are the rest)
+            if "SQ_INSTS_VALU_FMA_F32" in c:
+                mix = {n[len("SQ_INSTS_VALU_"):].lower(): c[n] for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32",
+                                                                        "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT") if n in c}
+                mix["other"] = c["SQ_INSTS_VALU"] - sum(mix.values())
+                rec["valu_mix"] = mix
+            for name in ("SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS_LOAD", "SQ_INSTS_LDS_STORE", "SQ_INSTS_LDS_ATOMIC", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VSKIPPED"):
                 if name in c:
                     rec[name.lower()] = c[name]
             rec["valu_lane_utilisation"] = d["derived"].get("valu_lane_utilisation")
