@@ -1014,13 +1014,16 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
                 S = L.tiles[0].last_used <= L.tiles[1].last_used ? &L.tiles[0] : &L.tiles[1];
                 // behind the set's last readers and behind the pass that wrote it last (whatever stream that ran on), on the
                 // prep stream: beside the launches in flight, ahead of this one
-                if (S->free_recorded) HIP_TRY(hipStreamWaitEvent(s->prep_stream, S->ev_free, 0));
-                if (S->key_valid) HIP_TRY(hipStreamWaitEvent(s->prep_stream, S->ev_lists, 0));
+                // (a launch that has the GPU to itself has nothing to run beside: its pass goes on its own stream, one
+                // cross-stream hop less in front of a blocking frame)
+                hipStream_t cs = overlapped ? s->prep_stream : ts;
+                if (S->free_recorded) HIP_TRY(hipStreamWaitEvent(cs, S->ev_free, 0));
+                if (S->key_valid) HIP_TRY(hipStreamWaitEvent(cs, S->ev_lists, 0));
                 P.tile_cull = S->d_cull, P.tile_lists = S->d_lists;
                 P.tile_list_mode = list_mode;
                 P.tiles_reversed = rowmajor_reversed;  // (mode 4 builds its list in the direction row-major order is handed out in)
-                HIP_TRY(launch_primary_cull(P, s->prep_stream));
-                HIP_TRY(hipEventRecord(S->ev_lists, s->prep_stream));
+                HIP_TRY(launch_primary_cull(P, cs));
+                HIP_TRY(hipEventRecord(S->ev_lists, cs));
                 S->key = key, S->key_valid = true;
                 if (s->trace_launches) std::fprintf(stderr, "[rbrt_hip] tile pass on the prep stream: lane %u set %d list_mode %u\n",
                                                     unsigned(&L - s->lanes.data()), int(S - L.tiles), list_mode);

@@ -878,7 +878,11 @@ constexpr uint32_t kCullLanes = 4;   // lanes per tile
 // (at most 128 VGPRs, like a trace wave: a wave of this kernel then fits the slot ONE exiting trace wave leaves on its SIMD;
 // at 140 it needed two of them to have left)
 __global__ __launch_bounds__(kCullBlock, 4) void primary_cull_kernel(const TraceParams P) {
-    const uint32_t tile = (blockIdx.x * kCullBlock + threadIdx.x) / kCullLanes;
+    // (a rank of a multi-GPU render makes the words of ITS tiles only -- tile = local * world + rank, the only words its
+    // lists and its launch read: an eighth of the pass for an eighth of the frame)
+    const uint32_t cull_world = P.tile_world > 1u ? P.tile_world : 1u;
+    const uint32_t tile_local = (blockIdx.x * kCullBlock + threadIdx.x) / kCullLanes;
+    const uint32_t tile = tile_local * cull_world + (cull_world > 1u ? P.tile_rank : 0u);
     const uint32_t quad_lane = threadIdx.x % kCullLanes, quad_shift = threadIdx.x & ~(kCullLanes - 1u);
     if (tile >= P.n_tiles) return;  // (whole quads: the votes below count active lanes only)
     const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -1288,7 +1292,9 @@ hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint3
 // The tile pass: the culling table of P.cam, then (tile_lists given) the rank's two tile lists from it.
 hipError_t launch_primary_cull(const TraceParams& P, hipStream_t stream) {
     if (P.n_tiles == 0 || !P.tile_cull) return hipSuccess;
-    const size_t cull_threads = size_t(P.n_tiles) * kCullLanes;
+    const uint32_t cull_tiles = P.tile_world > 1u ? local_tiles_of(P.n_tiles, P.tile_rank, P.tile_world) : P.n_tiles;
+    if (cull_tiles == 0u) return hipSuccess;
+    const size_t cull_threads = size_t(cull_tiles) * kCullLanes;
     hipLaunchKernelGGL(primary_cull_kernel, dim3(uint32_t((cull_threads + kCullBlock - 1) / kCullBlock)), dim3(kCullBlock), 0, stream, P);
     if (P.tile_lists) hipLaunchKernelGGL(tile_lists_kernel, dim3(1), dim3(kListBlock), 0, stream, P);
     return hipGetLastError();
