@@ -44,6 +44,11 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# The library overlaps up to eight trace launches on streams of its own; the HIP runtime maps streams onto FOUR hardware
+# queues unless told otherwise, and lanes that share a queue wait for each other (depth_for; an
+# integrator exports the same). It has to be in the environment before the runtime starts, i.e. before
+# torch is imported; a value the user exported is left alone.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 TRI_ALG_BYTES = 36     # the 9 fp32 SoA values Moller-Trumbore reads per triangle (triangle.rs:177-187)
@@ -78,7 +83,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=0,
                     help="frame pipeline depth (rbrt_hip_scene_set_pipeline): consecutive steps' trace launches overlap "
-                         "on this many internal streams; 0 = the library's automatic choice (3)")
+                         "on this many internal streams; 0 = the library's automatic choice (8)")
     ap.add_argument("--vary-seed", type=int, default=0, help="1: every step renders a new frame (seed + step number)")
     ap.add_argument("--triangles", type=int, default=69451)
     ap.add_argument("--mesh", choices=("smooth", "rough"), default="smooth",
@@ -546,7 +551,8 @@ def main():
                                f"{W}x{H}, {spp} spp, seed {args.seed}",
                    "baseline_config": args.config,
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
-                   "pipeline": (f"{args.pipeline or 'auto: 3'} trace launches in flight, half-size grids while they overlap (consecutive steps overlap)")
+                   "pipeline": (f"{args.pipeline or 'auto: 8'} trace launches in flight (two resident, the others ready), half-size grids while they overlap; "
+                                f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
                    if args.pipeline != 1 else "1 (no overlap between steps)",
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                    "launch_mix_timed_region": {"full_grid": mix_full, "half_grid": mix_half},

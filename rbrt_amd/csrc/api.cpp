@@ -277,7 +277,24 @@ constexpr uint32_t kLanesAtCreate = 4;  // lanes made by scene_create (deeper pi
 constexpr size_t kMaxTimedLaunches = 4096;  // timing events are recycled per set_timing, never more than this many launches
 
 // Depth of the frame pipeline: what was set, or 3.
-uint32_t depth_for(const rbrt_hip_scene* s) { return s->pipeline != 0 ? s->pipeline : 3u; }
+// Depth of the frame pipeline: what was set, or 8. Two half-grid launches are resident at any time; the lanes beyond them
+// hold launches that are READY the moment a resident one drains. For a short launch the time between its end and the
+// moment its lane's next launch can start (resolve, background kernel, two cross-stream hops: ~0.1 ms) is a fifth of a
+// step, and the extra lanes hide it. Measured with a new camera every frame (round 4, tools/ab_knobs.sh, per step):
+//   depth              3       4       5       6       8
+//   frame             3.50    3.55    3.76    3.58    3.50
+//   an eighth of it   0.64    0.57    0.74    0.66    0.545      (HIP runtime's default: 4 hardware queues)
+//   frame             3.50            3.51    3.50    3.48
+//   an eighth         0.64    0.567   0.552   0.545   0.527      (GPU_MAX_HW_QUEUES=8)
+// The lanes' streams map onto the runtime's hardware queues: with four of them a fifth and a sixth lane share a queue with
+// another lane's launches and barriers, unevenly (5 and 6 deep are WORSE than 4), eight lanes pair up evenly and behave like
+// four with more buffers; with eight queues deeper is monotonically better. So: 8 deep, and GPU_MAX_HW_QUEUES=8 is what
+// an integrator should export before the HIP runtime starts (bench.py and the rbrt CLI do). Before round
+// 4's one-wave short kernels a fourth lane only added a lane waiting for its starved resolve (round 3: "deeper is worse").
+uint32_t depth_for(const rbrt_hip_scene* s, uint64_t /*samples_per_launch*/) {
+    if (s->pipeline != 0) return s->pipeline;
+    return 8u;
+}
 
 // Is a trace launch of this scene still running on another lane? (What decides how the next one is issued.)
 bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane* mine) {
@@ -821,7 +838,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     if (batch < 1) batch = 1;
     if (batch > s_end - s_begin) batch = s_end - s_begin;
     const size_t need = batch * per_sample;
-    const uint32_t depth = depth_for(s);
+    const uint32_t depth = depth_for(s, uint64_t(npix) * batch);
     if (int rc = ensure_lanes(s, depth)) return rc;
     const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
         HIP_TRY(hipStreamSynchronize(stream));

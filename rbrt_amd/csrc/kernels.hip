@@ -1048,8 +1048,7 @@ __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParam
     const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
     // class of a tile: 2 = background only; 1 = light (no mesh box in reach, at most one sphere); 0 = heavy
     const uint32_t el_mask = (1u << (P.n_spheres < 24u ? P.n_spheres : 24u)) - 1u, me_mask = (1u << (P.n_meshes < 7u ? P.n_meshes : 7u)) - 1u;
-    const auto tile_class = [&](uint32_t tl) -> uint32_t {
-        const uint32_t word = P.tile_cull[tl * P.tile_world + P.tile_rank];
+    const auto class_of = [&](uint32_t word) -> uint32_t {
         if (word >> 31) return 2u;
         if (P.tile_list_mode == 0u) return 0u;
         // (the table's element bits are indexed by position in Scene::elements and are only ever set for spheres: with
@@ -1058,10 +1057,22 @@ __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParam
                            P.n_elem_tris == 0u;
         return light ? 1u : 0u;
     };
+    // (one wave walks the whole table, every lane a run of it: the table's words are fetched eight at a time, so that a
+    // lane's loads are in flight together instead of one dependent round trip per tile)
+    constexpr uint32_t kBatch = 8;
+    const auto load_batch = [&](uint32_t tl0, uint32_t (&w)[kBatch]) {
+#pragma unroll
+        for (uint32_t j = 0; j < kBatch; ++j) w[j] = tl0 + j < hi ? P.tile_cull[(tl0 + j) * P.tile_world + P.tile_rank] : 0x80000000u;
+    };
     uint32_t mine[2] = {0u, 0u};  // heavy / light tiles of this run (both go to the trace kernel)
-    for (uint32_t tl = lo; tl < hi; ++tl) {
-        const uint32_t c = tile_class(tl);
-        if (c < 2u) ++mine[c];
+    for (uint32_t tl0 = lo; tl0 < hi; tl0 += kBatch) {
+        uint32_t w[kBatch];
+        load_batch(tl0, w);
+#pragma unroll
+        for (uint32_t j = 0; j < kBatch; ++j) {
+            const uint32_t c = class_of(w[j]);
+            if (tl0 + j < hi && c < 2u) ++mine[c];
+        }
     }
     uint32_t incl[2] = {mine[0], mine[1]};
     for (uint32_t d = 1; d < kListBlock; d <<= 1) {  // inclusive scans over the wave
@@ -1083,8 +1094,14 @@ __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParam
     uint32_t n_tail = n_work / (P.tile_tail_div != 0u ? P.tile_tail_div : 8u);
     n_tail = n_tail < n_light ? n_tail : n_light;
     const uint32_t n_front_light = n_light - n_tail;  // light tiles that stay in row-major order
-    for (uint32_t tl = lo; tl < hi; ++tl) {
-        const uint32_t c = tile_class(tl);
+    for (uint32_t tl0 = lo; tl0 < hi; tl0 += kBatch) {
+      uint32_t w[kBatch];
+      load_batch(tl0, w);
+#pragma unroll
+      for (uint32_t j = 0; j < kBatch; ++j) {
+        const uint32_t tl = tl0 + j;
+        if (tl >= hi) continue;
+        const uint32_t c = class_of(w[j]);
         if (c == 2u) {
             sky[k++] = tl;
             continue;
@@ -1104,6 +1121,7 @@ __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParam
             pos = (P.tile_list_mode == 1u ? n_heavy : P.tile_list_mode == 2u && r[1] >= half ? n_heavy : 0u) + r[1]++;
         }
         work[pos] = tl;
+      }
     }
     if (t == kListBlock - 1) {
         P.tile_lists[0] = n_work;

@@ -66,6 +66,10 @@ bool parse_u32(const char* s, uint32_t& out) {
 }  // namespace
 
 int main(int argc, char** argv) {
+    // The library overlaps up to eight trace launches on streams of its own; the HIP runtime maps streams onto four hardware
+    // queues unless told otherwise, and lanes that share a queue wait for each other (depth_for).
+    // Set before the first HIP call; a value the user exported is left alone.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     std::string target = "dbg_out.png", config = "scenes/example_scene.yaml";
     uint32_t height = 600, width = 800, samples = 5, gpus = 1, pass_samples = 0, checkpoint_every = 1;
     std::string gather = "host", checkpoint, report_path;
