@@ -291,9 +291,13 @@ constexpr size_t kMaxTimedLaunches = 4096;  // timing events are recycled per se
 // four with more buffers; with eight queues deeper is monotonically better. So: 8 deep, and GPU_MAX_HW_QUEUES=8 is what
 // an integrator should export before the HIP runtime starts (bench.py and the rbrt CLI do). Before round
 // 4's one-wave short kernels a fourth lane only added a lane waiting for its starved resolve (round 3: "deeper is worse").
-uint32_t depth_for(const rbrt_hip_scene* s, uint64_t /*samples_per_launch*/) {
+// (Every lane has a sample buffer of its own: the lanes' buffers together stay within 8 GiB -- eight lanes at the default
+// workspace cap of 1 GiB --, but there are never fewer than three: a caller who raises RBRT_HIP_WORKSPACE_MB gets long
+// launches, which need no deep pipeline.)
+uint32_t depth_for(const rbrt_hip_scene* s, size_t sample_buffer_bytes) {
     if (s->pipeline != 0) return s->pipeline;
-    return 8u;
+    const size_t fit = (size_t(8) << 30) / (sample_buffer_bytes ? sample_buffer_bytes : 1);
+    return fit >= 8 ? 8u : fit >= 4 ? 4u : 3u;  // (never 5 to 7: with the runtime's four hardware queues they are worse than 4)
 }
 
 // Is a trace launch of this scene still running on another lane? (What decides how the next one is issued.)
@@ -838,7 +842,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     if (batch < 1) batch = 1;
     if (batch > s_end - s_begin) batch = s_end - s_begin;
     const size_t need = batch * per_sample;
-    const uint32_t depth = depth_for(s, uint64_t(npix) * batch);
+    const uint32_t depth = depth_for(s, need);
     if (int rc = ensure_lanes(s, depth)) return rc;
     const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
         HIP_TRY(hipStreamSynchronize(stream));
@@ -991,7 +995,21 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         const uint32_t base = s_begin + uint32_t(b * batch);
         const uint32_t nb = uint32_t(std::min<size_t>(batch, s_end - base));
         // counting launches run alone on lane 0: their counters are reset and read on the caller's stream
-        rbrt_hip_scene::Lane& L = s->lanes[stats ? 0 : s->next_lane++ % depth];
+        // (the lanes take turns; but a launch that finds nothing of this scene in flight and is not one of a stream -- a
+        // blocking caller's -- goes to a lane that already has the tile tables of its camera, if there is one: with eight
+        // lanes taking turns a caller who renders one view again and again would otherwise pay the tile pass eight times)
+        uint32_t lane_no = stats ? 0u : s->next_lane % depth;
+        if (!stats && depth > 1 && s->primary_cull != 0 && !s->streaming_hint && !other_launch_in_flight(s, nullptr)) {
+            rbrt_hip_scene::Lane::TileKey want;
+            std::memset(&want, 0, sizeof(want));
+            want.cam = *cam, want.rank = o->tile_rank, want.world = world, want.list_mode = list_mode_for(s, false);
+            for (uint32_t li = 0; li < depth; ++li)
+                for (const auto& C : s->lanes[li].tiles)
+                    if (C.key_valid && std::memcmp(&want, &C.key, sizeof(want)) == 0) lane_no = li;
+        } else if (!stats) {
+            ++s->next_lane;
+        }
+        rbrt_hip_scene::Lane& L = s->lanes[lane_no];
         const bool piped = depth > 1 && !stats;
         hipStream_t ts = piped ? L.stream : stream;  // the trace launch's stream
         rbrt_hip_scene::Lane::Buf& B = L.bufs[0];
