@@ -205,16 +205,20 @@ def main():
     if world > 1:
         slot_pixels = rbrt_amd.packed_pixels(W, H, 0, world)  # rank 0 owns the most tiles: equal-size slots
         maxn = slot_pixels * 3
-        # Two sets of buffers and a side stream: the gather of frame k (and rank 0's unpack) runs beside the render of
-        # frame k + 1 instead of in front of it -- the render's resolve kernel, which frees a pipeline lane for its
-        # next launch, does not queue behind a collective that waits for the slowest rank.
-        mine = [torch.empty(maxn, dtype=torch.float32, device=dev) for _ in range(2)]  # this rank's tiles (tail of the slot unused)
+        # NBUF sets of buffers and a side stream: the gather of frame k (and rank 0's unpack) runs beside the renders of
+        # the frames after it instead of in front of them -- the render's resolve kernel, which frees a pipeline lane for
+        # its next launch, does not queue behind a collective that waits for the slowest rank. Four sets (round 4; two
+        # before): the collective's kernels are multi-wave workgroups and, like every kernel beside the persistent trace
+        # launches, start only when a launch drains (DESIGN.md section 6 "Short kernels beside a persistent one"); a step
+        # of an eighth is 0.5 ms, so a gather may take three steps before a render has to wait for its buffer.
+        NBUF = 4
+        mine = [torch.empty(maxn, dtype=torch.float32, device=dev) for _ in range(NBUF)]  # this rank's tiles (tail of the slot unused)
         # rank 0 receives straight into one buffer of `world` equal slots; the unpack kernel strides over it
-        slots = [torch.empty(world * maxn, dtype=torch.float32, device=dev) for _ in range(2)] if rank == 0 else None
-        gathered = [list(sl.chunk(world)) for sl in slots] if rank == 0 else [None, None]
+        slots = [torch.empty(world * maxn, dtype=torch.float32, device=dev) for _ in range(NBUF)] if rank == 0 else None
+        gathered = [list(sl.chunk(world)) for sl in slots] if rank == 0 else [None] * NBUF
         xs = torch.cuda.Stream(device=dev, priority=-1)  # (high priority: short kernels among persistent ones)
-        rendered = [torch.cuda.Event(), torch.cuda.Event()]
-        gathered_ev = [None, None]
+        rendered = [torch.cuda.Event() for _ in range(NBUF)]
+        gathered_ev = [None] * NBUF
 
     step_no = [0]
     cam_no = [0]
@@ -245,17 +249,17 @@ def main():
         if world == 1:
             scene.render_device(c, opts, image.data_ptr(), None, stream)  # (emulation: packed tiles, fits)
             return
-        b = step_no[0] & 1
+        b = step_no[0] % NBUF
         main = torch.cuda.current_stream()
         if gathered_ev[b] is not None:
-            main.wait_event(gathered_ev[b])  # the gather of two frames ago has read this buffer
+            main.wait_event(gathered_ev[b])  # the gather of NBUF frames ago has read this buffer
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
         if evs:
             evs[0].record(main)
         scene.render_device(c, opts, mine[b].data_ptr(), None, stream)
-        rendered[b].record(main)
         if evs:
-            evs[1].record(main)
+            evs[1].record(main)  # (ahead of the event the side stream waits for: the spans below cannot come out negative)
+        rendered[b].record(main)
         xs.wait_event(rendered[b])
         with torch.cuda.stream(xs):
             if evs:
