@@ -72,11 +72,12 @@ ISSUE_COST = {"valu_mean": 0.62 * 2.0 + 0.355 * 3.1 + 0.025 * 6.1, "salu": 2.0, 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40,
-                    help="timed steps (default 40: after the fence that opens the timed region the frame pipeline starts from an idle "
-                         "GPU with its launches bunched and needs about six frames to spread them out again, profiles/r04_trace_frames.txt; "
-                         "20 steps charge that start-up at 2.3 %% of the figure, 40 at 1.2 %%)")
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100,
+                    help="timed steps (default 100 = 0.35 s: behind the fence that opens the timed region the frame pipeline starts from "
+                         "an idle GPU with its launches bunched and needs about six frames to spread them out, and the last launches "
+                         "drain with nothing behind them -- together ~3 ms, profiles/r04_trace_frames.txt: 4 %% of a 20-step figure, "
+                         "2 %% of a 40-step one, under 1 %% of this one; steady state is 3.41 ms per frame)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--spp", type=int, default=50)
