@@ -619,7 +619,7 @@ def main():
         out["cpu_baseline"] = {
             "value": round(cpu_samples / cpu_s / 1e6, 4), "unit": "Mray-samples/s", "cores": n_threads,
             "host_logical_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"{'every column' if args.cpu_col_stride == 1 else f'every {args.cpu_col_stride}th column'} ({cols} of {W}) x {H} rows x {spp} spp of the same "
+            "sample": f"{'every column' if args.cpu_col_stride == 1 else 'every 2nd column' if args.cpu_col_stride == 2 else f'every {args.cpu_col_stride}th column'} ({cols} of {W}) x {H} rows x {spp} spp of the same "
                       f"scene and seed, {cpu_s:.1f} s; C++ restatement of the reference AVX path (brute force over "
                       f"all triangles), not the Rust binary{cpu_note}",
         }
