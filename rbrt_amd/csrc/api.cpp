@@ -965,6 +965,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         T.tile_list_mode = list_mode_for(s, true);  // (what the launches of a stream use; an isolated launch makes its own list)
         T.tile_tail_div = s->tile_tail_div;
         T.tiles_reversed = P.tiles_reversed;
+        T.tile_lists_wide = 1u;  // (a scene's first call: nothing of it is in flight)
         for (uint32_t li = 0; li < depth; ++li) {
             rbrt_hip_scene::Lane& L = s->lanes[li];
             if (L.tiles[0].key_valid || L.tiles[1].key_valid) continue;
@@ -1057,6 +1058,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
                 P.tile_cull = S->d_cull, P.tile_lists = S->d_lists;
                 P.tile_list_mode = list_mode;
                 P.tiles_reversed = rowmajor_reversed;  // (mode 4 builds its list in the direction row-major order is handed out in)
+                P.tile_lists_wide = overlapped ? 0u : 1u;
                 HIP_TRY(launch_primary_cull(P, cs));
                 HIP_TRY(hipEventRecord(S->ev_lists, cs));
                 S->key = key, S->key_valid = true;
@@ -1221,6 +1223,9 @@ int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const r
     if (!cam || !scene || !opts) return fail(RBRT_ERR_INVALID_ARG, "render: null argument");
     rbrt_hip_scene_t* s = nullptr;
     if (int rc = rbrt_hip_scene_create(scene, 0, &s)) return rc;
+    // (one frame and the scene is gone again: the batches of this one render overlap on three lanes as before; the eight
+    // lanes of a scene that serves a stream of frames would only be allocated -- 8 sample buffers, 1 GB of scratch -- and freed)
+    if (s->pipeline == 0) s->pipeline = 3;
     const uint32_t world = opts->tile_world ? opts->tile_world : 1;
     const size_t npix_img = size_t(cam->img_width_pix) * cam->img_height_pix;
     const size_t n_out = world > 1

@@ -160,6 +160,7 @@ struct TraceParams {
     uint32_t* tile_lists;
     uint32_t tile_list_mode;  // order of the work list (tile_lists_kernel)
     uint32_t tile_tail_div;   // mode 4: the last n_work / this light tiles of the row-major order are handed out at the very end
+    uint32_t tile_lists_wide;  // 1: tile_lists_kernel as four waves (a launch that has the GPU to itself); 0: as one wave
 };
 
 struct ResolveParams {

@@ -1041,7 +1041,9 @@ __global__ __launch_bounds__(kCullBlock, 4) void primary_cull_kernel(const Trace
 // kernel has to find room beside resident trace waves, which hold every wave slot and all of every CU's LDS. A 1024-thread
 // workgroup waited milliseconds for a whole free CU (round 3), the 256-thread one with its 2 KB of LDS that followed still
 // needed four free slots on one CU at once (round 4's trace: up to 3 ms).)
-constexpr int kListBlock = 64;
+// kListBlock = 256 (four waves, 32 bytes of LDS for their totals) is the form for a launch that has the GPU to itself -- nothing
+// to fit beside, and a quarter of the table per wave: 0.075 -> 0.03 ms in front of a blocking frame of a new camera.
+template <int kListBlock>
 __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParams P) {
     const uint32_t n = P.n_local_tiles, t = threadIdx.x;
     const uint32_t per = (n + kListBlock - 1) / kListBlock;
@@ -1075,11 +1077,22 @@ __global__ __launch_bounds__(kListBlock) void tile_lists_kernel(const TraceParam
         }
     }
     uint32_t incl[2] = {mine[0], mine[1]};
-    for (uint32_t d = 1; d < kListBlock; d <<= 1) {  // inclusive scans over the wave
+    const uint32_t wlane = t & 63u;
+    for (uint32_t d = 1; d < 64u; d <<= 1) {  // inclusive scans over the wave
         const uint32_t v0 = uint32_t(__shfl_up(int(incl[0]), d, 64)), v1 = uint32_t(__shfl_up(int(incl[1]), d, 64));
-        if (t >= d) incl[0] += v0, incl[1] += v1;
+        if (wlane >= d) incl[0] += v0, incl[1] += v1;
     }
-    const uint32_t n_heavy = uint32_t(__shfl(int(incl[0]), kListBlock - 1, 64)), n_light = uint32_t(__shfl(int(incl[1]), kListBlock - 1, 64));
+    uint32_t n_heavy = uint32_t(__shfl(int(incl[0]), 63, 64)), n_light = uint32_t(__shfl(int(incl[1]), 63, 64));
+    if (kListBlock > 64) {  // ... and over the workgroup's waves, through their totals
+        __shared__ uint32_t wave_total[2][kListBlock / 64];
+        if (wlane == 63u) wave_total[0][t >> 6] = n_heavy, wave_total[1][t >> 6] = n_light;
+        __syncthreads();
+        n_heavy = n_light = 0u;
+        for (uint32_t w = 0; w < uint32_t(kListBlock / 64); ++w) {
+            if (w < (t >> 6)) incl[0] += wave_total[0][w], incl[1] += wave_total[1][w];
+            n_heavy += wave_total[0][w], n_light += wave_total[1][w];
+        }
+    }
     const uint32_t n_work = n_heavy + n_light;
     uint32_t r[2] = {incl[0] - mine[0], incl[1] - mine[1]};  // heavy / light tiles before this run
     uint32_t k = lo - r[0] - r[1];                                  // background-only tiles before it
@@ -1314,7 +1327,10 @@ hipError_t launch_primary_cull(const TraceParams& P, hipStream_t stream) {
     if (cull_tiles == 0u) return hipSuccess;
     const size_t cull_threads = size_t(cull_tiles) * kCullLanes;
     hipLaunchKernelGGL(primary_cull_kernel, dim3(uint32_t((cull_threads + kCullBlock - 1) / kCullBlock)), dim3(kCullBlock), 0, stream, P);
-    if (P.tile_lists) hipLaunchKernelGGL(tile_lists_kernel, dim3(1), dim3(kListBlock), 0, stream, P);
+    if (P.tile_lists) {
+        if (P.tile_lists_wide) hipLaunchKernelGGL(tile_lists_kernel<256>, dim3(1), dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL(tile_lists_kernel<64>, dim3(1), dim3(64), 0, stream, P);
+    }
     return hipGetLastError();
 }
 

@@ -286,6 +286,9 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
         const size_t npix = world > 1 ? rbrt_hip_packed_pixels(img.width, img.height, o.tile_rank, o.tile_world)
                                       : size_t(img.width) * img.height;
         if (rbrt_hip_scene_create(&view.scene, dev, &hs) != RBRT_OK) fail(rbrt_hip_last_error());
+        // (every pass is followed by a synchronisation here: only the sample batches INSIDE a pass overlap, on three lanes;
+        // the library's default of eight is for streams of frames)
+        if (hs) (void)rbrt_hip_scene_set_pipeline(hs, 3);
         if (hs && rank == 0) {
             rbrt_hip_scene_info_t info;
             if (rbrt_hip_scene_info(hs, &info) == RBRT_OK) {
