@@ -556,7 +556,7 @@ def main():
                                f"{W}x{H}, {spp} spp, seed {args.seed}",
                    "baseline_config": args.config,
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
-                   "pipeline": (f"{args.pipeline or 'auto: 8'} trace launches in flight (two resident, the others ready), half-size grids while they overlap; "
+                   "pipeline": (f"{args.pipeline or 'auto: 8'} trace launches in flight, each on 3 of a CU's 16 wave slots while they overlap (together 1.5x the slots there are); "
                                 f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
                    if args.pipeline != 1 else "1 (no overlap between steps)",
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),

@@ -23,6 +23,8 @@
  *                                light/2|heavy|light/2, light|heavy, or (4) row-major order with its last light tiles moved to the end
  *   RBRT_TILE_ISOLATED_MODE=0..4 the list mode of a launch that has the GPU to itself (4); a launch of a stream uses 0
  *   RBRT_TILE_TAIL_DIV=1..1024   mode 4: the share of the work list (1/n, 8) that is handed out last, from light tiles
+ *   RBRT_OVERLAP_WAVES_PER_CU=0..16  waves per CU of a launch of a stream (0: 24 / pipeline depth, rounded up: 3 at depth 8)
+ *   RBRT_TRACE_LAUNCHES=1        one stderr line per trace launch and per tile pass (which lane, grid, table set)
  */
 #ifndef RBRT_HIP_DEBUG_H
 #define RBRT_HIP_DEBUG_H

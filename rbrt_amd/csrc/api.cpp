@@ -167,6 +167,7 @@ struct rbrt_hip_scene {
     uint32_t scratch_waves = 0;
     uint32_t n_cus = 256;
     bool waves_fixed = false;  // RBRT_WAVES_PER_CU given: no automatic half-size grids
+    uint32_t overlap_waves_per_cu = 0;  // RBRT_OVERLAP_WAVES_PER_CU: waves per CU of a launch issued while another is running (0: automatic)
     uint32_t next_lane = 0;
     float* d_acc = nullptr;
     size_t acc_bytes = 0;
@@ -311,17 +312,27 @@ bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane*
     return busy;
 }
 
-// Waves of one trace launch. A launch that finds the GPU idle (a blocking caller, the first frame of a stream)
-// takes all resident wave slots. One issued while another is still running -- consecutive frames or sample batches
-// queued back to back -- takes HALF, so that two launches are resident side by side (one's drain always has the
-// other's bulk to share the SIMDs with) and a third is queued behind them. Measured per step on config 2, full
-// grids 2 deep against half grids 3 deep: the whole frame 4.43 vs 4.25 ms, a half 2.88 vs 2.53, a quarter 1.78 vs
-// 1.45, an eighth 1.18 vs 0.91 (half grids 2 or 4 deep are worse; 12 of 16 slots is worse than either: the second
-// launch then gets the 4 that are left).
-uint32_t grid_for(const rbrt_hip_scene* s, bool overlapped) {
+// Waves of one trace launch. A launch that finds the GPU idle (a blocking caller, the first frame of a stream) takes all
+// resident wave slots. One issued while another is still running -- consecutive frames or sample batches queued back to
+// back -- takes a PART of them, sized so that the lanes of the pipeline together ask for one and a half times the slots there
+// are: 3 of a CU's 16 with eight lanes, 6 with four, 8 with three. The launches then run side by side, each wave works
+// through more items before its pool runs empty (the drain's share of a launch shrinks with the grid), and what one
+// launch's drain frees the waves of the queued ones take at once. Measured, eight lanes, new camera every frame, waves per
+// CU of an overlapped launch -> ms per frame / half / quarter / eighth of config 2 (tools/ab_knobs.sh):
+//    8 (rounds 2-3: "half the slots")   3.47   1.80   0.945   0.509
+//    4                                  3.44   1.78   0.905   0.478
+//    3                                  3.43   1.776  0.900   0.475     (rough stand-in 5.25 -> 5.20, visible 871k mesh 4.28 -> 4.23)
+//    2 (all lanes resident, none queued) 3.46  1.825  0.967   0.547
+//    1                                  5.93   3.11   1.61    0.87
+// Twelve lanes of 2 or 3 waves per CU on sixteen hardware queues: the same as eight of 3 (3.42-3.43 / 0.470-0.471); sixteen: worse.
+// (Rounds 2-3 had found smaller grids and deeper pipelines worse than half grids three deep: every launch's resolve then
+// waited for a draining launch, DESIGN.md section 6 "Short kernels beside a persistent one".)
+uint32_t grid_for(const rbrt_hip_scene* s, bool overlapped, uint32_t depth) {
     if (s->waves_fixed || !overlapped) return s->n_waves;
-    const uint32_t half = s->n_cus * 8u;
-    return half < s->n_waves ? half : s->n_waves;
+    uint32_t per_cu = s->overlap_waves_per_cu;  // (lab knob; 0: by the pipeline's depth)
+    if (per_cu == 0u) per_cu = depth >= 2u ? (24u + depth - 1u) / depth : 16u;
+    const uint32_t part = s->n_cus * per_cu;
+    return part < s->n_waves ? part : s->n_waves;
 }
 
 // In which order a launch's tiles are handed out (tile_lists_kernel's modes), by what KIND of launch it is -- a rule, not a
@@ -718,6 +729,7 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             lab_u32("RBRT_SHADE_CONT_MIN", 1, 64, s->shade_cont_min, err) && lab_u32("RBRT_PIPELINE", 0, kMaxPipeline, s->pipeline, err) &&
             lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err) && lab_u32("RBRT_PRIMARY_CULL", 0, 1, s->primary_cull, err) &&
             lab_u32("RBRT_TILE_ORDER", 0, 2, s->tile_order, err) && lab_u32("RBRT_TILE_CLASSES", 0, 4, s->tile_classes, err) &&
+            lab_u32("RBRT_OVERLAP_WAVES_PER_CU", 0, 16, s->overlap_waves_per_cu, err) &&
             lab_u32("RBRT_TILE_ISOLATED_MODE", 0, 4, s->isolated_list_mode, err) && lab_u32("RBRT_TILE_TAIL_DIV", 1, 1024, s->tile_tail_div, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
         s->tile_classes_set = lab_env("RBRT_TILE_CLASSES") != nullptr;
@@ -1031,7 +1043,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         s->streaming_hint = busy;
         P.work_stripes = !overlapped ? s->work_stripes
                          : s->work_stripes_overlap != kStripesAuto ? s->work_stripes_overlap
-                         : P.n_items < 20000000ull ? 4u : 0u;
+                         : 0u;  // (contiguous shards; with half grids three deep small launches preferred stripes of 4, round 3)
         P.sample_buf = B.d_sample_buf;
         P.work_counter = B.d_work_counter;
         P.gseq = L.d_gseq;
@@ -1080,7 +1092,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(B.d_sample_buf, 0xFF, B.sample_buf_bytes, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
         if (S) HIP_TRY(hipStreamWaitEvent(ts, S->ev_lists, 0));  // (the set's tables: made on the prep stream, or at the first call on the caller's)
-        const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped);
+        const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped, depth);
         (grid < s->n_waves ? s->n_half_grid : s->n_full_grid) += 1;
         HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, s->share_idle != 0u && P.n_items < s->share_below, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
