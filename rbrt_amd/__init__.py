@@ -149,6 +149,7 @@ class HipScene:
                  drain_sum=dict(rounds=int(buf[51]), trav_steps=int(buf[52]), passes=int(buf[53]),
                                 lane_steps=int(buf[54])),
                  stack_pushes_beyond_lds=int(buf[30]), stack_deepest=int(buf[31]),
+                 parked_at_burst_entry=int(buf[55]), fullest_shading_kind_at_burst_entry=int(buf[56]),
                  shared_entries_given=int(buf[59]), share_rounds=int(buf[60]), traversals_ending_at_root=int(buf[61]),
                  sphere_tail_runs=int(buf[62]), sphere_tail_lanes=int(buf[63]))
         return d

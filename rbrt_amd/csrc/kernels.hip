@@ -380,8 +380,11 @@ __device__ __forceinline__ void node4_visit(const BvhNode4* node, const RayCull&
     me = *RBRT_AS1(f32x4, nb + 112);
     links = *RBRT_AS1(f32x4, nb + 96);
     // one pad for the node: the largest of its children's error terms (siblings have similar triangles)
-    const float pad = __builtin_fmaf(rc.pad_k, __builtin_fmaxf(__builtin_fmaxf(me.x, me.y), __builtin_fmaxf(me.z, me.w)),
-                                     rc.pad_base);
+    // (the error terms are products of lengths, >= +0: the order of their bits as integers is their order, and an integer
+    // max3 needs no canonicalising v_max x, x, x in front of it, which fmaxf of a loaded value gets. A NaN -- a mesh with
+    // non-finite vertices -- comes out as the maximum and makes every test of the node pass.)
+    const uint32_t me_max = max(max(__float_as_uint(me.x), __float_as_uint(me.y)), max(__float_as_uint(me.z), __float_as_uint(me.w)));
+    const float pad = __builtin_fmaf(rc.pad_k, __uint_as_float(me_max), rc.pad_base);
     // the pad in ray-parameter units, per axis (|1/d| may be inf: the plane parameters are then +-inf or NaN,
     // which only makes the test more permissive)
     const V3 pt = mk(pad * __builtin_fabsf(rc.inv.x), pad * __builtin_fabsf(rc.inv.y), pad * __builtin_fabsf(rc.inv.z));

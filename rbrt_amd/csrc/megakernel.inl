@@ -311,6 +311,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     uint32_t n_samples_done = 0;
     uint32_t dg_pass[kNumStatus] = {0, 0, 0, 0, 0, 0}, dg_lanes[kNumStatus] = {0, 0, 0, 0, 0, 0};
     uint32_t dg_steps = 0, dg_lane_steps = 0, dg_refills = 0, dg_census = 0;
+    uint32_t dg_parked_at_burst = 0, dg_shade_at_burst = 0;
+    uint32_t dg_mix_free = 0, dg_mix_take8 = 0, dg_mix_pass8 = 0, dg_mix_take16 = 0, dg_mix_pass16 = 0;
     uint32_t dg_dr_rounds = 0, dg_dr_steps = 0, dg_dr_passes = 0, dg_dr_lane_steps = 0;  // after the work ran out
     unsigned long long dg_t_trav = 0, dg_t_shade = 0, dg_t0 = 0, dg_tk = 0;
     uint32_t dg_share_rounds = 0, dg_share_given = 0, dg_root_only = 0, dg_sph_tails = 0, dg_sph_pairs = 0;
@@ -518,6 +520,8 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 ++dg_pass[ST_TRAV];
                 if (best == 0) ++dg_pass[ST_EMPTY];  // diag[0]: traversal entered because nothing else to do
                 dg_lanes[ST_EMPTY] += n_active;       // diag[6]: sum of busy lanes at entry
+                dg_parked_at_burst += cnt[ST_TRAV];   // diag[55]: rays parked (no lane yet) at entry
+                dg_shade_at_burst += best;            // diag[56]: slots of the fullest shading kind at entry
                 dg_tk = __builtin_amdgcn_s_memtime();
             }
             // leave as soon as enough lanes are idle to make a refill / shading pass worthwhile; when no
@@ -790,6 +794,16 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         }
         const uint32_t n_gen = c1 < 64u - n_main ? c1 : 64u - n_main;
         __syncthreads();
+        if (STATS) {  // what a pass of mixed kinds would have picked up: the fullest OTHER scatter kind, into the free lanes
+            const uint32_t free_lanes = 64u - n_main - n_gen;
+            uint32_t other = 0;
+            for (uint32_t k2 = ST_LAMB; k2 <= ST_DIEL; ++k2)
+                if (k2 != kind && cnt[k2] > other) other = cnt[k2];
+            const uint32_t take = other < free_lanes ? other : free_lanes;
+            dg_mix_free += free_lanes;
+            if (take >= 8u) dg_mix_take8 += take, ++dg_mix_pass8;
+            if (take >= 16u) dg_mix_take16 += take, ++dg_mix_pass16;
+        }
         const bool is_main = lane < n_main;
         const bool is_gen = !is_main && lane < n_main + n_gen;
         if (STATS) dg_lanes[kind] += n_main + n_gen;
@@ -1133,6 +1147,11 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 atomicAdd(&P.counters->diag[53], (unsigned long long)dg_dr_passes);
                 atomicAdd(&P.counters->diag[54], (unsigned long long)dg_dr_lane_steps);
             }
+            atomicAdd(&P.counters->diag[55], (unsigned long long)dg_parked_at_burst);
+            atomicAdd(&P.counters->diag[23], (unsigned long long)dg_mix_free);
+            atomicAdd(&P.counters->diag[49], (((unsigned long long)dg_mix_pass8) << 32) | dg_mix_take8);
+            atomicAdd(&P.counters->diag[58], (((unsigned long long)dg_mix_pass16) << 32) | dg_mix_take16);
+            atomicAdd(&P.counters->diag[56], (unsigned long long)dg_shade_at_burst);
             atomicAdd(&P.counters->diag[12], (unsigned long long)dg_steps);
             atomicAdd(&P.counters->diag[13], (unsigned long long)dg_lane_steps);
             atomicAdd(&P.counters->diag[14], (unsigned long long)dg_refills);

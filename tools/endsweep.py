@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--spp", type=int, default=50)
     args = ap.parse_args()
     os.environ["RBRT_HIP_LAB"] = "1"
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (as bench.py and the CLI do: the library's pipeline is eight streams deep)
     import torch
 
     import rbrt_amd

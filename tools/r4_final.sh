@@ -17,5 +17,11 @@ step bench2r 300 python3 bench.py $C --config 2r
 step bench4 300 python3 bench.py $C --config 4
 step bench4v 300 python3 bench.py $C --config 4v
 step moving 300 python3 tools/moving_camera.py
+step lane_use 300 python3 tools/lane_use.py
+step lane_use_r8 300 python3 tools/lane_use.py --world 8
+if [ -f rbrt_amd/lib/librbrt_hip_timers.so ]; then  # (make timers, before the session: the box has no need to compile)
+  RBRT_HIP_LIB=rbrt_amd/lib/librbrt_hip_timers.so step regions_full 300 python3 tools/region_profile.py
+  RBRT_HIP_LIB=rbrt_amd/lib/librbrt_hip_timers.so step regions_r8 300 python3 tools/region_profile.py --emulate-rank-of 8
+fi
 step profile 1100 bash tools/profile.sh
 echo "session done"
