@@ -8,8 +8,10 @@ A step = one full render of the workload: scenes/example_scene.yaml (the referen
 with the 69,451-triangle STAND-IN for bunny.obj (the real asset is not available offline),
 1024x768, 50 samples per pixel, seed 1. With N ranks the image's 8x8 pixel tiles are dealt
 round-robin to the ranks (every rank holds the whole scene + BVH), each rank renders its tiles with
-the same kernel, and one RCCL gather over xGMI brings the packed fp32 radiance to rank 0, which
-de-interleaves it — so the total work per step is fixed ("scaling": "strong").
+the same kernel, and a gather over xGMI brings the packed fp32 radiance to rank 0, which
+de-interleaves it — so the total work per step is fixed ("scaling": "strong"). The gather is RCCL's (dist.gather) or
+rank 0 pulling the peers' buffers through HIP IPC with device copies (--gather; by default a short untimed probe picks
+the faster: RCCL's copy kernels need wave slots beside the persistent trace launches, the copy engines do not).
 
 The scene is resident in HBM before the timed region (upload + BVH build are setup); the timed
 region is K x [render kernels + gather + unpack], bracketed by barrier + synchronize, MAX over ranks.
@@ -69,6 +71,76 @@ INT_FULL_FRAC = 0.58  # of the binary's integer VALU instructions, those that is
 ISSUE_COST = {"valu_mean": 0.62 * 2.0 + 0.355 * 3.1 + 0.025 * 6.1, "salu": 2.0, "lds": 6.0, "vmem": 4.0}
 
 
+def setup_ipc_gather(torch, dist, np, rank, world, dev, mine, nbuf, guarded, timeout_s=60.0):
+    """The IPC gather's shared objects (see main(): "The IPC gather"). Collective: every rank calls it. Returns a dict with
+    ok / why and, when ok, the opened buffers and events, and set_flag / wait_flag over the ranks' step counters in /dev/shm.
+    Any failure on any rank makes every rank return ok = False (the caller then gathers with dist.gather)."""
+    st = {"ok": False, "why": "", "last_use": [0] * nbuf}
+    payload, err = None, ""
+    try:
+        from torch.multiprocessing.reductions import reduce_tensor
+        rendered = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(nbuf)]
+        consumed = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(nbuf)] if rank == 0 else []
+        for e in rendered + consumed:
+            e.record()
+        payload = {"mine": [reduce_tensor(t) for t in mine], "rendered": [e.ipc_handle() for e in rendered],
+                   "consumed": [e.ipc_handle() for e in consumed]}
+        st["rendered"], st["consumed"] = rendered, consumed
+    except Exception as e:  # (a torch build or a driver without IPC)
+        err = f"export: {type(e).__name__}: {e}"
+    got = [None] * world
+    guarded(lambda: dist.all_gather_object(got, (payload, err)))
+    flags = None
+    if not err and all(g[0] is not None for g in got):
+        try:
+            if rank == 0:
+                st["peer_mine"] = [None] + [[fn(*a) for fn, a in got[r][0]["mine"]] for r in range(1, world)]
+                st["peer_rendered"] = [None] + [[torch.cuda.Event.from_ipc_handle(dev, h) for h in got[r][0]["rendered"]]
+                                                for r in range(1, world)]
+            else:
+                st["consumed_by_rank0"] = [torch.cuda.Event.from_ipc_handle(dev, h) for h in got[0][0]["consumed"]]
+        except Exception as e:
+            err = f"open: {type(e).__name__}: {e}"
+    name = [f"/dev/shm/rbrt_bench_flags_{os.getpid()}_{os.environ.get('MASTER_PORT', '0')}"]
+    try:
+        if rank == 0 and not err:
+            flags = np.memmap(name[0], dtype=np.int64, mode="w+", shape=(world + 1,))
+            flags[:] = 0
+            flags.flush()
+    except Exception as e:
+        err = f"flags: {type(e).__name__}: {e}"
+    guarded(lambda: dist.broadcast_object_list(name, src=0))
+    try:
+        if rank != 0 and not err:
+            flags = np.memmap(name[0], dtype=np.int64, mode="r+", shape=(world + 1,))
+    except Exception as e:
+        err = f"flags: {type(e).__name__}: {e}"
+    errs = [None] * world
+    guarded(lambda: dist.all_gather_object(errs, err))  # (also: every rank has the file open before rank 0 unlinks it)
+    if rank == 0:
+        try:
+            os.unlink(name[0])
+        except OSError:
+            pass
+    bad = [f"rank {r}: {e or g[1]}" for r, (e, g) in enumerate(zip(errs, got)) if e or g[1] or g[0] is None]
+    if bad:
+        st["why"] = "; ".join(bad)
+        return st
+
+    def set_flag(i, v):
+        flags[i] = v
+
+    def wait_flag(i, v):
+        t0 = time.perf_counter()
+        while int(flags[i]) < v:
+            if time.perf_counter() - t0 > timeout_s:
+                raise RuntimeError(f"IPC gather: rank {rank} waited {timeout_s:.0f} s for step {v} of counter {i} (at {int(flags[i])})")
+            time.sleep(0)
+
+    st.update(ok=True, why="", set_flag=set_flag, wait_flag=wait_flag, flags=flags)
+    return st
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +187,12 @@ def parse_args():
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="WORLD",
                     help="single process: time only rank 0's share of a WORLD-GPU run (its tiles, no gather); a "
                          "scaling estimate for one-GPU boxes, not a benchmark result")
+    ap.add_argument("--gather", choices=("auto", "rccl", "ipc"), default="auto",
+                    help="N > 1: how rank 0 gets the other ranks' tiles. rccl: dist.gather (copy KERNELS, which need wave slots "
+                         "beside the persistent trace launches); ipc: rank 0 maps the peers' buffers (HIP IPC) and pulls them with "
+                         "device copies behind interprocess events (copy engines, no wave slots); auto: a short probe of both, the "
+                         "faster one is used (rccl when the IPC set-up fails on any rank)")
+    ap.add_argument("--gather-probe-steps", type=int, default=8, help="--gather auto: steps per probe leg (untimed, before the warm-up)")
     ap.add_argument("--rehearse-single-gpu", action="store_true",
                     help="N > 1 ranks all on cuda:0 with a gloo gather through host memory: exercises the sharded "
                          "path on a one-GPU box; its numbers mean nothing")
@@ -202,6 +280,16 @@ def main():
         opts.max_depth = int(os.environ["RBRT_BENCH_MAX_DEPTH"])
     stream = torch.cuda.current_stream().cuda_stream
 
+    import numpy as np_mod
+
+    def guarded_early(fn):
+        try:
+            return fn()
+        except Exception as e:
+            sys.stderr.write(f"bench.py rank {rank}/{world}: a collective failed during set-up ({type(e).__name__}: {e}); no result line\n")
+            sys.stderr.flush()
+            os._exit(4)
+
     image = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
     if world > 1:
         slot_pixels = rbrt_amd.packed_pixels(W, H, 0, world)  # rank 0 owns the most tiles: equal-size slots
@@ -220,6 +308,21 @@ def main():
         xs = torch.cuda.Stream(device=dev, priority=-1)  # (high priority: short kernels among persistent ones)
         rendered = [torch.cuda.Event() for _ in range(NBUF)]
         gathered_ev = [None] * NBUF
+        # The IPC gather (--gather ipc / auto). Every rank's NBUF buffers and an interprocess event per buffer are opened by
+        # rank 0 (torch's CUDA-IPC reductions: hipIpcGetMemHandle / hipIpcOpenMemHandle, hipIpcGetEventHandle); rank 0 waits
+        # for a peer's event, copies the peer's buffer into its slot with a device copy (xGMI, the copy engines), and records
+        # an interprocess event of its own per buffer that the peers wait for before they render into that buffer again.
+        # A wait on an interprocess event takes the LAST record issued, so the record has to have been issued (not run)
+        # before the wait is: each rank publishes the number of the step it has issued in a small file in /dev/shm, and a
+        # rank checks that number on the host before it enqueues a wait (host threads run ahead of the GPUs; nobody waits
+        # for a GPU there).
+        ipc = {"ok": False, "why": "not asked for (--gather rccl)"}
+        if args.gather in ("auto", "ipc"):
+            ipc = setup_ipc_gather(torch, dist, np_mod, rank, world, dev, mine, NBUF, guarded_early, timeout_s=args.init_timeout_s)
+            if args.gather == "ipc" and not ipc["ok"]:
+                sys.stderr.write(f"bench.py rank {rank}/{world}: --gather ipc cannot be set up ({ipc['why']})\n")
+                os._exit(5)
+        gather_mode = ["ipc" if args.gather == "ipc" else "rccl"]  # (auto: decided by the probe below)
 
     step_no = [0]
     cam_no = [0]
@@ -242,18 +345,26 @@ def main():
 
     phase_ev = []  # N > 1: (before render, rendered, gather begins, gathered, unpacked) per timed step, for the per-rank split
 
-    def step(new_camera=False, timed=False):
+    def step(new_camera=False, timed=False, final=False):
         step_no[0] += 1
-        if args.vary_seed:
-            opts.seed = args.seed + step_no[0]
+        if args.vary_seed:  # (tests: a stale buffer shows; the frame whose hash is reported has the configuration's seed)
+            opts.seed = args.seed if final else args.seed + step_no[0]
         c = fresh_camera() if new_camera else cam
         if world == 1:
             scene.render_device(c, opts, image.data_ptr(), None, stream)  # (emulation: packed tiles, fits)
             return
         b = step_no[0] % NBUF
+        k = step_no[0]
+        use_ipc = gather_mode[0] == "ipc"
         main = torch.cuda.current_stream()
         if gathered_ev[b] is not None:
             main.wait_event(gathered_ev[b])  # the gather of NBUF frames ago has read this buffer
+        if rank != 0 and ipc["ok"] and ipc["last_use"][b] > 0:
+            # (rank 0's copy of what this buffer held, whichever way THIS step gathers: its record has been issued once rank 0
+            # says it has consumed that step)
+            ipc["wait_flag"](world, ipc["last_use"][b])
+            main.wait_event(ipc["consumed_by_rank0"][b])
+            ipc["last_use"][b] = 0
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
         if evs:
             evs[0].record(main)
@@ -261,11 +372,22 @@ def main():
         if evs:
             evs[1].record(main)  # (ahead of the event the side stream waits for: the spans below cannot come out negative)
         rendered[b].record(main)
+        if use_ipc:
+            ipc["rendered"][b].record(main)
+            ipc["last_use"][b] = k
+            ipc["set_flag"](rank, k)
         xs.wait_event(rendered[b])
         with torch.cuda.stream(xs):
             if evs:
                 evs[2].record(xs)
-            if args.rehearse_single_gpu:  # gloo cannot gather device tensors: stage through the host
+            if use_ipc:
+                if rank == 0:
+                    gathered[b][0].copy_(mine[b], non_blocking=True)
+                    for r in range(1, world):
+                        ipc["wait_flag"](r, k)  # (host: rank r has issued its record for this step)
+                        xs.wait_event(ipc["peer_rendered"][r][b])
+                        gathered[b][r].copy_(ipc["peer_mine"][r][b], non_blocking=True)
+            elif args.rehearse_single_gpu:  # gloo cannot gather device tensors: stage through the host
                 host = mine[b].cpu()
                 hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, hg, dst=0)
@@ -279,6 +401,9 @@ def main():
             if rank == 0:
                 rbrt_amd.unpack_tiles(local_rank, slots[b].data_ptr(), W, H, world, image.data_ptr(), None, xs.cuda_stream,
                                       rank_stride_pixels=slot_pixels)
+                if use_ipc:  # (the peers' buffers of this step have been read once the copies above have run)
+                    ipc["consumed"][b].record(xs)
+                    ipc["set_flag"](world, k)
             ev = torch.cuda.Event()
             ev.record(xs)
             gathered_ev[b] = ev
@@ -340,6 +465,24 @@ def main():
         scene.set_timing(False)
         return el, enq, tr, rs, nl, mix
 
+    # ---- N > 1, --gather auto: both gathers for a few untimed steps each, the faster one is used from here on ----
+    gather_probe = None
+    if world > 1 and args.gather == "auto" and ipc["ok"]:
+        def probe():
+            times = {}
+            for mode in ("rccl", "ipc"):
+                gather_mode[0] = mode
+                for _ in range(2):
+                    step(True)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(args.gather_probe_steps):
+                    step(True)
+                fence()
+                times[mode] = max_over_ranks(time.perf_counter() - t0) / args.gather_probe_steps * 1e3
+            return times
+        gather_probe = guarded(probe)
+        gather_mode[0] = "ipc" if gather_probe["ipc"] < gather_probe["rccl"] else "rccl"
     elapsed, enqueue_s, trace_ms, resolve_ms, n_launches, (mix_full, mix_half) = guarded(lambda: timed_leg(args.warmup, args.steps, True))
     scene.check()  # a NaN sphere discriminant (sphere.rs:33 panics) or corrupt path state fails the run loudly
     # per-rank split of a step (N > 1): spans on this rank's streams, means over the timed steps
@@ -355,7 +498,7 @@ def main():
                   "max": {k: max(p[k] for p in allp) for k in ("render_ms", "gather_wait_ms", "gather_ms", "unpack_ms")},
                   "what": "spans between events on each rank's own streams, mean over the timed steps: render = the library's call on the "
                           "caller's stream (trace launches on its lanes + resolve); gather_wait = side stream waiting for it; gather = "
-                          "dist.gather; unpack = rank 0's de-interleave"}
+                          "dist.gather, or rank 0's copies out of the peers' buffers (collective.gather says which); unpack = rank 0's de-interleave"}
     # ---- the same camera over and over (a stream of frames of one view: the tile pass is paid once) ----
     same = None
     n_same = args.steps if args.same_camera_steps < 0 else args.same_camera_steps
@@ -419,7 +562,14 @@ def main():
                   "ms_same_camera": sum(ts8) / len(ts8) * 1e3, "ms_radiance": sum(ts) / len(ts) * 1e3}
 
     # the frame whose hash is reported: the configuration's own camera, rendered last (untimed)
-    guarded(lambda: (step(False), fence()))
+    guarded(lambda: (step(False, final=True), fence()))
+    if world > 1 and ipc["ok"]:  # rank 0 lets go of the peers' buffers before the peers (who end here) free them
+        import gc
+        for key in ("peer_mine", "peer_rendered", "consumed_by_rank0"):
+            ipc.pop(key, None)
+        gc.collect()
+        torch.cuda.ipc_collect()
+        guarded(lambda: dist.barrier())
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -555,7 +705,7 @@ def main():
                                f"{'' if args.mesh_scale is None else f' at scale {args.mesh_scale:g} (translation {args.mesh_translation})'}, "
                                f"{W}x{H}, {spp} spp, seed {args.seed}",
                    "baseline_config": args.config,
-                   "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (", RCCL gather" if world > 1 else ""),
+                   "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (f", {gather_mode[0]} gather to rank 0" if world > 1 else ""),
                    "pipeline": (f"{args.pipeline or 'auto: 8'} trace launches in flight, each on 3 of a CU's 16 wave slots while they overlap (together 1.5x the slots there are); "
                                 f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
                    if args.pipeline != 1 else "1 (no overlap between steps)",
@@ -581,7 +731,11 @@ def main():
         out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
                              "library": ("gloo (rehearsal on one GPU through host memory)" if args.rehearse_single_gpu else
                                          "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version())),
-                             "gather_bytes_per_rank": int(maxn * 4), "timeout_s": args.init_timeout_s}
+                             "gather_bytes_per_rank": int(maxn * 4), "timeout_s": args.init_timeout_s,
+                             "gather": {"rccl": "dist.gather (" + dist.get_backend() + ")",
+                                        "ipc": "rank 0 copies out of the peers' buffers (HIP IPC, interprocess events)"}[gather_mode[0]],
+                             "gather_asked": args.gather, "gather_probe_ms_per_step": gather_probe,
+                             "ipc_gather_available": bool(ipc["ok"]), "ipc_gather_note": ipc["why"] or None}
     if single is not None:
         out["single_frame"] = {"ms": round(single["ms"], 4), "ms_new_camera": round(single["ms"], 4), "ms_min": round(single["ms_min"], 4),
                                "ms_same_camera": round(single["ms_same_camera"], 4), "frames": single["frames"],

@@ -144,6 +144,7 @@ struct rbrt_hip_scene {
             rbrt_camera_t cam;
             uint32_t rank, world;
             uint32_t list_mode;  // the order of the work list (tile_lists_kernel): by the kind of launch, list_mode_for()
+            float min_dist;      // the tree boxes of the pass are grown by a pad that holds 1 / min_dist (TraceParams::eps_frac)
         };
         struct TileSet {
             uint32_t* d_cull = nullptr;    // [n_tiles]
@@ -986,7 +987,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             HIP_TRY(launch_primary_cull(T, stream));
             HIP_TRY(hipEventRecord(S.ev_lists, stream));
             std::memset(&S.key, 0, sizeof(S.key));
-            S.key.cam = *cam, S.key.rank = o->tile_rank, S.key.world = world, S.key.list_mode = T.tile_list_mode;
+            S.key.cam = *cam, S.key.rank = o->tile_rank, S.key.world = world, S.key.list_mode = T.tile_list_mode, S.key.min_dist = o->min_dist;
             S.key_valid = true;
             // (the lane this call's first launch takes: if that launch finds the GPU idle it wants the isolated launch's list
             // as well -- made here too, it does not have to wait for the prep stream while the launches behind it pile up)
@@ -1015,7 +1016,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         if (!stats && depth > 1 && s->primary_cull != 0 && !s->streaming_hint && !other_launch_in_flight(s, nullptr)) {
             rbrt_hip_scene::Lane::TileKey want;
             std::memset(&want, 0, sizeof(want));
-            want.cam = *cam, want.rank = o->tile_rank, want.world = world, want.list_mode = list_mode_for(s, false);
+            want.cam = *cam, want.rank = o->tile_rank, want.world = world, want.list_mode = list_mode_for(s, false), want.min_dist = o->min_dist;
             for (uint32_t li = 0; li < depth; ++li)
                 for (const auto& C : s->lanes[li].tiles)
                     if (C.key_valid && std::memcmp(&want, &C.key, sizeof(want)) == 0) lane_no = li;
@@ -1055,7 +1056,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             rbrt_hip_scene::Lane::TileKey key;
             std::memset(&key, 0, sizeof(key));
             const uint32_t list_mode = list_mode_for(s, overlapped && !stats);
-            key.cam = *cam, key.rank = o->tile_rank, key.world = world, key.list_mode = list_mode;
+            key.cam = *cam, key.rank = o->tile_rank, key.world = world, key.list_mode = list_mode, key.min_dist = o->min_dist;
             for (auto& C : L.tiles)
                 if (C.key_valid && std::memcmp(&key, &C.key, sizeof(key)) == 0) S = &C;
             if (!S) {

@@ -512,6 +512,29 @@ def test_one_scene_many_cameras_and_sizes(hip, oracle):
             assert_same_image(img.cpu().numpy(), exp, f"{w}x{h}x{spp} seed {seed}")
 
 
+def test_one_camera_rendered_with_different_distance_windows(hip, oracle):
+    """The tile pass grows the tree boxes it tests by a pad that holds 1 / min_dist (the traversal's own), so its tables
+    belong to (camera, partition, list order, min_dist): one camera rendered with another window must not be served
+    the tables of the first. Blocking frames (which look for a lane that has the camera's tables) and a stream."""
+    import torch
+    cam = scenes.camera(oracle, 160, 120)
+    sc = scenes.example_scene(oracle, 2003)
+    windows = [(0.001, 2000.0), (1e-5, 2000.0), (0.05, 50.0), (0.001, 2000.0), (1e-5, 2000.0)]
+    with hip.HipScene(sc) as hs:
+        outs = []
+        for k, (lo, hi) in enumerate(windows):
+            img = torch.full((120, 160, 3), float("nan"), dtype=torch.float32, device="cuda")
+            hs.render_device(cam, abi.default_opts(spp=3, seed=7, min_dist=lo, max_dist=hi), img.data_ptr(), None, None)
+            if k < 3:
+                torch.cuda.synchronize()
+            outs.append(img)
+        torch.cuda.synchronize()
+        hs.check()
+    for (lo, hi), img in zip(windows, outs):
+        exp, _, _ = oracle.render(cam, sc, abi.default_opts(spp=3, seed=7, min_dist=lo, max_dist=hi))
+        assert_same_image(img.cpu().numpy(), exp, f"window ({lo}, {hi})")
+
+
 def test_division_free_mesh_gate_decides_like_the_ieee_form(hip, oracle):
     """The megakernel's mesh gate forms its six slab quotients with v_rcp_f32 and falls back to the verbatim IEEE
     form (aabbox.rs:28-58) only near a decision boundary. Both forms, and the oracle, on random rays, on rays aimed at

@@ -5,8 +5,8 @@ tiles over ranks. Two hosts drive it and both are run here with mo
 
 * the C++ host `rbrt --gpus N --oversubscribe` (rank r on device r % n_devices): worker threads, per-pass barriers,
   per-rank checkpoint slots, an interrupted + resumed run, the host-side merge of the ranks' packed tiles;
-* `bench.py --gpus N --rehearse-single-gpu` under torch.distributed.run: N processes on cuda:0, the double-buffered
-  side-stream gather with gloo standing in for RCCL.
+* `bench.py --gpus N --rehearse-single-gpu` under torch.distributed.run: N processes on cuda:0, the side-stream gather
+  with gloo standing in for RCCL, and the IPC gather (rank 0 copying out of the peers' device buffers) as it is.
 
 What can NOT run on one GPU is RCCL itself (a communicator refuses two ranks on one device): `--gather rccl` with
 duplicate devices must fail with a message, not hang; its code is kept as small as it is (render.cpp).
@@ -129,13 +129,13 @@ def _bench(extra, launcher=()):
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bench_sharded_step_on_one_gpu_gives_the_single_gpu_frame(hip, world):
+@pytest.mark.parametrize("world,gather", [(2, "rccl"), (3, "ipc"), (3, "auto")])
+def test_bench_sharded_step_on_one_gpu_gives_the_single_gpu_frame(hip, world, gather):
     """bench.py's N > 1 step -- tiles of rank r, two buffer sets, gather on a side stream behind an event, strided
     unpack on rank 0 -- as `world` fresh processes on cuda:0 (gloo through host memory in place of RCCL): the last
     frame's SHA-256 equals the single-process run's. Seeds vary per step, so a stale buffer would show."""
     one = _bench(["--gpus", "1"])
-    many = _bench(["--gpus", str(world), "--rehearse-single-gpu"],
+    many = _bench(["--gpus", str(world), "--rehearse-single-gpu", "--gather", gather, "--gather-probe-steps", "3"],
                   launcher=("-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                             "--master-port", str(_free_port())))
     assert many["n_gpus"] == world and one["n_gpus"] == 1
@@ -148,6 +148,13 @@ def test_bench_sharded_step_on_one_gpu_gives_the_single_gpu_frame(hip, world):
         assert all(p[k] >= 0.0 for k in ("render_ms", "gather_wait_ms", "gather_ms", "unpack_ms")) and p["render_ms"] > 0.0
     assert ph["max"]["render_ms"] == max(p["render_ms"] for p in ph["per_rank"])
     assert co["ranks"] == world and co["backend"] == "gloo" and co["gather_bytes_per_rank"] > 0
+    # how rank 0 got the tiles: the backend's gather, or its own copies out of the peers' buffers (HIP IPC between the
+    # processes, interprocess events, step counters in /dev/shm) -- the second is the same code on one GPU as on eight
+    assert co["gather_asked"] == gather and co["ipc_gather_available"] == (gather != "rccl"), co
+    if gather == "auto":
+        assert set(co["gather_probe_ms_per_step"]) == {"rccl", "ipc"} and co["gather"].startswith(("dist.gather", "rank 0 copies"))
+    else:
+        assert co["gather"].startswith("dist.gather" if gather == "rccl" else "rank 0 copies") and co["gather_probe_ms_per_step"] is None
     for j in (one, many):  # every timed step renders a camera the library has not seen; the cached-camera leg is reported apart
         assert j["config"]["tile_pass"]["in_timed_region"] is True and j["ms_per_step_new_camera"] == j["ms_per_step"]
         assert j["ms_per_step_same_camera"] > 0.0 and j["same_camera_leg"]["steps"] == 3
