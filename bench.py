@@ -368,7 +368,10 @@ def main():
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
         if evs:
             evs[0].record(main)
-        scene.render_device(c, opts, mine[b].data_ptr(), None, stream)
+        # (IPC gather: rank 0 renders straight into its slot of the gathered buffer -- a copy inside one device is a blit
+        # KERNEL, which would wait for wave slots like every multi-wave kernel beside the persistent launches)
+        out_buf = gathered[b][0] if use_ipc and rank == 0 else mine[b]
+        scene.render_device(c, opts, out_buf.data_ptr(), None, stream)
         if evs:
             evs[1].record(main)  # (ahead of the event the side stream waits for: the spans below cannot come out negative)
         rendered[b].record(main)
@@ -382,7 +385,6 @@ def main():
                 evs[2].record(xs)
             if use_ipc:
                 if rank == 0:
-                    gathered[b][0].copy_(mine[b], non_blocking=True)
                     for r in range(1, world):
                         ipc["wait_flag"](r, k)  # (host: rank r has issued its record for this step)
                         xs.wait_event(ipc["peer_rendered"][r][b])
