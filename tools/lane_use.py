@@ -57,6 +57,9 @@ def main():
     print(f"extra shading rounds        {d['shade_extra_rounds']:>12,}")
     print(f"traversal bursts            {d['passes_trav']:>12,}   busy lanes at entry {d['slots_empty'] / max(1, d['passes_trav']):5.1f}   steps per burst {ws / max(1, d['passes_trav']):5.1f}")
     print(f"  at entry: rays parked without a lane {d['parked_at_burst_entry'] / max(1, d['passes_trav']):5.1f}   slots of the fullest shading kind {d['fullest_shading_kind_at_burst_entry'] / max(1, d['passes_trav']):5.1f}")
+    print(f"traversals {c['mesh_gate_pass']:,}: {d['traversals_ending_at_root'] / max(1, c['mesh_gate_pass']):.3f} of them end at the root (no child box hit); "
+          f"node visits per traversal {c['nodes_visited'] / max(1, c['mesh_gate_pass']):.1f}, triangle tests {c['tris_tested'] / max(1, c['mesh_gate_pass']):.1f}, "
+          f"accepted hits {c['mesh_hits'] / max(1, c['mesh_gate_pass']):.3f}")
     print(f"refills                     {d['refill_rounds']:>12,}   lanes per refill {d['slots_trav'] / max(1, d['refill_rounds']):5.1f}")
     print(f"scheduling rounds           {d['sched_rounds']:>12,}")
     print(f"sphere tails                {d['sphere_tail_runs']:>12,}   lanes per tail {d['sphere_tail_lanes'] / max(1, d['sphere_tail_runs']):5.1f}")
