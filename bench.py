@@ -71,6 +71,20 @@ INT_FULL_FRAC = 0.58  # of the binary's integer VALU instructions, those that is
 ISSUE_COST = {"valu_mean": 0.62 * 2.0 + 0.355 * 3.1 + 0.025 * 6.1, "salu": 2.0, "lds": 6.0, "vmem": 4.0}
 
 
+def pipeline_note(asked):
+    """What the library does with the frame pipeline (api.cpp depth_for / grid_for), for the JSON line."""
+    if asked == 1:
+        return "1 (no overlap between steps)"
+    try:
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        queues = 4
+    depth = asked or (8 if queues >= 8 else 4)
+    side = max(2, min(depth, queues))
+    return (f"{asked or f'auto: {depth}'} trace launches in flight, {min(depth, queues)} side by side on {-(-24 // side)} of a CU's 16 wave slots each while they "
+            f"overlap (together 1.5x the slots there are); GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
+
+
 def setup_ipc_gather(torch, dist, np, rank, world, dev, mine, nbuf, guarded, timeout_s=60.0):
     """The IPC gather's shared objects (see main(): "The IPC gather"). Collective: every rank calls it. Returns a dict with
     ok / why and, when ok, the opened buffers and events, and set_flag / wait_flag over the ranks' step counters in /dev/shm.
@@ -708,9 +722,7 @@ def main():
                                f"{W}x{H}, {spp} spp, seed {args.seed}",
                    "baseline_config": args.config,
                    "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (f", {gather_mode[0]} gather to rank 0" if world > 1 else ""),
-                   "pipeline": (f"{args.pipeline or 'auto: 8'} trace launches in flight, each on 3 of a CU's 16 wave slots while they overlap (together 1.5x the slots there are); "
-                                f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
-                   if args.pipeline != 1 else "1 (no overlap between steps)",
+                   "pipeline": pipeline_note(args.pipeline),
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                    "launch_mix_timed_region": {"full_grid": mix_full, "half_grid": mix_half},
                    # which tiles the trace kernel never sees (DESIGN.md "The tile pass"): every sample of theirs is still

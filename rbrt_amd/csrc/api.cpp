@@ -167,6 +167,7 @@ struct rbrt_hip_scene {
     uint32_t pipeline = 0;   // RBRT_PIPELINE / rbrt_hip_scene_set_pipeline; 0 = automatic (depth_for)
     uint32_t scratch_waves = 0;
     uint32_t n_cus = 256;
+    uint32_t hw_queues = 4;  // hardware queues the HIP runtime maps streams onto: $GPU_MAX_HW_QUEUES as scene_create finds it, else the runtime's 4
     bool waves_fixed = false;  // RBRT_WAVES_PER_CU given: no automatic half-size grids
     uint32_t overlap_waves_per_cu = 0;  // RBRT_OVERLAP_WAVES_PER_CU: waves per CU of a launch issued while another is running (0: automatic)
     uint32_t next_lane = 0;
@@ -296,9 +297,14 @@ constexpr size_t kMaxTimedLaunches = 4096;  // timing events are recycled per se
 // (Every lane has a sample buffer of its own: the lanes' buffers together stay within 8 GiB -- eight lanes at the default
 // workspace cap of 1 GiB --, but there are never fewer than three: a caller who raises RBRT_HIP_WORKSPACE_MB gets long
 // launches, which need no deep pipeline.)
+// A process that has NOT exported GPU_MAX_HW_QUEUES=8 runs on four hardware queues: four launches at most run side by
+// side, and the pipeline is four deep with grids to match (grid_for) -- eight lanes of 3 waves per CU each would leave a
+// quarter of the wave slots empty (measured with four queues, per frame / per eighth: 8 deep x 3 per CU 4.58 / 0.72 ms;
+// 4 deep x 6 per CU 3.57 / 0.578; 8 deep x 6 3.61 / 0.58; 8 deep x 8 3.56 / 0.596; with eight queues 8 deep x 3: 3.42 / 0.47).
 uint32_t depth_for(const rbrt_hip_scene* s, size_t sample_buffer_bytes) {
     if (s->pipeline != 0) return s->pipeline;
     const size_t fit = (size_t(8) << 30) / (sample_buffer_bytes ? sample_buffer_bytes : 1);
+    if (s->hw_queues < 8u) return fit >= 4 ? 4u : 3u;
     return fit >= 8 ? 8u : fit >= 4 ? 4u : 3u;  // (never 5 to 7: with the runtime's four hardware queues they are worse than 4)
 }
 
@@ -331,7 +337,8 @@ bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane*
 uint32_t grid_for(const rbrt_hip_scene* s, bool overlapped, uint32_t depth) {
     if (s->waves_fixed || !overlapped) return s->n_waves;
     uint32_t per_cu = s->overlap_waves_per_cu;  // (lab knob; 0: by the pipeline's depth)
-    if (per_cu == 0u) per_cu = depth >= 2u ? (24u + depth - 1u) / depth : 16u;
+    const uint32_t side_by_side = depth < s->hw_queues ? depth : s->hw_queues;  // launches that can run at the same time
+    if (per_cu == 0u) per_cu = side_by_side >= 2u ? (24u + side_by_side - 1u) / side_by_side : 16u;
     const uint32_t part = s->n_cus * per_cu;
     return part < s->n_waves ? part : s->n_waves;
 }
@@ -749,6 +756,11 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         if (waves_per_cu != 0) per_cu = int(waves_per_cu), s->waves_fixed = true;
         s->n_waves = uint32_t(cus * per_cu);
         s->n_cus = uint32_t(cus);
+        if (const char* q = std::getenv("GPU_MAX_HW_QUEUES")) {  // (read by the HIP runtime when it starts; not a knob of this library)
+            char* end = nullptr;
+            const long v = std::strtol(q, &end, 10);
+            if (end != q && *end == '\0' && v >= 1 && v <= 64) s->hw_queues = uint32_t(v);
+        }
         s->scratch_waves = s->n_waves;  // per-wave scratch is indexed by workgroup (= wave); no grid is larger than n_waves
         // all lanes up front: rbrt_hip_render_device then never allocates lanes (which synchronises the device)
         if (int rc = ensure_lanes(s, std::max(kLanesAtCreate, s->pipeline))) return bail(rc);
