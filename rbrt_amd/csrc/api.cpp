@@ -309,15 +309,16 @@ uint32_t depth_for(const rbrt_hip_scene* s, size_t sample_buffer_bytes) {
 }
 
 // Is a trace launch of this scene still running on another lane? (What decides how the next one is issued.)
-bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane* mine) {
-    bool busy = false;
+uint32_t other_launches_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane* mine) {
+    uint32_t busy = 0;
     for (const auto& L : s->lanes)
-        if (&L != mine && L.in_use && L.ev_traced && hipEventQuery(L.ev_traced) == hipErrorNotReady) busy = true;
+        if (&L != mine && L.in_use && L.ev_traced && hipEventQuery(L.ev_traced) == hipErrorNotReady) ++busy;
     // (hipErrorNotReady is an answer, not a failure: keep it out of the next launch check -- and clear the error state
     // only then, so that an unrelated sticky error still reaches whoever checks next)
     if (busy) (void)hipGetLastError();
     return busy;
 }
+bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane* mine) { return other_launches_in_flight(s, mine) != 0u; }
 
 // Waves of one trace launch. A launch that finds the GPU idle (a blocking caller, the first frame of a stream) takes all
 // resident wave slots. One issued while another is still running -- consecutive frames or sample batches queued back to
@@ -334,10 +335,15 @@ bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane*
 // Twelve lanes of 2 or 3 waves per CU on sixteen hardware queues: the same as eight of 3 (3.42-3.43 / 0.470-0.471); sixteen: worse.
 // (Rounds 2-3 had found smaller grids and deeper pipelines worse than half grids three deep: every launch's resolve then
 // waited for a draining launch, DESIGN.md section 6 "Short kernels beside a persistent one".)
-uint32_t grid_for(const rbrt_hip_scene* s, bool overlapped, uint32_t depth) {
+// `company`: launches of this scene that will share the GPU with this one as far as the call can tell -- those in flight on
+// the other lanes plus the sample batches of the same call still to be issued (a stream of frames has a full pipeline in
+// flight: the table above; a render of TWO batches has one: with the steady state's 3 slots per CU the second batch of a
+// blocking 1920x1080x512 eighth ran on 3/16 of the GPU once the first had ended, 38.6 ms for the frame against 14.7).
+uint32_t grid_for(const rbrt_hip_scene* s, bool overlapped, uint32_t depth, uint32_t company) {
     if (s->waves_fixed || !overlapped) return s->n_waves;
-    uint32_t per_cu = s->overlap_waves_per_cu;  // (lab knob; 0: by the pipeline's depth)
-    const uint32_t side_by_side = depth < s->hw_queues ? depth : s->hw_queues;  // launches that can run at the same time
+    uint32_t per_cu = s->overlap_waves_per_cu;  // (lab knob; 0: by the launches that run side by side)
+    uint32_t side_by_side = depth < s->hw_queues ? depth : s->hw_queues;  // launches that can run at the same time
+    if (company + 1u < side_by_side) side_by_side = company + 1u;
     if (per_cu == 0u) per_cu = side_by_side >= 2u ? (24u + side_by_side - 1u) / side_by_side : 16u;
     const uint32_t part = s->n_cus * per_cu;
     return part < s->n_waves ? part : s->n_waves;
@@ -1017,6 +1023,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         }
     }
     const size_t ev0 = s->events_used;
+    bool call_streams = false;  // this call was made while an earlier one's launch was still running (decided at its first batch)
+    uint32_t prev_lane = ~0u;
     for (size_t b = 0; b < n_batches; ++b) {
         const uint32_t base = s_begin + uint32_t(b * batch);
         const uint32_t nb = uint32_t(std::min<size_t>(batch, s_end - base));
@@ -1034,7 +1042,9 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
                     if (C.key_valid && std::memcmp(&want, &C.key, sizeof(want)) == 0) lane_no = li;
         } else if (!stats) {
             ++s->next_lane;
+            if (b != 0 && depth > 1 && lane_no == prev_lane) lane_no = s->next_lane++ % depth;  // (beside the batch before, not behind it)
         }
+        prev_lane = lane_no;
         rbrt_hip_scene::Lane& L = s->lanes[lane_no];
         const bool piped = depth > 1 && !stats;
         hipStream_t ts = piped ? L.stream : stream;  // the trace launch's stream
@@ -1051,9 +1061,19 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.n_items = uint64_t(npix) * nb;
         // (a caller that streams launches keeps doing so: the first launch after a pause -- the GPU is idle, but the
         // launch before it was issued into a busy one -- is still issued as one of a stream)
-        const bool busy = piped && other_launch_in_flight(s, &L);
-        const bool overlapped = busy || (piped && s->streaming_hint);
-        s->streaming_hint = busy;
+        const uint32_t in_flight = piped ? other_launches_in_flight(s, &L) : 0u;
+        const bool busy = in_flight != 0u;
+        // (the hint is about CALLS: a call's later batches always find its earlier ones in flight, which says nothing about
+        // whether the caller streams frames or waits for each. The batches of a call that found the GPU idle all take the
+        // full grid and the isolated launch's list: they queue on their lanes, each one's waves move into the slots the
+        // one before frees while it drains, and the last one ends with nothing behind it -- a blocking 1920x1080x512
+        // eighth, two batches: 14.8 ms; with the second batch on 12 of 16 slots 15.8; on the stream's 3: 38.6)
+        if (b == 0) call_streams = busy || (piped && s->streaming_hint);
+        const bool overlapped = call_streams;
+        // (launches that will share the GPU with this one: those in flight and the batches of this call still to come; a
+        // stream whose pipeline has just run dry is about to fill it again)
+        const uint32_t company = busy ? in_flight + uint32_t(n_batches - 1 - b) : depth;
+        if (b == 0) s->streaming_hint = busy;
         P.work_stripes = !overlapped ? s->work_stripes
                          : s->work_stripes_overlap != kStripesAuto ? s->work_stripes_overlap
                          : 0u;  // (contiguous shards; with half grids three deep small launches preferred stripes of 4, round 3)
@@ -1105,7 +1125,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(B.d_sample_buf, 0xFF, B.sample_buf_bytes, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
         if (S) HIP_TRY(hipStreamWaitEvent(ts, S->ev_lists, 0));  // (the set's tables: made on the prep stream, or at the first call on the caller's)
-        const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped, depth);
+        const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped, depth, company);
         (grid < s->n_waves ? s->n_half_grid : s->n_full_grid) += 1;
         HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, s->share_idle != 0u && P.n_items < s->share_below, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
