@@ -25,6 +25,7 @@ size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_sp
 int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes);
 hipError_t launch_primary_cull(const TraceParams& P, hipStream_t stream);
 hipError_t launch_sky_resolve(const TraceParams& P, const ResolveParams& R, hipStream_t stream);
+hipError_t launch_code_load(hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_unpack(const float* gathered, uint32_t width, uint32_t height, uint32_t world,
                          size_t rank_stride_pixels, float* out_radiance, uint8_t* out_rgb8, hipStream_t stream);
@@ -770,6 +771,9 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         s->scratch_waves = s->n_waves;  // per-wave scratch is indexed by workgroup (= wave); no grid is larger than n_waves
         // all lanes up front: rbrt_hip_render_device then never allocates lanes (which synchronises the device)
         if (int rc = ensure_lanes(s, std::max(kLanesAtCreate, s->pipeline))) return bail(rc);
+        // (the library's device code, loaded now instead of inside the first render)
+        if (launch_code_load(nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            return bail(fail(RBRT_ERR_HIP, "the library's device code does not load on this GPU (built for gfx950)"));
     }
     *out = s;
     return RBRT_OK;
@@ -873,7 +877,17 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     if (batch < 1) batch = 1;
     if (batch > s_end - s_begin) batch = s_end - s_begin;
     const size_t need = batch * per_sample;
-    const uint32_t depth = depth_for(s, need);
+    // The pipeline is for STREAMS of launches. A call that finds the GPU idle and is not one of a stream -- the CLI's one
+    // render, a blocking caller -- uses the lanes there are (four from scene_create) or as many as it has batches, and only
+    // the lanes it launches on get their buffers: the first frame of a scene took 12.9 ms with three lanes' buffers to make
+    // and 39.9 with eight lanes', against 5.0 with one (4.2 from the second frame on). The first call of a stream that is
+    // issued into a busy GPU makes the rest, during the stream's first frames.
+    const size_t n_batches_wanted = (size_t(s_end - s_begin) + batch - 1) / batch;
+    const bool stats_call = (o->flags & RBRT_FLAG_COLLECT_STATS) != 0;
+    const uint32_t depth_full = depth_for(s, need);
+    const bool streams_now = !stats_call && depth_full > 1 && (s->streaming_hint || other_launch_in_flight(s, nullptr));
+    const uint32_t depth = streams_now ? depth_full
+                                       : std::min<uint32_t>(depth_full, uint32_t(std::max<size_t>(s->lanes.size(), n_batches_wanted)));
     if (int rc = ensure_lanes(s, depth)) return rc;
     const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
         HIP_TRY(hipStreamSynchronize(stream));
@@ -943,11 +957,11 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             s->events.push_back(e);
         }
     }
-    // Every lane's buffers are sized here, at the first call that needs them, not when a lane first comes up in the
-    // rotation (a hipMalloc in the middle of a stream of frames).
+    // For a stream every lane's buffers are sized here, at the first call that needs them, not when a lane first comes up in
+    // the rotation (a hipMalloc in the middle of a stream of frames); otherwise a lane's are sized when a batch goes to it.
     const bool tile_pass = s->primary_cull != 0;
     const size_t lists_need = size_t(kTileListHeader) + 2u * size_t(n_local);
-    for (uint32_t li = 0; li < depth; ++li) {
+    const auto size_lane = [&](uint32_t li) -> int {
         rbrt_hip_scene::Lane& L = s->lanes[li];
         for (auto& B : L.bufs) {
             if (need <= B.sample_buf_bytes) continue;
@@ -980,7 +994,11 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             }
             L.tile_cull_words = n_tiles, L.tile_lists_words = lists_need;
         }
-    }
+        return RBRT_OK;
+    };
+    if (streams_now)
+        for (uint32_t li = 0; li < depth; ++li)
+            if (int rc = size_lane(li)) return rc;
     if (tile_pass && !s->prep_stream) {
         int prio_low = 0, prio_high = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: low >= high)
@@ -988,7 +1006,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     }
     // The tile pass of a lane that has never had one runs now, for this camera, on the caller's stream (the lanes' buffers
     // were made just above; in the middle of a stream of frames a first pass would have to find room beside resident waves).
-    if (tile_pass) {
+    if (tile_pass && streams_now) {
         TraceParams T;
         fill_trace_params(s, cam, o, T);
         T.tiles_x = tiles_x, T.tiles_y = tiles_y, T.n_tiles = n_tiles;
@@ -1045,6 +1063,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             if (b != 0 && depth > 1 && lane_no == prev_lane) lane_no = s->next_lane++ % depth;  // (beside the batch before, not behind it)
         }
         prev_lane = lane_no;
+        if (int rc = size_lane(lane_no)) return rc;  // (nothing to do for a lane of a stream)
         rbrt_hip_scene::Lane& L = s->lanes[lane_no];
         const bool piped = depth > 1 && !stats;
         hipStream_t ts = piped ? L.stream : stream;  // the trace launch's stream

@@ -1337,6 +1337,14 @@ hipError_t launch_primary_cull(const TraceParams& P, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// One empty launch: the HIP runtime loads a library's device code at the first launch of one of its kernels (7-8 ms for this
+// one). rbrt_hip_scene_create does it, so that the first render of a process is a render.
+__global__ void code_load_kernel() {}
+hipError_t launch_code_load(hipStream_t stream) {
+    hipLaunchKernelGGL(code_load_kernel, dim3(1), dim3(64), 0, stream);
+    return hipGetLastError();
+}
+
 hipError_t launch_sky_resolve(const TraceParams& P, const ResolveParams& R, hipStream_t stream) {
     const size_t npix = size_t(R.n_local_tiles) * 64u;  // (an upper bound: the list's length is known on the device)
     if (npix == 0 || !R.tile_lists) return hipSuccess;
