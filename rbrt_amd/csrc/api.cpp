@@ -1088,10 +1088,12 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         // one before frees while it drains, and the last one ends with nothing behind it -- a blocking 1920x1080x512
         // eighth, two batches: 14.8 ms; with the second batch on 12 of 16 slots 15.8; on the stream's 3: 38.6)
         if (b == 0) call_streams = busy || (piped && s->streaming_hint);
-        const bool overlapped = call_streams;
-        // (launches that will share the GPU with this one: those in flight and the batches of this call still to come; a
-        // stream whose pipeline has just run dry is about to fill it again)
-        const uint32_t company = busy ? in_flight + uint32_t(n_batches - 1 - b) : depth;
+        const uint32_t to_come = uint32_t(n_batches - 1 - b);
+        const bool overlapped = call_streams || (piped && to_come != 0u);
+        // (launches that will share the GPU with this one: for a stream those in flight and the batches of this call still
+        // to come -- a stream whose pipeline has just run dry is about to fill it again --, for a blocking call's batch the
+        // batches behind it: the last one ends alone and takes the full grid, the one before it shares with one, ...)
+        const uint32_t company = !call_streams ? to_come : busy ? in_flight + to_come : depth;
         if (b == 0) s->streaming_hint = busy;
         P.work_stripes = !overlapped ? s->work_stripes
                          : s->work_stripes_overlap != kStripesAuto ? s->work_stripes_overlap
