@@ -1083,10 +1083,10 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         const uint32_t in_flight = piped ? other_launches_in_flight(s, &L) : 0u;
         const bool busy = in_flight != 0u;
         // (the hint is about CALLS: a call's later batches always find its earlier ones in flight, which says nothing about
-        // whether the caller streams frames or waits for each. The batches of a call that found the GPU idle all take the
-        // full grid and the isolated launch's list: they queue on their lanes, each one's waves move into the slots the
-        // one before frees while it drains, and the last one ends with nothing behind it -- a blocking 1920x1080x512
-        // eighth, two batches: 14.8 ms; with the second batch on 12 of 16 slots 15.8; on the stream's 3: 38.6)
+        // whether the caller streams frames or waits for each. The batches of a call that found the GPU idle are sized by
+        // the batches behind them, the last one takes the full grid and the isolated launch's list: it ends with nothing
+        // behind it -- a blocking 1920x1080x512 eighth, two batches: 14.7 ms; both on the full grid 14.8; the FIRST on the
+        // full grid and the second on 12 of 16 slots 15.8; the second on the stream's 3: 38.6)
         if (b == 0) call_streams = busy || (piped && s->streaming_hint);
         const uint32_t to_come = uint32_t(n_batches - 1 - b);
         const bool overlapped = call_streams || (piped && to_come != 0u);
