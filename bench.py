@@ -81,8 +81,9 @@ def pipeline_note(asked):
         queues = 4
     depth = asked or (8 if queues >= 8 else 4)
     side = max(2, min(depth, queues))
-    return (f"{asked or f'auto: {depth}'} trace launches in flight, {min(depth, queues)} side by side on {-(-24 // side)} of a CU's 16 wave slots each while they "
-            f"overlap (together 1.5x the slots there are); GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
+    per_cu = -(-24 // side)
+    return (f"{asked or f'auto: {depth}'} trace launches in flight, {min(depth, queues)} side by side on {per_cu}{' (4 for launches of 8 M work items or more)' if per_cu < 4 else ''} "
+            f"of a CU's 16 wave slots each while they overlap; GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
 
 
 def setup_ipc_gather(torch, dist, np, rank, world, dev, mine, nbuf, guarded, timeout_s=60.0):
@@ -481,6 +482,13 @@ def main():
         scene.set_timing(False)
         return el, enq, tr, rs, nl, mix
 
+    # ---- set-up (untimed): the library makes the frame pipeline's lanes and their buffers when it first sees a STREAM of
+    # calls (one issued while another is running): three calls back to back here, whatever --warmup is ----
+    def prime_pipeline():
+        for _ in range(3):
+            step(True)
+        fence()
+    guarded(prime_pipeline)
     # ---- N > 1, --gather auto: both gathers for a few untimed steps each, the faster one is used from here on ----
     gather_probe = None
     if world > 1 and args.gather == "auto" and ipc["ok"]:

@@ -336,16 +336,28 @@ bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane*
 // Twelve lanes of 2 or 3 waves per CU on sixteen hardware queues: the same as eight of 3 (3.42-3.43 / 0.470-0.471); sixteen: worse.
 // (Rounds 2-3 had found smaller grids and deeper pipelines worse than half grids three deep: every launch's resolve then
 // waited for a draining launch, DESIGN.md section 6 "Short kernels beside a persistent one".)
-// `company`: launches of this scene that will share the GPU with this one as far as the call can tell -- those in flight on
-// the other lanes plus the sample batches of the same call still to be issued (a stream of frames has a full pipeline in
-// flight: the table above; a render of TWO batches has one: with the steady state's 3 slots per CU the second batch of a
-// blocking 1920x1080x512 eighth ran on 3/16 of the GPU once the first had ended, 38.6 ms for the frame against 14.7).
-uint32_t grid_for(const rbrt_hip_scene* s, bool overlapped, uint32_t depth, uint32_t company) {
+// A STREAM has a beginning and an end: its first launches start together and drain together, its last ones are left with
+// their small share of an emptying GPU. With 20 frames between two fences instead of 100 (bench.py --steps; tools/k20_sweep.sh),
+// ms per frame / half / quarter / eighth:   3 per CU  3.65  1.906  0.996  0.548   (100 frames: 3.431  1.745  0.894  0.470)
+//                                            4         3.58  1.857  0.971  0.552               3.437  1.759  0.906  0.486
+//                                            6         3.58  1.846  0.990  0.558               3.443  1.776  0.929  0.507
+//                                            8         3.54  1.859  0.992  0.588               3.474  1.813  0.949  0.524
+// so a launch of 8 M work items or more takes 4 of a CU's slots, a smaller one 3. (Sizing a stream's launches by the number
+// in flight when each is issued -- its first ones large, 12, 8, 6 ... -- makes the beginning worse: 3.74 for 20 frames; the
+// full grid for a stream's first launch into an idle GPU: 3.49 against 3.59 in one session, 3.66 against 3.55 in the next --
+// twenty frames between two fences come out 2-3 % apart from one box and session to the next.)
+// `company` (a call that found the GPU idle: `stream` false): the sample batches of the call still to be issued behind this
+// one -- the last batch ends alone, the one before it shares with one, ...: with the stream's 3 slots per CU the second batch
+// of a blocking 1920x1080x512 eighth ran on 3/16 of the GPU once the first had ended, 38.6 ms for the frame against 14.7.
+uint32_t grid_for(const rbrt_hip_scene* s, bool overlapped, uint32_t depth, bool stream, uint32_t company, uint64_t n_items) {
     if (s->waves_fixed || !overlapped) return s->n_waves;
     uint32_t per_cu = s->overlap_waves_per_cu;  // (lab knob; 0: by the launches that run side by side)
     uint32_t side_by_side = depth < s->hw_queues ? depth : s->hw_queues;  // launches that can run at the same time
-    if (company + 1u < side_by_side) side_by_side = company + 1u;
-    if (per_cu == 0u) per_cu = side_by_side >= 2u ? (24u + side_by_side - 1u) / side_by_side : 16u;
+    if (!stream && company + 1u < side_by_side) side_by_side = company + 1u;
+    if (per_cu == 0u) {
+        per_cu = side_by_side >= 2u ? (24u + side_by_side - 1u) / side_by_side : 16u;
+        if (stream && per_cu < 4u && n_items >= (8ull << 20)) per_cu = 4u;
+    }
     const uint32_t part = s->n_cus * per_cu;
     return part < s->n_waves ? part : s->n_waves;
 }
@@ -878,16 +890,16 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     if (batch > s_end - s_begin) batch = s_end - s_begin;
     const size_t need = batch * per_sample;
     // The pipeline is for STREAMS of launches. A call that finds the GPU idle and is not one of a stream -- the CLI's one
-    // render, a blocking caller -- uses the lanes there are (four from scene_create) or as many as it has batches, and only
-    // the lanes it launches on get their buffers: the first frame of a scene took 12.9 ms with three lanes' buffers to make
+    // render, a blocking caller -- uses the lanes there are (four from scene_create: four more cost 20 ms to make, more than
+    // thirteen batches of a 1920x1080x512 render gain from them), and only the lanes it launches on get their buffers: the first frame of a scene took 12.9 ms with three lanes' buffers to make
     // and 39.9 with eight lanes', against 5.0 with one (4.2 from the second frame on). The first call of a stream that is
     // issued into a busy GPU makes the rest, during the stream's first frames.
     const size_t n_batches_wanted = (size_t(s_end - s_begin) + batch - 1) / batch;
     const bool stats_call = (o->flags & RBRT_FLAG_COLLECT_STATS) != 0;
     const uint32_t depth_full = depth_for(s, need);
     const bool streams_now = !stats_call && depth_full > 1 && (s->streaming_hint || other_launch_in_flight(s, nullptr));
-    const uint32_t depth = streams_now ? depth_full
-                                       : std::min<uint32_t>(depth_full, uint32_t(std::max<size_t>(s->lanes.size(), n_batches_wanted)));
+    const uint32_t depth = streams_now ? depth_full : std::min<uint32_t>(depth_full, uint32_t(std::max<size_t>(s->lanes.size(), 1)));
+    (void)n_batches_wanted;
     if (int rc = ensure_lanes(s, depth)) return rc;
     const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1090,10 +1102,10 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         if (b == 0) call_streams = busy || (piped && s->streaming_hint);
         const uint32_t to_come = uint32_t(n_batches - 1 - b);
         const bool overlapped = call_streams || (piped && to_come != 0u);
-        // (launches that will share the GPU with this one: for a stream those in flight and the batches of this call still
-        // to come -- a stream whose pipeline has just run dry is about to fill it again --, for a blocking call's batch the
-        // batches behind it: the last one ends alone and takes the full grid, the one before it shares with one, ...)
-        const uint32_t company = !call_streams ? to_come : busy ? in_flight + to_come : depth;
+        // (a blocking call's batch shares the GPU with the batches behind it: the last one ends alone and takes the full
+        // grid, the one before it shares with one, ...; a stream's launch takes the steady state's share: grid_for)
+        const uint32_t company = to_come;
+        (void)in_flight;
         if (b == 0) s->streaming_hint = busy;
         P.work_stripes = !overlapped ? s->work_stripes
                          : s->work_stripes_overlap != kStripesAuto ? s->work_stripes_overlap
@@ -1146,7 +1158,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         if (s->poison_samples) HIP_TRY(hipMemsetAsync(B.d_sample_buf, 0xFF, B.sample_buf_bytes, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b], ts));  // after the memset nodes
         if (S) HIP_TRY(hipStreamWaitEvent(ts, S->ev_lists, 0));  // (the set's tables: made on the prep stream, or at the first call on the caller's)
-        const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped, depth, company);
+        const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped, depth, call_streams, company, P.n_items);
         (grid < s->n_waves ? s->n_half_grid : s->n_full_grid) += 1;
         HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, s->share_idle != 0u && P.n_items < s->share_below, ts));
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
