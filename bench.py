@@ -86,6 +86,46 @@ def pipeline_note(asked):
             f"of a CU's 16 wave slots each while they overlap; GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
 
 
+def open_step_counters(dist, np, rank, world, guarded, timeout_s, failed=False):
+    """world + 1 step counters shared by the ranks of one node through a file in /dev/shm (rank 0 makes it, the others open
+    it, rank 0 unlinks it once everybody has it open). Collective. Returns (set_flag(i, v), wait_flag(i, v), error text):
+    counter i is written by one rank only (rank i its own, rank 0 also counter `world`); wait_flag spins on the host until
+    counter i has reached v and raises after timeout_s."""
+    err, flags = "", None
+    name = [f"/dev/shm/rbrt_bench_flags_{os.getpid()}_{os.environ.get('MASTER_PORT', '0')}"]
+    try:
+        if rank == 0 and not failed:
+            flags = np.memmap(name[0], dtype=np.int64, mode="w+", shape=(world + 1,))
+            flags[:] = 0
+            flags.flush()
+    except Exception as e:
+        err = f"flags: {type(e).__name__}: {e}"
+    guarded(lambda: dist.broadcast_object_list(name, src=0))
+    try:
+        if rank != 0 and not failed:
+            flags = np.memmap(name[0], dtype=np.int64, mode="r+", shape=(world + 1,))
+    except Exception as e:
+        err = f"flags: {type(e).__name__}: {e}"
+    guarded(lambda: dist.barrier())  # (every rank has the file open before rank 0 unlinks it)
+    if rank == 0:
+        try:
+            os.unlink(name[0])
+        except OSError:
+            pass
+
+    def set_flag(i, v):
+        flags[i] = v
+
+    def wait_flag(i, v):
+        t0 = time.perf_counter()
+        while int(flags[i]) < v:
+            if time.perf_counter() - t0 > timeout_s:
+                raise RuntimeError(f"IPC gather: rank {rank} waited {timeout_s:.0f} s for step {v} of counter {i} (at {int(flags[i])})")
+            time.sleep(0)
+
+    return set_flag, wait_flag, err
+
+
 def setup_ipc_gather(torch, dist, np, rank, world, dev, mine, nbuf, guarded, timeout_s=60.0):
     """The IPC gather's shared objects (see main(): "The IPC gather"). Collective: every rank calls it. Returns a dict with
     ok / why and, when ok, the opened buffers and events, and set_flag / wait_flag over the ranks' step counters in /dev/shm.
@@ -105,7 +145,6 @@ def setup_ipc_gather(torch, dist, np, rank, world, dev, mine, nbuf, guarded, tim
         err = f"export: {type(e).__name__}: {e}"
     got = [None] * world
     guarded(lambda: dist.all_gather_object(got, (payload, err)))
-    flags = None
     if not err and all(g[0] is not None for g in got):
         try:
             if rank == 0:
@@ -116,43 +155,16 @@ def setup_ipc_gather(torch, dist, np, rank, world, dev, mine, nbuf, guarded, tim
                 st["consumed_by_rank0"] = [torch.cuda.Event.from_ipc_handle(dev, h) for h in got[0][0]["consumed"]]
         except Exception as e:
             err = f"open: {type(e).__name__}: {e}"
-    name = [f"/dev/shm/rbrt_bench_flags_{os.getpid()}_{os.environ.get('MASTER_PORT', '0')}"]
-    try:
-        if rank == 0 and not err:
-            flags = np.memmap(name[0], dtype=np.int64, mode="w+", shape=(world + 1,))
-            flags[:] = 0
-            flags.flush()
-    except Exception as e:
-        err = f"flags: {type(e).__name__}: {e}"
-    guarded(lambda: dist.broadcast_object_list(name, src=0))
-    try:
-        if rank != 0 and not err:
-            flags = np.memmap(name[0], dtype=np.int64, mode="r+", shape=(world + 1,))
-    except Exception as e:
-        err = f"flags: {type(e).__name__}: {e}"
+    set_flag, wait_flag, flags_err = open_step_counters(dist, np, rank, world, guarded, timeout_s, failed=bool(err))
+    err = err or flags_err
     errs = [None] * world
-    guarded(lambda: dist.all_gather_object(errs, err))  # (also: every rank has the file open before rank 0 unlinks it)
-    if rank == 0:
-        try:
-            os.unlink(name[0])
-        except OSError:
-            pass
+    guarded(lambda: dist.all_gather_object(errs, err))
     bad = [f"rank {r}: {e or g[1]}" for r, (e, g) in enumerate(zip(errs, got)) if e or g[1] or g[0] is None]
     if bad:
         st["why"] = "; ".join(bad)
         return st
 
-    def set_flag(i, v):
-        flags[i] = v
-
-    def wait_flag(i, v):
-        t0 = time.perf_counter()
-        while int(flags[i]) < v:
-            if time.perf_counter() - t0 > timeout_s:
-                raise RuntimeError(f"IPC gather: rank {rank} waited {timeout_s:.0f} s for step {v} of counter {i} (at {int(flags[i])})")
-            time.sleep(0)
-
-    st.update(ok=True, why="", set_flag=set_flag, wait_flag=wait_flag, flags=flags)
+    st.update(ok=True, why="", set_flag=set_flag, wait_flag=wait_flag)
     return st
 
 

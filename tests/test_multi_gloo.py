@@ -59,6 +59,71 @@ def test_gather_and_unpack_over_gloo(world, w, h):
     assert all(ok for _, ok in res), res
 
 
+def _counter_worker(rank, world, port, q):
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    set_flag, wait_flag, err = bench.open_step_counters(dist, np, rank, world, lambda fn: fn(), timeout_s=20.0)
+    ok = err == ""
+    lag = 3  # (bench.py's NBUF - 1: a peer may run this many steps ahead of rank 0's consumption)
+    for k in range(1, 201):
+        if rank != 0 and k > lag:
+            wait_flag(world, k - lag)  # rank 0 has consumed the step whose buffer this one reuses
+        set_flag(rank, k)              # "my record for step k has been issued"
+        if rank == 0:
+            for r in range(1, world):
+                wait_flag(r, k)
+            set_flag(world, k)
+    dist.barrier()
+    try:  # a counter nobody advances: the wait ends with an error, not a hang
+        import time
+        t0 = time.perf_counter()
+        short = bench.open_step_counters(dist, np, rank, world, lambda fn: fn(), timeout_s=0.3)[1]
+        try:
+            short(world, 10 ** 9)
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "waited" in str(e) and time.perf_counter() - t0 < 10.0
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_step_counters_of_the_ipc_gather(world):
+    """bench.py --gather ipc orders its waits on interprocess events through step counters in /dev/shm
+    (bench.open_step_counters): rank 0 waits on the host until every peer has issued step k, a peer until rank 0 has
+    consumed the step whose buffer it is about to reuse; a counter that never advances raises instead of hanging."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_counter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
+def test_pipeline_note_follows_the_hardware_queues(monkeypatch):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert bench.pipeline_note(0).startswith("auto: 8 trace launches in flight, 8 side by side on 3 (4 for launches of 8 M")
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    assert bench.pipeline_note(0).startswith("auto: 4 trace launches in flight, 4 side by side on 6 of a CU")
+    assert bench.pipeline_note(1) == "1 (no overlap between steps)"
+
+
 def test_pack_unpack_roundtrip_and_partition():
     rng = np.random.default_rng(1)
     for (w, h) in ((1, 1), (9, 17), (100, 60), (64, 64)):
