@@ -263,9 +263,13 @@ int rbrt_hip_scene_check(rbrt_hip_scene_t* scene);
 /* Counters of the last render on this scene that had RBRT_FLAG_COLLECT_STATS set. */
 int rbrt_hip_scene_stats(rbrt_hip_scene_t* scene, rbrt_hip_stats_t* out);
 
-/* Frame pipeline depth of a scene handle: 1..8, or 0 = automatic (the default, or $RBRT_PIPELINE): 3. A launch
- * issued while another launch of the scene is still running takes half of the GPU's wave slots, one that finds the
- * GPU idle takes them all (api.cpp grid_for).
+/* Frame pipeline depth of a scene handle: 1..8, or 0 = automatic (the default, or $RBRT_PIPELINE): 8 in a process that
+ * has exported GPU_MAX_HW_QUEUES=8 before the HIP runtime started, else 4 (the runtime's four hardware queues run four
+ * launches side by side). A launch issued into a stream of launches -- while another launch of the scene is still
+ * running -- takes a part of the GPU's wave slots (3 or 4 of a CU's 16 at depth 8, 6 at depth 4), one that finds the
+ * GPU idle takes them all, and the sample batches of one blocking call are sized by the batches behind them (api.cpp
+ * grid_for). Lanes beyond the four made by rbrt_hip_scene_create, and every lane's sample buffer, are made when a
+ * stream of calls is first seen; a blocking caller uses the lanes there are.
  * With depth d > 1 consecutive
  * trace launches -- the sample batches of one render and successive rbrt_hip_render_device calls -- alternate
  * over d internal streams and d sets of work buffers, so that a launch's last, poorly filled waves overlap

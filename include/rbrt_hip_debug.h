@@ -23,7 +23,8 @@
  *                                light/2|heavy|light/2, light|heavy, or (4) row-major order with its last light tiles moved to the end
  *   RBRT_TILE_ISOLATED_MODE=0..4 the list mode of a launch that has the GPU to itself (4); a launch of a stream uses 0
  *   RBRT_TILE_TAIL_DIV=1..1024   mode 4: the share of the work list (1/n, 8) that is handed out last, from light tiles
- *   RBRT_OVERLAP_WAVES_PER_CU=0..16  waves per CU of a launch of a stream (0: 24 / pipeline depth, rounded up: 3 at depth 8)
+ *   RBRT_OVERLAP_WAVES_PER_CU=0..16  waves per CU of a launch of a stream (0: 24 / launches side by side, rounded up, and
+ *                                4 instead of 3 for a launch of 8 M work items or more)
  *   RBRT_TRACE_LAUNCHES=1        one stderr line per trace launch and per tile pass (which lane, grid, table set)
  */
 #ifndef RBRT_HIP_DEBUG_H
@@ -113,8 +114,8 @@ int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* scene, int enable);
 int rbrt_hip_scene_kernel_ms(rbrt_hip_scene_t* scene, float* trace_ms_total, float* resolve_ms_total,
                              uint32_t* n_trace_launches);
 
-/* Trace launches since set_timing(scene, 1), by grid: a launch issued while another launch of the scene is still
- * running takes half of the wave slots (rbrt_hip_scene_set_pipeline), so the mix depends on host timing. */
+/* Trace launches since set_timing(scene, 1), by grid: the full grid, or the part of the wave slots a launch of a stream
+ * takes (rbrt_hip_scene_set_pipeline; "half" is round 2's name for it), so the mix depends on host timing. */
 int rbrt_hip_scene_launch_mix(rbrt_hip_scene_t* scene, uint32_t* n_full_grid, uint32_t* n_half_grid);
 
 #ifdef __cplusplus

@@ -280,9 +280,8 @@ constexpr uint32_t kMaxPipeline = 8;
 constexpr uint32_t kLanesAtCreate = 4;  // lanes made by scene_create (deeper pipelines: rbrt_hip_scene_set_pipeline makes the rest)
 constexpr size_t kMaxTimedLaunches = 4096;  // timing events are recycled per set_timing, never more than this many launches
 
-// Depth of the frame pipeline: what was set, or 3.
-// Depth of the frame pipeline: what was set, or 8. Two half-grid launches are resident at any time; the lanes beyond them
-// hold launches that are READY the moment a resident one drains. For a short launch the time between its end and the
+// Depth of the frame pipeline: what was set, or 8 (4 on the runtime's default four hardware queues). Four or five part-grid
+// launches are resident at any time (grid_for); the lanes beyond them hold launches that are READY the moment a resident one drains. For a short launch the time between its end and the
 // moment its lane's next launch can start (resolve, background kernel, two cross-stream hops: ~0.1 ms) is a fifth of a
 // step, and the extra lanes hide it. Measured with a new camera every frame (round 4, tools/ab_knobs.sh, per step):
 //   depth              3       4       5       6       8
