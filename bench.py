@@ -132,7 +132,10 @@ def setup_ipc_gather(torch, dist, np, rank, world, dev, mine, nbuf, guarded, tim
     Any failure on any rank makes every rank return ok = False (the caller then gathers with dist.gather)."""
     st = {"ok": False, "why": "", "last_use": [0] * nbuf}
     payload, err = None, ""
+    inject = os.environ.get("RBRT_BENCH_IPC_FAIL", "")  # (tests: "export:1" / "open:0" = that stage fails on that rank)
     try:
+        if inject == f"export:{rank}":
+            raise RuntimeError("injected failure")
         from torch.multiprocessing.reductions import reduce_tensor
         rendered = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(nbuf)]
         consumed = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(nbuf)] if rank == 0 else []
@@ -147,6 +150,8 @@ def setup_ipc_gather(torch, dist, np, rank, world, dev, mine, nbuf, guarded, tim
     guarded(lambda: dist.all_gather_object(got, (payload, err)))
     if not err and all(g[0] is not None for g in got):
         try:
+            if inject == f"open:{rank}":
+                raise RuntimeError("injected failure")
             if rank == 0:
                 st["peer_mine"] = [None] + [[fn(*a) for fn, a in got[r][0]["mine"]] for r in range(1, world)]
                 st["peer_rendered"] = [None] + [[torch.cuda.Event.from_ipc_handle(dev, h) for h in got[r][0]["rendered"]]

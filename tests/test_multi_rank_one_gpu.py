@@ -121,10 +121,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(extra, launcher=()):
+def _bench(extra, launcher=(), env=None, expect_failure=False):
     cmd = [sys.executable, *launcher, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--width", "256", "--height", "192", "--spp", "6",
            "--triangles", "3003", "--cpu-col-stride", "0", "--isolated-steps", "0", "--single-frames", "0", "--vary-seed", "1", *extra]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT), env=dict(os.environ, **(env or {})))
+    if expect_failure:
+        assert r.returncode != 0, r.stdout[-1500:]
+        return r
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
@@ -159,3 +162,23 @@ def test_bench_sharded_step_on_one_gpu_gives_the_single_gpu_frame(hip, world, ga
         assert j["config"]["tile_pass"]["in_timed_region"] is True and j["ms_per_step_new_camera"] == j["ms_per_step"]
         assert j["ms_per_step_same_camera"] > 0.0 and j["same_camera_leg"]["steps"] == 3
     assert "phases" not in one
+
+
+@pytest.mark.parametrize("stage", ["export:1", "open:0"])
+def test_bench_ipc_gather_that_cannot_be_set_up_leaves_the_backends_gather(hip, stage):
+    """The IPC gather's set-up ends with an agreement step: a failure on ANY rank, while exporting its buffers or while
+    opening the peers', makes EVERY rank gather with dist.gather (what a node does whose driver refuses to map another
+    device's memory) -- the frame is the single-GPU frame and the line says why. Asked for by name (--gather ipc) the
+    same failure ends all ranks with a message and a non-zero exit code instead."""
+    world = 3
+    launcher = ("-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port")
+    one = _bench(["--gpus", "1"])
+    many = _bench(["--gpus", str(world), "--rehearse-single-gpu", "--gather", "auto"], launcher=(*launcher, str(_free_port())),
+                  env={"RBRT_BENCH_IPC_FAIL": stage})
+    co = many["collective"]
+    assert many["config"]["image_sha256_16"] == one["config"]["image_sha256_16"]
+    assert co["ipc_gather_available"] is False and co["gather"].startswith("dist.gather") and co["gather_probe_ms_per_step"] is None
+    assert f"rank {stage.split(':')[1]}" in co["ipc_gather_note"] and "injected failure" in co["ipc_gather_note"]
+    r = _bench(["--gpus", str(world), "--rehearse-single-gpu", "--gather", "ipc"], launcher=(*launcher, str(_free_port())),
+               env={"RBRT_BENCH_IPC_FAIL": stage}, expect_failure=True)
+    assert "--gather ipc cannot be set up" in r.stderr and "injected failure" in r.stderr
