@@ -2,7 +2,8 @@
 """bench.py — Mray-samples/s of the HIP path-tracing hot path on BASELINE config 2.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... --
+     or by itself: with WORLD_SIZE unset, bench.py starts its N ranks under torch.distributed.run as a child process)
 
 A step = one full render of the workload: scenes/example_scene.yaml (the reference's example scene)
 with the 69,451-triangle STAND-IN for bunny.obj (the real asset is not available offline),
@@ -231,6 +232,24 @@ def parse_args():
     return ap.parse_args()
 
 
+def launch_ranks(n):
+    """One rank per GPU under torch.distributed.run, as a child process of a parent that stays off the GPU. Returns the
+    child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:  # a free port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    sys.stderr.write(f"bench.py: --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ... as a child process\n")
+    sys.stderr.flush()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL and the IPC gather need it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
     if args.config == "2r":
@@ -244,8 +263,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` by itself: this process has not touched the GPU (torch is not even imported) and never
+            # will; it starts the N ranks as a CHILD under torch.distributed.run (the fan-out of lib.rs:84-86), passes their
+            # output through and exits with their code. No exec of any kind.
+            sys.exit(launch_ranks(args.gpus))
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch

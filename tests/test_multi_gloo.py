@@ -132,3 +132,25 @@ def test_pack_unpack_roundtrip_and_partition():
             parts = [tiles.pack(img, r, world) for r in range(world)]
             assert np.array_equal(tiles.unpack(parts, w, h), img)
             assert sum(len(p) for p in parts) == tiles.n_tiles(w, h) * 64
+
+
+def test_bench_gpus_n_by_itself_starts_ranks_as_a_child_and_passes_their_exit_code_on():
+    """`python bench.py --gpus 2` without a launcher: the parent starts two ranks under torch.distributed.run as a child
+    process (it never touches the GPU itself) and exits with their code. Without a GPU the ranks end with bench.py's own
+    message -- which shows they were started, with WORLD_SIZE=2, and that the failure reaches the caller."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU form of this test is tests/test_multi_rank_one_gpu.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-single-gpu", "--steps", "1",
+                        "--warmup", "0", "--cpu-col-stride", "0"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode != 0
+    assert "as a child process" in r.stderr and r.stderr.count("bench.py needs a GPU") >= 1, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # a WORLD_SIZE that contradicts --gpus is still refused, not relaunched
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=60,
+                       cwd=root, env=dict(env, WORLD_SIZE="1"))
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr

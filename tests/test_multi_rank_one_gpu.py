@@ -182,3 +182,18 @@ def test_bench_ipc_gather_that_cannot_be_set_up_leaves_the_backends_gather(hip, 
     r = _bench(["--gpus", str(world), "--rehearse-single-gpu", "--gather", "ipc"], launcher=(*launcher, str(_free_port())),
                env={"RBRT_BENCH_IPC_FAIL": stage}, expect_failure=True)
     assert "--gather ipc cannot be set up" in r.stderr and "injected failure" in r.stderr
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks(hip):
+    """`python bench.py --gpus 2 ...` with no torch.distributed.run in front of it -- the form a driver may use for the
+    scaling run -- starts the ranks itself as a child process and prints exactly ONE JSON line, from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-single-gpu", "--steps", "2", "--warmup", "1",
+           "--cpu-col-stride", "0", "--width", "256", "--height", "192", "--spp", "6", "--triangles", "3003"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT), env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["collective"]["ranks"] == 2 and j["steps"] == 2 and j["warmup"] == 1
+    assert "as a child process" in r.stderr
