@@ -211,6 +211,9 @@ def parse_args():
     ap.add_argument("--isolated-steps", type=int, default=8,
                     help="steps of the second, unpipelined leg that times isolated trace launches for the roofline (N = 1 only; 0 = skip)")
     ap.add_argument("--single-frames", type=int, default=5, help="blocking frames incl. D2H timed for single_frame (N = 1 only; 0 = skip)")
+    ap.add_argument("--one-shot", type=int, default=5,
+                    help="calls of the one-shot rbrt_hip_render (host arrays in, host RGB8 out: create + BVH build + render + copy + "
+                         "destroy, what the reference's one render_scene call costs end to end) timed for one_shot (N = 1 only; 0 = skip)")
     ap.add_argument("--same-camera-steps", type=int, default=-1,
                     help="steps of the leg that renders ONE camera over and over (the tile pass cached); -1 = as many as --steps, 0 = skip")
     ap.add_argument("--cpu-budget-s", type=float, default=120.0,
@@ -328,6 +331,12 @@ def main():
     t0 = time.perf_counter()
     scene = rbrt_amd.HipScene(host_scene, device=local_rank)
     setup_s = time.perf_counter() - t0
+    # The handle starts with the tree that costs scene_create least (the device builder's) and adopts the host builder's
+    # tree when a background thread has made it (api.cpp struct Refine): the counting pass and every timed leg below run on
+    # the tree a handle that goes on rendering ends up with, so it is waited for here. The one_shot leg pays for its own.
+    create_times = scene.create_times()
+    refine_state, refine_s = scene.refine_wait(300.0)
+    setup_total_s = time.perf_counter() - t0
     emu = args.emulate_rank_of if world == 1 and args.emulate_rank_of > 1 else 0
     opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=emu if emu else world)
     if os.environ.get("RBRT_BENCH_MAX_DEPTH"):  # diagnosis only (changes the image)
@@ -624,6 +633,36 @@ def main():
         single = {"frames": args.single_frames, "ms": sum(tsn) / len(tsn) * 1e3, "ms_min": min(tsn) * 1e3,
                   "ms_same_camera": sum(ts8) / len(ts8) * 1e3, "ms_radiance": sum(ts) / len(ts) * 1e3}
 
+    # ---- fourth leg (N = 1): the ONE call the reference makes (src/main.rs:82), end to end: rbrt_hip_render from the host's
+    # scene arrays to the host's RGB8 image -- scene upload, BVH build, lanes, tile pass, render, quantisation, copy,
+    # release -- of a camera the library has not seen. Nothing of it is in `value`.
+    one_shot = None
+    if world == 1 and not emu and args.one_shot > 0:
+        torch.cuda.synchronize()
+        rad1, _ = rbrt_amd.render_scene(cam, spp, host_scene, seed=args.seed)  # (untimed: the configuration's camera, for the hash)
+        first = rbrt_amd.last_render_times()
+        recs = []
+        for _ in range(args.one_shot):
+            c = fresh_camera()
+            t0 = time.perf_counter()
+            rbrt_amd.render_scene(c, spp, host_scene, seed=args.seed, want_radiance=False)
+            recs.append((time.perf_counter() - t0, rbrt_amd.last_render_times()))
+        mean = lambda k: sum(r[1][k] for r in recs) / len(recs) * 1e3  # noqa: E731
+        import hashlib as _h
+        one_shot = {"calls": len(recs), "ms": round(sum(r[0] for r in recs) / len(recs) * 1e3, 3), "ms_min": round(min(r[0] for r in recs) * 1e3, 3),
+                    "create_ms": round(mean("create_s"), 3), "upload_ms": round(mean("upload_s"), 3), "build_ms": round(mean("bvh_build_s"), 3),
+                    "lanes_ms": round(mean("lanes_s"), 3), "render_ms": round(mean("render_s"), 3), "copy_ms": round(mean("copy_s"), 3),
+                    "destroy_ms": round(mean("destroy_s"), 3),
+                    "bvh_builder": "device" if recs[-1][1]["meshes_device_built"] else "host",
+                    "first_call_ms": round(first["total_s"] * 1e3, 3),
+                    "image_sha256_16": _h.sha256(rad1.tobytes()).hexdigest()[:16],
+                    "value": round(W * H * spp / (sum(r[0] for r in recs) / len(recs)) / 1e6, 2), "unit": "Mray-samples/s",
+                    "what": "rbrt_hip_render, the drop-in for the reference's one render_scene call (src/main.rs:82), from the host's scene "
+                            "arrays to the host's RGB8 image, a camera the library has not seen: create (upload + BVH build by whichever "
+                            "builder costs the call less + lanes) + render (tile pass, trace, resolve, quantise) + copy + destroy; the "
+                            "HIP runtime is up already (first_call_ms: this process's first such call, with the radiance copied too)"}
+        del rad1
+
     # the frame whose hash is reported: the configuration's own camera, rendered last (untimed)
     guarded(lambda: (step(False, final=True), fence()))
     if world > 1 and ipc["ok"]:  # rank 0 lets go of the peers' buffers before the peers (who end here) free them
@@ -683,7 +722,10 @@ def main():
                               "tree_stack_need": sinfo.get("bvh_stack_need"),
                               "pushes_beyond_lds": dbg_all["stack_pushes_beyond_lds"],
                               "pushes_beyond_lds_per_traversal": round(dbg_all["stack_pushes_beyond_lds"] / max(1, st["mesh_gate_pass"]), 5),
-                              "deepest_stack": dbg_all["stack_deepest"], "bvh_builder": "device" if sinfo.get("n_meshes_device_built") else "host",
+                              "deepest_stack": dbg_all["stack_deepest"],
+                              "bvh_builder": ("host" if not create_times["meshes_device_built"] else
+                                              f"device first ({create_times['bvh_build_s'] * 1e3:.1f} ms), the host builder's tree adopted from a "
+                                              f"background thread after {refine_s * 1e3:.0f} ms" if refine_state == 1 else "device"),
                               "bvh_nodes": sinfo.get("n_nodes")}}
     if iso is not None:
         roofline["isolated_leg"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in iso.items()}
@@ -775,7 +817,12 @@ def main():
                    # which tiles the trace kernel never sees (DESIGN.md "The tile pass"): every sample of theirs is still
                    # produced -- by sky_resolve_kernel, inside the timed region -- and counted in `value`
                    "tile_pass": tile_pass,
-                   "setup_s_excluded": round(setup_s, 3), "image_sha256_16": image_sha,
+                   "setup_s_excluded": round(setup_total_s, 3),
+                   "setup": {"scene_create_s": round(setup_s, 4), "hip_init_s": round(create_times["hip_init_s"], 4),
+                             "upload_s": round(create_times["upload_s"], 4), "bvh_build_s": round(create_times["bvh_build_s"], 4),
+                             "lanes_s": round(create_times["lanes_s"], 4), "waited_for_the_background_tree_s": round(setup_total_s - setup_s, 4),
+                             "background_tree": {0: "none started", 1: "adopted", 2: "failed or cancelled", 3: "still at work"}[refine_state]},
+                   "image_sha256_16": image_sha,
                    **({"EMULATION_rank0_share_of_world": emu} if emu else {}),
                    # (with the pipeline on, the resolve waits on another stream: its event pair measures that wait)
                    "resolve_kernel_ms": round(resolve_ms / max(1, n_launches), 4) if args.pipeline == 1 else None},
@@ -797,6 +844,8 @@ def main():
                                         "ipc": "rank 0 copies out of the peers' buffers (HIP IPC, interprocess events)"}[gather_mode[0]],
                              "gather_asked": args.gather, "gather_probe_ms_per_step": gather_probe,
                              "ipc_gather_available": bool(ipc["ok"]), "ipc_gather_note": ipc["why"] or None}
+    if one_shot is not None:
+        out["one_shot"] = one_shot
     if single is not None:
         out["single_frame"] = {"ms": round(single["ms"], 4), "ms_new_camera": round(single["ms"], 4), "ms_min": round(single["ms_min"], 4),
                                "ms_same_camera": round(single["ms_same_camera"], 4), "frames": single["frames"],

@@ -79,8 +79,13 @@ int rbrt_hip_scene_debug_set_counter(rbrt_hip_scene_t* scene, size_t index, uint
 int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
                             size_t* n_tris, uint32_t* max_depth, float* max_e12);
 void rbrt_hip_free_host(void* p);
-/* Diagnostic: the GPU-side BVH builder alone (rbrt_amd/csrc/bvh_device.hip; rbrt_hip_scene_create uses it for meshes of
- * 131,072 entries or more, $RBRT_BVH_BUILDER = host | device overrides). Same outputs as rbrt_hip_bvh_build_host;
+/* Diagnostic: the host builder over n 48-B triangle records (device_types.h BvhTri) in ANY order, `index` = the triangle's
+ * position in the reference arrays: for the indexed records of a mesh, array for array the tree rbrt_hip_bvh_build_host
+ * makes of that mesh. (It is what a scene handle's background thread runs on the device builder's output.) */
+int rbrt_hip_bvh_build_host_records(const void* records, size_t n, void** nodes_out, size_t* n_nodes, void** tris_out,
+                                    size_t* n_tris, uint32_t* max_depth, float* max_e12);
+/* Diagnostic: the GPU-side BVH builder alone (rbrt_amd/csrc/bvh_device.hip; rbrt_hip_scene_create uses it wherever it costs the
+ * call less than the host builder, $RBRT_BVH_BUILDER = host | device overrides). Same outputs as rbrt_hip_bvh_build_host;
  * *built = 0 when the builder declined the mesh (fewer than 8 entries, <= 4 indexed triangles, or a tree beyond the
  * traversal's depth budget), in which case scene_create falls back to the host builder. */
 int rbrt_hip_bvh_build_device(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n_nodes, void** tris_out,
@@ -117,6 +122,33 @@ int rbrt_hip_scene_kernel_ms(rbrt_hip_scene_t* scene, float* trace_ms_total, flo
 /* Trace launches since set_timing(scene, 1), by grid: the full grid, or the part of the wave slots a launch of a stream
  * takes (rbrt_hip_scene_set_pipeline; "half" is round 2's name for it), so the mix depends on host timing. */
 int rbrt_hip_scene_launch_mix(rbrt_hip_scene_t* scene, uint32_t* n_full_grid, uint32_t* n_half_grid);
+
+/* Where the wall-clock time of rbrt_hip_scene_create (and, for the one-shot rbrt_hip_render, of the whole call) went, in
+ * seconds. The parts of create_s: hip_init_s + upload_s + bvh_build_s + lanes_s (+ a remainder of validation and small
+ * allocations); of total_s: create_s + render_s + copy_s + destroy_s. bench.py's one_shot leg and the CLI's --report read it. */
+typedef struct rbrt_hip_call_times {
+    double hip_init_s;  /* device selection: the HIP runtime's own start-up when this is a process's first HIP call */
+    double upload_s;    /* the caller's scene arrays to the device */
+    double bvh_build_s; /* BVH construction: the host builder's CPU time + upload of its tree, or the device builder's kernels */
+    double lanes_s;     /* pipeline lanes (streams, events, per-wave scratch) and loading the device code */
+    double create_s;    /* all of rbrt_hip_scene_create */
+    double render_s;    /* rbrt_hip_render only: issue of the render to the synchronised device image */
+    double copy_s;      /* rbrt_hip_render only: image to the caller's host buffers */
+    double destroy_s;   /* rbrt_hip_render only: scene and buffers released */
+    double total_s;     /* rbrt_hip_render only */
+    uint32_t meshes_device_built, meshes_host_built;
+} rbrt_hip_call_times_t;
+int rbrt_hip_scene_create_times(rbrt_hip_scene_t* scene, rbrt_hip_call_times_t* out);
+int rbrt_hip_last_render_times(rbrt_hip_call_times_t* out); /* of the calling thread's last rbrt_hip_render */
+
+/* A scene handle starts with the trees that cost rbrt_hip_scene_create least -- the device builder's for all but small meshes
+ * -- and a background thread makes the host builder's (better) trees of those meshes, which the first render call that
+ * finds them ready adopts (api.cpp "The tree a scene STARTS with"; $RBRT_BVH_REFINE=0 turns it off). This waits up to
+ * timeout_s for that thread and adopts its result now. *state: 0 = none was started, 1 = its trees are in use, 2 = it
+ * failed or was cancelled (rbrt_hip_last_error says why; the first trees stay), 3 = still at work. *build_seconds: start of
+ * the thread to its trees on the device. Either pointer may be NULL. Tests and bench.py (whose counting pass and timed
+ * legs have to run on ONE tree) use it. */
+int rbrt_hip_scene_refine_wait(rbrt_hip_scene_t* scene, double timeout_s, int* state, double* build_seconds);
 
 #ifdef __cplusplus
 }

@@ -23,21 +23,30 @@ def device_count() -> int:
     return int(load_hip().rbrt_hip_device_count())
 
 
-def render_scene(cam: abi.Camera, num_samples: int, scene: abi.SceneData, seed: int = 1, **opt_overrides):
+def render_scene(cam: abi.Camera, num_samples: int, scene: abi.SceneData, seed: int = 1, want_radiance: bool = True,
+                 **opt_overrides):
     """One-shot render through rbrt_hip_render (host buffers in and out).
 
     Same contract as the reference's render_scene (lib.rs:75-79) plus the pre-gamma radiance:
-    returns (radiance float32[H,W,3], rgb8 uint8[H,W,3]).
+    returns (radiance float32[H,W,3], rgb8 uint8[H,W,3]); want_radiance=False: (None, rgb8), exactly what the
+    reference returns.
     """
     lib = load_hip()
     opts = default_opts(spp=num_samples, seed=seed, **opt_overrides)
     H, W = cam.img_height_pix, cam.img_width_pix
-    rad = np.zeros((H, W, 3), np.float32)
-    rgb = np.zeros((H, W, 3), np.uint8)
-    rc = lib.rbrt_hip_render(C.byref(cam), scene.ptr(), C.byref(opts), rad.ctypes.data_as(abi.f32p),
+    rad = np.zeros((H, W, 3), np.float32) if want_radiance else None
+    rgb = np.empty((H, W, 3), np.uint8) if not want_radiance else np.zeros((H, W, 3), np.uint8)
+    rc = lib.rbrt_hip_render(C.byref(cam), scene.ptr(), C.byref(opts), rad.ctypes.data_as(abi.f32p) if want_radiance else None,
                              rgb.ctypes.data_as(abi.u8p))
     abi.check(rc)
     return rad, rgb
+
+
+def last_render_times() -> dict:
+    """Where the time of this thread's last one-shot render_scene (rbrt_hip_render) went (rbrt_hip_last_render_times)."""
+    t = abi.CallTimes()
+    abi.check(load_hip().rbrt_hip_last_render_times(C.byref(t)))
+    return t.as_dict()
 
 
 class HipScene:
@@ -99,6 +108,19 @@ class HipScene:
         abi.check(self._lib.rbrt_hip_scene_launch_mix(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def create_times(self) -> dict:
+        """Where the time of rbrt_hip_scene_create went (rbrt_hip_scene_create_times)."""
+        t = abi.CallTimes()
+        abi.check(self._lib.rbrt_hip_scene_create_times(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def refine_wait(self, timeout_s: float = 60.0):
+        """Waits for the background build of the host builder's trees and adopts them (rbrt_hip_scene_refine_wait).
+        Returns (state, seconds): 0 none was started, 1 in use now, 2 failed / cancelled, 3 still at work."""
+        st, sec = C.c_int(), C.c_double()
+        abi.check(self._lib.rbrt_hip_scene_refine_wait(self._h, float(timeout_s), C.byref(st), C.byref(sec)))
+        return st.value, sec.value
+
     def info(self) -> dict:
         i = abi.SceneInfo()
         abi.check(self._lib.rbrt_hip_scene_info(self._h, C.byref(i)))
@@ -138,7 +160,7 @@ class HipScene:
         d.update(trav_wave_steps=int(buf[12]), trav_lane_steps=int(buf[13]), refill_rounds=int(buf[14]),
                  sched_rounds=int(buf[15]), cycles_trav=int(buf[16]), cycles_shade=int(buf[17]),
                  cycles_total=int(buf[18]), leaf_rounds=int(buf[19]), leaf_lanes=int(buf[20]),
-                 walk_rounds=int(buf[21]), walk_lanes=int(buf[22]), waves_gave_up=int(buf[23]),
+                 walk_rounds=int(buf[21]), walk_lanes=int(buf[22]), shading_pass_free_lanes=int(buf[23]),
                  rt_first_start=int(buf[24]), rt_last_workout=int(buf[25]), rt_last_end=int(buf[26]),
                  rt_sum_wave_time=int(buf[27]), rt_first_workout=int(buf[28]),
                  path_len_hist=[int(buf[32 + i]) for i in range(8)],     # bounces 0, 1, 2-3, 4-7, ... 64+
@@ -151,7 +173,10 @@ class HipScene:
                  stack_pushes_beyond_lds=int(buf[30]), stack_deepest=int(buf[31]),
                  parked_at_burst_entry=int(buf[55]), fullest_shading_kind_at_burst_entry=int(buf[56]),
                  shared_entries_given=int(buf[59]), share_rounds=int(buf[60]), traversals_ending_at_root=int(buf[61]),
-                 sphere_tail_runs=int(buf[62]), sphere_tail_lanes=int(buf[63]))
+                 sphere_tail_runs=int(buf[62]), sphere_tail_lanes=int(buf[63]),
+                 # what a pass of mixed kinds would pick up: passes (and lanes) where the fullest OTHER scatter kind has >= 8 / >= 16 waiting
+                 mixed_pass_8=dict(passes=int(buf[49]) >> 32, lanes=int(buf[49]) & 0xFFFFFFFF),
+                 mixed_pass_16=dict(passes=int(buf[58]) >> 32, lanes=int(buf[58]) & 0xFFFFFFFF))
         return d
 
     def primary_cull(self, cam):

@@ -128,6 +128,14 @@ class SceneInfo(C.Structure):
     ]
 
 
+class CallTimes(C.Structure):  # rbrt_hip_call_times_t (include/rbrt_hip_debug.h)
+    _fields_ = [(k, C.c_double) for k in ("hip_init_s", "upload_s", "bvh_build_s", "lanes_s", "create_s", "render_s", "copy_s",
+                                          "destroy_s", "total_s")] + [("meshes_device_built", C.c_uint32), ("meshes_host_built", C.c_uint32)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 # every symbol include/rbrt_hip.h (the drop-in boundary) declares: name -> (restype, argtypes)
 HIP_SYMBOLS = {
     "rbrt_hip_render": (C.c_int, [C.POINTER(Camera), C.POINTER(Scene), C.POINTER(RenderOpts), f32p, u8p]),
@@ -161,6 +169,8 @@ DEBUG_SYMBOLS = {
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
                                           f32p]),
     "rbrt_hip_free_host": (None, [C.c_void_p]),
+    "rbrt_hip_bvh_build_host_records": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), f32p]),
     "rbrt_hip_bvh_build_device": (C.c_int, [C.POINTER(Mesh), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
                                             f32p, C.POINTER(C.c_int)]),
@@ -172,6 +182,9 @@ DEBUG_SYMBOLS = {
     "rbrt_hip_debug_scatter": (C.c_int, [C.POINTER(Material), f32p, f32p, f32p, C.POINTER(C.c_uint32), C.c_size_t, f32p, u8p,
                                         C.POINTER(C.c_uint32)]),
     "rbrt_hip_debug_primary_cull": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(C.c_uint32), C.c_size_t]),
+    "rbrt_hip_scene_create_times": (C.c_int, [C.c_void_p, C.POINTER(CallTimes)]),
+    "rbrt_hip_last_render_times": (C.c_int, [C.POINTER(CallTimes)]),
+    "rbrt_hip_scene_refine_wait": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }
 
 

@@ -3,12 +3,16 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <limits>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh.h"
@@ -43,6 +47,21 @@ using namespace rbrt;
 namespace {
 
 thread_local std::string g_last_error;
+thread_local rbrt_hip_call_times_t g_last_render_times{};  // of this thread's last rbrt_hip_render (rbrt_hip_debug.h)
+
+// GPU_MAX_HW_QUEUES as the process had it when this library was LOADED: the HIP runtime reads the variable when it starts,
+// and a host that exports it later (an embedding application, a profiler's preload that initialised the GPU first) would
+// make the library plan for eight queues on a runtime that has four.
+const uint32_t g_hw_queues_at_load = [] {
+    if (const char* q = std::getenv("GPU_MAX_HW_QUEUES")) {
+        char* end = nullptr;
+        const long v = std::strtol(q, &end, 10);
+        if (end != q && *end == '\0' && v >= 1 && v <= 64) return uint32_t(v);
+    }
+    return 4u;  // the runtime's default
+}();
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -217,6 +236,111 @@ struct rbrt_hip_scene {
     uint32_t n_full_grid = 0, n_half_grid = 0;    // trace launches since set_timing(1), by grid size (rbrt_hip_scene_kernel_ms_ex)
     uint64_t total_nodes = 0, total_tris = 0;
     uint32_t n_device_built = 0;  // meshes whose BVH the GPU built
+    rbrt_hip_call_times_t create_times{};  // where scene_create's time went (rbrt_hip_scene_create_times)
+    std::unique_ptr<struct Refine> refine;  // the host builder's tree of device-built meshes, made in the background (below)
+    uint32_t n_refined = 0;                 // meshes whose device-built tree has been replaced by it
+};
+
+// ---- The tree a scene STARTS with and the tree it goes on with -------------------------------------------------------
+// rbrt_hip_scene_create cannot know how long its handle will live: the reference's one call (src/main.rs:82) renders a
+// 1024x768x50 frame in 4 ms here, and the host's binned-SAH build of the bunny-sized mesh costs twenty times that, while
+// the device builder makes a tree in about a millisecond per hundred thousand triangles whose frames are 2-3 % slower
+// (clustered over the Morton order). So a mesh the device builder accepts gets its tree FIRST,
+// the handle is usable at once, and a background thread makes the SAH tree from the very records the device builder
+// emitted (read back from the device: the caller's arrays are only borrowed for the duration of scene_create) and uploads
+// it into fresh allocations; the first render call that finds it ready switches the scene's pointers over. Launches
+// in flight keep reading the old arrays, which live until the handle is destroyed. Any tree with bvh.h's properties gives
+// the scan's answer, so the image does not change (tests/test_bvh_refine.py). rbrt_hip_scene_destroy cancels a build
+// nobody waits for; the one-shot rbrt_hip_render does not start one. $RBRT_BVH_REFINE=0 turns it off, RBRT_BVH_BUILDER =
+// host | device force one builder (and no refinement).
+struct Refine {
+    std::thread th;
+    std::atomic<int> state{0};  // 0: the thread is at work; 1: results ready, not adopted yet; 2: nothing (more) to adopt
+    std::atomic<bool> cancel{false};
+    // in
+    int device = 0;
+    const BvhTri* d_tris = nullptr;  // the scene's record array as the device builder left it
+    size_t tri_total = 0;
+    std::vector<DevMesh> meshes;     // the scene's mesh table
+    std::vector<uint32_t> tri_base, n_valid;
+    std::vector<uint8_t> wanted;     // per mesh: 1 = device-built, to be rebuilt
+    unsigned max_threads = 0;
+    // out
+    std::vector<void*> allocs;
+    BvhTri* d_tris_new = nullptr;
+    DevMesh* d_meshes_new = nullptr;
+    uint32_t stack_need = 1, n_done = 0;
+    uint64_t nodes_delta_plus = 0, nodes_delta_minus = 0;
+    double seconds = 0.0;  // start of the thread to results on the device
+    std::string error;
+
+    void run() {
+        const double t0 = now_s();
+        hipStream_t st = nullptr;
+        std::vector<BvhTri> h;
+        const auto finish = [&](const std::string& why) {
+            if (st) (void)hipStreamDestroy(st);
+            if (!why.empty()) {
+                for (void* p : allocs) (void)hipFree(p);
+                allocs.clear();
+                error = why;
+            }
+            seconds = now_s() - t0;
+            state.store(why.empty() ? 1 : 2, std::memory_order_release);
+        };
+        const auto hip = [&](hipError_t e, const char* what) -> bool {
+            if (e == hipSuccess) return true;
+            finish(std::string(what) + ": " + hipGetErrorString(e));
+            return false;
+        };
+        if (!hip(hipSetDevice(device), "hipSetDevice")) return;
+        if (!hip(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate")) return;
+        h.resize(tri_total);
+        if (!hip(hipMemcpyAsync(h.data(), d_tris, tri_total * sizeof(BvhTri), hipMemcpyDeviceToHost, st), "read-back of the records")) return;
+        if (!hip(hipStreamSynchronize(st), "read-back of the records")) return;
+        std::vector<BvhBuildResult> built(meshes.size());
+        BvhBuildOptions opt;
+        opt.max_threads = max_threads, opt.cancel = &cancel;
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            if (!wanted[i]) continue;
+            built[i] = build_bvh_from_records(h.data() + tri_base[i], n_valid[i], opt);
+            if (built[i].cancelled || cancel.load()) return finish("cancelled");
+            BvhBuildResult& b = built[i];
+            const size_t cap = size_t(i + 1 < meshes.size() ? tri_base[i + 1] : uint32_t(tri_total)) - tri_base[i];
+            if (b.tris.size() > cap || b.nodes.empty()) return finish("the host builder's tree does not fit the mesh's records");
+            if (tri_base[i] != 0)
+                for (BvhNode4& nd : b.nodes)
+                    for (int c = 0; c < 4; ++c)
+                        if (nd.child[c] < 0 && nd.child[c] != kNoChild) {
+                            const uint32_t leaf = uint32_t(~nd.child[c]);
+                            nd.child[c] = ~int32_t((((leaf >> kLeafBits) + tri_base[i]) << kLeafBits) | (leaf & uint32_t(kLeafMax - 1)));
+                        }
+            void* p = nullptr;
+            if (!hip(hipMalloc(&p, b.nodes.size() * sizeof(BvhNode4)), "hipMalloc(nodes)")) return;
+            allocs.push_back(p);
+            if (!hip(hipMemcpyAsync(p, b.nodes.data(), b.nodes.size() * sizeof(BvhNode4), hipMemcpyHostToDevice, st), "upload of the nodes")) return;
+            std::copy(b.tris.begin(), b.tris.end(), h.begin() + tri_base[i]);
+            nodes_delta_minus += meshes[i].n_nodes, nodes_delta_plus += b.nodes.size();
+            meshes[i].nodes = static_cast<const BvhNode4*>(p);
+            meshes[i].max_e12 = b.max_e12;
+            meshes[i].n_nodes = uint32_t(b.nodes.size());
+            meshes[i].n_tris = uint32_t(b.tris.size());
+            stack_need = std::max(stack_need, b.stack_need);
+            ++n_done;
+        }
+        void* p = nullptr;
+        if (!hip(hipMalloc(&p, std::max<size_t>(tri_total * sizeof(BvhTri), 64)), "hipMalloc(records)")) return;
+        allocs.push_back(p);
+        d_tris_new = static_cast<BvhTri*>(p);
+        if (!hip(hipMemcpyAsync(p, h.data(), tri_total * sizeof(BvhTri), hipMemcpyHostToDevice, st), "upload of the records")) return;
+        for (DevMesh& dm : meshes) dm.tris = d_tris_new;
+        if (!hip(hipMalloc(&p, std::max<size_t>(meshes.size() * sizeof(DevMesh), 16)), "hipMalloc(mesh table)")) return;
+        allocs.push_back(p);
+        d_meshes_new = static_cast<DevMesh*>(p);
+        if (!hip(hipMemcpyAsync(p, meshes.data(), meshes.size() * sizeof(DevMesh), hipMemcpyHostToDevice, st), "upload of the mesh table")) return;
+        if (!hip(hipStreamSynchronize(st), "upload of the refined trees")) return;
+        finish("");
+    }
 };
 
 namespace {
@@ -246,7 +370,9 @@ int upload(rbrt_hip_scene* s, const std::vector<T>& host, T** out) {
 // Uploads a mesh's SoA arrays and builds its BVH on the GPU (bvh_device.hip): triangle records to d_tris_out (leaf
 // links absolute, d_tris_out[0] being record tri_base of the scene's array), normals to d_normals (may be null).
 // r->ok says whether a tree was built; on error nothing is left allocated.
-hipError_t device_build_mesh(const rbrt_mesh_t& m, BvhTri* d_tris_out, uint32_t tri_base, Normal4* d_normals, DeviceBvhResult* r) {
+hipError_t device_build_mesh(const rbrt_mesh_t& m, BvhTri* d_tris_out, uint32_t tri_base, Normal4* d_normals, DeviceBvhResult* r,
+                             double* upload_s = nullptr) {
+    const double t_up0 = now_s();
     const float* src[12] = {m.v0x, m.v0y, m.v0z, m.e1x, m.e1y, m.e1z, m.e2x, m.e2y, m.e2z, m.nx, m.ny, m.nz};
     float* d_soa = nullptr;
     uint8_t* d_pad = nullptr;
@@ -256,6 +382,7 @@ hipError_t device_build_mesh(const rbrt_mesh_t& m, BvhTri* d_tris_out, uint32_t 
     for (int k = 0; k < 12 && e == hipSuccess; ++k)
         e = hipMemcpy(d_soa + stride * k, src[k], size_t(m.n_total) * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_pad, m.is_padding, m.n_total, hipMemcpyHostToDevice);
+    if (upload_s) *upload_s = now_s() - t_up0;
     if (e == hipSuccess) {
         const DeviceMeshSoa soa = {d_soa, d_soa + stride, d_soa + 2 * stride, d_soa + 3 * stride, d_soa + 4 * stride,
                                    d_soa + 5 * stride, d_soa + 6 * stride, d_soa + 7 * stride, d_soa + 8 * stride, d_pad};
@@ -309,16 +436,16 @@ uint32_t depth_for(const rbrt_hip_scene* s, size_t sample_buffer_bytes) {
 }
 
 // Is a trace launch of this scene still running on another lane? (What decides how the next one is issued.)
-uint32_t other_launches_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane* mine) {
-    uint32_t busy = 0;
+bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane* mine) {
     for (const auto& L : s->lanes)
-        if (&L != mine && L.in_use && L.ev_traced && hipEventQuery(L.ev_traced) == hipErrorNotReady) ++busy;
-    // (hipErrorNotReady is an answer, not a failure: keep it out of the next launch check -- and clear the error state
-    // only then, so that an unrelated sticky error still reaches whoever checks next)
-    if (busy) (void)hipGetLastError();
-    return busy;
+        if (&L != mine && L.in_use && L.ev_traced && hipEventQuery(L.ev_traced) == hipErrorNotReady) {
+            // (hipErrorNotReady is an answer, not a failure: keep it out of the next launch check -- and clear the error
+            // state only then, so that an unrelated sticky error still reaches whoever checks next)
+            (void)hipGetLastError();
+            return true;
+        }
+    return false;
 }
-bool other_launch_in_flight(const rbrt_hip_scene* s, const rbrt_hip_scene::Lane* mine) { return other_launches_in_flight(s, mine) != 0u; }
 
 // Waves of one trace launch. A launch that finds the GPU idle (a blocking caller, the first frame of a stream) takes all
 // resident wave slots. One issued while another is still running -- consecutive frames or sample batches queued back to
@@ -423,6 +550,23 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
     return RBRT_OK;
 }
 
+// Switches the scene over to the background thread's trees once they are on the device (struct Refine). Launches issued
+// before keep the arrays they were given; nothing is freed before rbrt_hip_scene_destroy.
+void adopt_refined(rbrt_hip_scene* s) {
+    Refine* r = s->refine.get();
+    if (!r || r->state.load(std::memory_order_acquire) != 1) return;
+    if (r->th.joinable()) r->th.join();
+    s->d_tris = r->d_tris_new;
+    s->d_meshes = r->d_meshes_new;
+    s->allocs.insert(s->allocs.end(), r->allocs.begin(), r->allocs.end());
+    r->allocs.clear();
+    s->stack_need = std::max(s->stack_need, r->stack_need);
+    s->total_nodes = s->total_nodes + r->nodes_delta_plus - r->nodes_delta_minus;
+    s->n_device_built -= std::min(s->n_device_built, r->n_done);
+    s->n_refined += r->n_done;
+    r->state.store(2, std::memory_order_release);
+}
+
 int check_material(const rbrt_material_t& m) {
     if (m.kind < RBRT_MAT_LAMBERTIAN || m.kind > RBRT_MAT_DIELECTRIC)
         return fail(RBRT_ERR_INVALID_ARG, "unknown material kind");
@@ -488,6 +632,26 @@ bool empty_end_is_first(const rbrt_hip_scene* s, const rbrt_camera_t& cam, uint3
     return first < last;
 }
 
+// What scene_create is told about the call it serves (the ABI's rbrt_hip_scene_create knows nothing: a handle).
+struct CreateHint {
+    bool one_shot = false;       // rbrt_hip_render: one render, then the scene is destroyed
+    double render_s_est = 0.0;   // ... and about this long (0: unknown)
+};
+
+// Which builder makes a mesh's FIRST tree: the one that costs the call less. Measured on an MI355X box (tools/create_sweep.py,
+// profiles/r05_create_sweep.txt): the host builder takes kHostBuildSecPerTri per entry on the box's cores, the device builder
+// kDeviceBuildSec0 + kDeviceBuildSecPerTri per entry (uploads included); frames through the device's tree take
+// kDeviceTreeSlowdown longer. A handle starts with the cheaper build and, where that was the device's, gets the host's tree
+// in the background (struct Refine); a one-shot call adds what the slower frames of ITS render would cost.
+constexpr double kHostBuildSecPerTri = 1.1e-6, kDeviceBuildSec0 = 1.5e-3, kDeviceBuildSecPerTri = 1.2e-8, kDeviceTreeSlowdown = 0.04;
+bool device_builder_is_cheaper(uint32_t n_total, const CreateHint& hint) {
+    const double host_s = kHostBuildSecPerTri * n_total;
+    const double device_s = kDeviceBuildSec0 + kDeviceBuildSecPerTri * n_total + (hint.one_shot ? kDeviceTreeSlowdown * hint.render_s_est : 0.0);
+    return n_total >= 8u && device_s < host_s;
+}
+
+int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** out, const CreateHint& hint);
+
 }  // namespace
 
 extern "C" {
@@ -527,6 +691,14 @@ size_t rbrt_hip_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_ran
 }
 
 int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** out) {
+    return scene_create_impl(scene, device, out, CreateHint());
+}
+
+}  // extern "C"
+
+namespace {
+
+int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** out, const CreateHint& hint) {
     if (!scene || !out) return fail(RBRT_ERR_INVALID_ARG, "scene_create: null argument");
     *out = nullptr;
     if (scene->n_spheres && !scene->spheres) return fail(RBRT_ERR_INVALID_ARG, "spheres is null");
@@ -563,10 +735,13 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
                           !m.e2z || !m.nx || !m.ny || !m.nz || !m.is_padding))
             return fail(RBRT_ERR_INVALID_ARG, "mesh array pointer is null");
     }
+    const double t_create0 = now_s();
     if (int rc = ensure_device(device)) return rc;
 
     rbrt_hip_scene* s = new rbrt_hip_scene();
     s->device = device;
+    s->create_times.hip_init_s = now_s() - t_create0;
+    double t_upload = 0.0, t_build = 0.0;
     s->n_spheres = scene->n_spheres;
     s->n_meshes = scene->n_meshes;
     s->n_elem_tris = scene->n_triangles;
@@ -646,17 +821,23 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         s->d_tris = static_cast<BvhTri*>(p);
         HIP_TRY_BAIL(hipMemset(p, 0, bytes));  // (records no leaf points at: zero-area triangles)
     }
-    // Builder: the GPU (bvh_device.hip: Morton-ordered radix tree, ~ms for a million triangles) for big meshes, the
-    // host's binned-SAH builder (bvh.cpp: a better tree, 5 us per triangle) for small ones; RBRT_BVH_BUILDER = host |
-    // device forces one. The device builder declines what it does not handle (tiny meshes, a tree deeper than the
-    // traversal stack allows) and the host builder takes over.
-    int builder_mode = 0;  // 0 auto, 1 host, 2 device
+    // Builder of each mesh's first tree: whichever costs this call less (device_builder_is_cheaper), the host's tree
+    // following in the background for a handle (struct Refine); RBRT_BVH_BUILDER = host | device forces one and nothing
+    // follows. The device builder declines what it does not handle (tiny meshes, a tree deeper than the traversal stack
+    // allows) and the host builder takes over.
+    int builder_mode = 0;  // 0 by cost, 1 host, 2 device
     if (const char* e = std::getenv("RBRT_BVH_BUILDER")) builder_mode = !std::strcmp(e, "host") ? 1 : !std::strcmp(e, "device") ? 2 : 0;
-    uint32_t device_min_tris = 131072;
+    bool refine_allowed = builder_mode == 0 && !hint.one_shot;
+    if (const char* e = std::getenv("RBRT_BVH_REFINE")) refine_allowed = refine_allowed && e[0] != '0';
+    uint32_t device_min_tris = 0;  // (lab: a threshold on the entry count instead of the cost rule)
+    bool device_min_set = false;
     {
         std::string err;
         if (!lab_u32("RBRT_BVH_DEVICE_MIN", 0, 1ll << 30, device_min_tris, err)) return bail(fail(RBRT_ERR_INVALID_ARG, err));
+        device_min_set = lab_env("RBRT_BVH_DEVICE_MIN") != nullptr;
     }
+    std::vector<uint8_t> device_built(scene->n_meshes, 0);
+    std::vector<uint32_t> n_valid_of(scene->n_meshes, 0);
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         const rbrt_mesh_t& m = scene->meshes[i];
         put_mat(n_elem + i, m.mat);
@@ -669,10 +850,14 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
             d_normals = static_cast<Normal4*>(p);
         }
         bool built = false;
-        const bool try_device = builder_mode == 2 || (builder_mode == 0 && m.n_total >= device_min_tris);
+        const bool try_device = builder_mode == 2 || (builder_mode == 0 && (device_min_set ? m.n_total >= device_min_tris
+                                                                                           : device_builder_is_cheaper(m.n_total, hint)));
         if (try_device && m.n_total >= 8) {
             DeviceBvhResult r;
-            const hipError_t e = device_build_mesh(m, s->d_tris + tri_base[i], tri_base[i], d_normals, &r);
+            const double tb0 = now_s();
+            double up = 0.0;
+            const hipError_t e = device_build_mesh(m, s->d_tris + tri_base[i], tri_base[i], d_normals, &r, &up);
+            t_upload += up, t_build += now_s() - tb0 - up;
             if (e != hipSuccess)
                 return bail(fail(e == hipErrorOutOfMemory ? RBRT_ERR_OOM : RBRT_ERR_HIP, std::string("device BVH build: ") + hipGetErrorString(e)));
             if (r.ok) {
@@ -685,10 +870,12 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
                 s->total_nodes += r.n_nodes;
                 s->total_tris += r.n_valid;
                 s->n_device_built += 1;
+                device_built[i] = 1, n_valid_of[i] = r.n_valid;
                 built = true;
             }
         }
         if (!built) {
+            const double tb0 = now_s();
             BvhBuildResult bvh = build_bvh(m);
             if (tri_base[i] != 0)
                 for (BvhNode4& nd : bvh.nodes)
@@ -699,12 +886,14 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
                         }
             std::vector<Normal4> normals(m.n_total);
             for (uint32_t k = 0; k < m.n_total; ++k) normals[k] = Normal4{m.nx[k], m.ny[k], m.nz[k], 0.0f};
+            const double tb1 = now_s();
             BvhNode4* d_nodes = nullptr;
             if (int rc = upload(s, bvh.nodes, &d_nodes)) return bail(rc);
             if (!bvh.tris.empty())
                 HIP_TRY_BAIL(hipMemcpy(s->d_tris + tri_base[i], bvh.tris.data(), bvh.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
             if (!normals.empty())
                 HIP_TRY_BAIL(hipMemcpy(d_normals, normals.data(), normals.size() * sizeof(Normal4), hipMemcpyHostToDevice));
+            t_build += tb1 - tb0, t_upload += now_s() - tb1;
             dm.nodes = d_nodes;
             dm.max_e12 = bvh.max_e12;
             dm.n_nodes = uint32_t(bvh.nodes.size());
@@ -774,25 +963,52 @@ int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_
         if (waves_per_cu != 0) per_cu = int(waves_per_cu), s->waves_fixed = true;
         s->n_waves = uint32_t(cus * per_cu);
         s->n_cus = uint32_t(cus);
-        if (const char* q = std::getenv("GPU_MAX_HW_QUEUES")) {  // (read by the HIP runtime when it starts; not a knob of this library)
-            char* end = nullptr;
-            const long v = std::strtol(q, &end, 10);
-            if (end != q && *end == '\0' && v >= 1 && v <= 64) s->hw_queues = uint32_t(v);
-        }
+        s->hw_queues = g_hw_queues_at_load;
         s->scratch_waves = s->n_waves;  // per-wave scratch is indexed by workgroup (= wave); no grid is larger than n_waves
-        // all lanes up front: rbrt_hip_render_device then never allocates lanes (which synchronises the device)
-        if (int rc = ensure_lanes(s, std::max(kLanesAtCreate, s->pipeline))) return bail(rc);
+        // lanes up front: rbrt_hip_render_device then never allocates lanes (which synchronises the device); a one-shot
+        // call makes the lanes its batches will use (rbrt_hip_render)
+        const double t_lanes0 = now_s();
+        if (int rc = ensure_lanes(s, std::max(hint.one_shot ? 1u : kLanesAtCreate, s->pipeline))) return bail(rc);
         // (the library's device code, loaded now instead of inside the first render)
         if (launch_code_load(nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
             return bail(fail(RBRT_ERR_HIP, "the library's device code does not load on this GPU (built for gfx950)"));
+        s->create_times.lanes_s = now_s() - t_lanes0;
     }
+    // the host builder's tree of the device-built meshes, in the background (struct Refine)
+    if (refine_allowed && s->n_device_built != 0) {
+        std::unique_ptr<Refine> r(new Refine());
+        r->device = device;
+        r->d_tris = s->d_tris, r->tri_total = size_t(tri_total);
+        r->meshes = meshes, r->tri_base = tri_base, r->n_valid = n_valid_of, r->wanted = device_built;
+        const unsigned hc = std::thread::hardware_concurrency();
+        r->max_threads = std::max(1u, hc / 2u);  // (the caller's thread goes on issuing launches)
+        Refine* rp = r.get();
+        try {
+            r->th = std::thread([rp]() { rp->run(); });
+            s->refine = std::move(r);
+        } catch (...) {  // (no thread to be had: the device's tree stays)
+        }
+    }
+    s->create_times.upload_s = t_upload, s->create_times.bvh_build_s = t_build;
+    s->create_times.meshes_device_built = s->n_device_built, s->create_times.meshes_host_built = s->n_meshes - s->n_device_built;
+    s->create_times.create_s = now_s() - t_create0;
     *out = s;
     return RBRT_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     if (!s) return RBRT_OK;
     (void)hipSetDevice(s->device);
+    if (Refine* r = s->refine.get()) {  // a background build nobody will use: cancelled, its allocations released
+        r->cancel.store(true);
+        if (r->th.joinable()) r->th.join();
+        for (void* p : r->allocs) (void)hipFree(p);
+        r->allocs.clear();
+    }
     (void)hipDeviceSynchronize();  // lane streams included
     for (auto& L : s->lanes) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -872,6 +1088,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     const uint32_t world = o->tile_world ? o->tile_world : 1;
     if (o->tile_rank >= world) return fail(RBRT_ERR_INVALID_ARG, "tile_rank >= tile_world");
     HIP_TRY(hipSetDevice(s->device));
+    adopt_refined(s);  // (the background thread's trees, once they are on the device: this call's launches use them)
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
 
     const uint32_t W = cam->img_width_pix, H = cam->img_height_pix;
@@ -893,12 +1110,11 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     // thirteen batches of a 1920x1080x512 render gain from them), and only the lanes it launches on get their buffers: the first frame of a scene took 12.9 ms with three lanes' buffers to make
     // and 39.9 with eight lanes', against 5.0 with one (4.2 from the second frame on). The first call of a stream that is
     // issued into a busy GPU makes the rest, during the stream's first frames.
-    const size_t n_batches_wanted = (size_t(s_end - s_begin) + batch - 1) / batch;
     const bool stats_call = (o->flags & RBRT_FLAG_COLLECT_STATS) != 0;
     const uint32_t depth_full = depth_for(s, need);
-    const bool streams_now = !stats_call && depth_full > 1 && (s->streaming_hint || other_launch_in_flight(s, nullptr));
+    const bool busy_at_call = other_launch_in_flight(s, nullptr);  // (asked once: every answer is up to eight hipEventQuery calls)
+    const bool streams_now = !stats_call && depth_full > 1 && (s->streaming_hint || busy_at_call);
     const uint32_t depth = streams_now ? depth_full : std::min<uint32_t>(depth_full, uint32_t(std::max<size_t>(s->lanes.size(), 1)));
-    (void)n_batches_wanted;
     if (int rc = ensure_lanes(s, depth)) return rc;
     const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1025,7 +1241,10 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         T.tile_list_mode = list_mode_for(s, true);  // (what the launches of a stream use; an isolated launch makes its own list)
         T.tile_tail_div = s->tile_tail_div;
         T.tiles_reversed = P.tiles_reversed;
-        T.tile_lists_wide = 1u;  // (a scene's first call: nothing of it is in flight)
+        // (the one-wave form of the list kernel: `streams_now` means a launch of this scene is in flight or about to be, and a
+        // 256-thread workgroup waits for four free wave slots on one CU beside resident trace waves -- up to 10 ms for 21 us
+        // of work, profiles/r04_default_kernel_stats.csv -- with the resolve chain of the caller's stream queued behind it)
+        T.tile_lists_wide = 0u;
         for (uint32_t li = 0; li < depth; ++li) {
             rbrt_hip_scene::Lane& L = s->lanes[li];
             if (L.tiles[0].key_valid || L.tiles[1].key_valid) continue;
@@ -1062,7 +1281,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         // blocking caller's -- goes to a lane that already has the tile tables of its camera, if there is one: with eight
         // lanes taking turns a caller who renders one view again and again would otherwise pay the tile pass eight times)
         uint32_t lane_no = stats ? 0u : s->next_lane % depth;
-        if (!stats && depth > 1 && s->primary_cull != 0 && !s->streaming_hint && !other_launch_in_flight(s, nullptr)) {
+        // (a call's later batches find its earlier ones in flight)
+        if (!stats && depth > 1 && s->primary_cull != 0 && !s->streaming_hint && b == 0 && !busy_at_call) {
             rbrt_hip_scene::Lane::TileKey want;
             std::memset(&want, 0, sizeof(want));
             want.cam = *cam, want.rank = o->tile_rank, want.world = world, want.list_mode = list_mode_for(s, false), want.min_dist = o->min_dist;
@@ -1091,8 +1311,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.n_items = uint64_t(npix) * nb;
         // (a caller that streams launches keeps doing so: the first launch after a pause -- the GPU is idle, but the
         // launch before it was issued into a busy one -- is still issued as one of a stream)
-        const uint32_t in_flight = piped ? other_launches_in_flight(s, &L) : 0u;
-        const bool busy = in_flight != 0u;
+        const bool busy = piped && other_launch_in_flight(s, &L);
         // (the hint is about CALLS: a call's later batches always find its earlier ones in flight, which says nothing about
         // whether the caller streams frames or waits for each. The batches of a call that found the GPU idle are sized by
         // the batches behind them, the last one takes the full grid and the isolated launch's list: it ends with nothing
@@ -1104,7 +1323,6 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         // (a blocking call's batch shares the GPU with the batches behind it: the last one ends alone and takes the full
         // grid, the one before it shares with one, ...; a stream's launch takes the steady state's share: grid_for)
         const uint32_t company = to_come;
-        (void)in_flight;
         if (b == 0) s->streaming_hint = busy;
         P.work_stripes = !overlapped ? s->work_stripes
                          : s->work_stripes_overlap != kStripesAuto ? s->work_stripes_overlap
@@ -1256,8 +1474,44 @@ int rbrt_hip_scene_check(rbrt_hip_scene_t* s) {
     return RBRT_OK;
 }
 
+int rbrt_hip_scene_create_times(rbrt_hip_scene_t* s, rbrt_hip_call_times_t* out) {
+    if (!s || !out) return fail(RBRT_ERR_INVALID_ARG, "create_times: null argument");
+    *out = s->create_times;
+    return RBRT_OK;
+}
+
+int rbrt_hip_last_render_times(rbrt_hip_call_times_t* out) {
+    if (!out) return fail(RBRT_ERR_INVALID_ARG, "last_render_times: null argument");
+    *out = g_last_render_times;
+    return RBRT_OK;
+}
+
+// Waits (at most timeout_s) for the background build of a scene's trees (struct Refine) and adopts its result.
+// *state: 0 = no background build was started (host-built meshes, a forced builder, RBRT_BVH_REFINE=0, a one-shot call),
+// 1 = its trees are in use now, 2 = it failed or was cancelled (the device builder's trees stay), 3 = still at work.
+int rbrt_hip_scene_refine_wait(rbrt_hip_scene_t* s, double timeout_s, int* state, double* build_seconds) {
+    if (!s) return fail(RBRT_ERR_INVALID_ARG, "refine_wait: null scene");
+    int st = 0;
+    if (Refine* r = s->refine.get()) {
+        const double t0 = now_s();
+        while (r->state.load(std::memory_order_acquire) == 0 && now_s() - t0 < timeout_s) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        HIP_TRY(hipSetDevice(s->device));
+        adopt_refined(s);
+        const int rs = r->state.load(std::memory_order_acquire);
+        st = rs == 0 ? 3 : s->n_refined != 0 ? 1 : 2;
+        if (build_seconds) *build_seconds = rs == 0 ? 0.0 : r->seconds;
+        if (st == 2 && r->th.joinable()) r->th.join();
+        if (st == 2) g_last_error = "background BVH build: " + r->error;
+    } else if (build_seconds) {
+        *build_seconds = 0.0;
+    }
+    if (state) *state = st;
+    return RBRT_OK;
+}
+
 int rbrt_hip_scene_info(rbrt_hip_scene_t* s, rbrt_hip_scene_info_t* out) {
     if (!s || !out) return fail(RBRT_ERR_INVALID_ARG, "scene_info: null argument");
+    adopt_refined(s);
     std::memset(out, 0, sizeof(*out));
     out->n_spheres = s->n_spheres, out->n_meshes = s->n_meshes;
     out->n_meshes_device_built = s->n_device_built;
@@ -1298,11 +1552,23 @@ int rbrt_hip_unpack_tiles(int device, void* stream, const float* d_gathered, uin
 int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const rbrt_render_opts_t* opts,
                     float* out_radiance, uint8_t* out_rgb8) {
     if (!cam || !scene || !opts) return fail(RBRT_ERR_INVALID_ARG, "render: null argument");
+    const double t_call0 = now_s();
+    rbrt_hip_call_times_t& times = g_last_render_times;
+    std::memset(&times, 0, sizeof(times));
     rbrt_hip_scene_t* s = nullptr;
-    if (int rc = rbrt_hip_scene_create(scene, 0, &s)) return rc;
-    // (one frame and the scene is gone again: the batches of this one render overlap on three lanes as before; the eight
-    // lanes of a scene that serves a stream of frames would only be allocated -- 8 sample buffers, 1 GB of scratch -- and freed)
-    if (s->pipeline == 0) s->pipeline = 3;
+    // One render, then the scene is gone again: its trees are made by whichever builder costs THIS call less (a frame of
+    // ~10 G path samples per second against the host builder's ~1 us per triangle: device_builder_is_cheaper), no
+    // background build is started, and it gets the lanes its sample batches will use, not a stream's eight.
+    CreateHint hint;
+    hint.one_shot = true;
+    {
+        const uint32_t w1 = opts->tile_world ? opts->tile_world : 1;
+        hint.render_s_est = double(cam->img_width_pix) * cam->img_height_pix * opts->spp / w1 / 10.0e9;
+    }
+    if (int rc = scene_create_impl(scene, 0, &s, hint)) return rc;
+    times = s->create_times;
+    if (s->pipeline == 0) s->pipeline = 3;  // (the batches of this one render overlap on three lanes)
+    const double t_render0 = now_s();
     const uint32_t world = opts->tile_world ? opts->tile_world : 1;
     const size_t npix_img = size_t(cam->img_width_pix) * cam->img_height_pix;
     const size_t n_out = world > 1
@@ -1337,6 +1603,8 @@ int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const r
         return rc;
     }
     TRY_OR_CLEAN(hipDeviceSynchronize());
+    const double t_copy0 = now_s();
+    times.render_s = t_copy0 - t_render0;
     if (world > 1) {
         // scatter this rank's packed tiles into the caller's full-size images
         std::vector<float> hr(n_out * 3);
@@ -1366,7 +1634,11 @@ int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const r
     }
     DevCounters c;
     TRY_OR_CLEAN(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    const double t_destroy0 = now_s();
+    times.copy_s = t_destroy0 - t_copy0;
     cleanup();
+    times.destroy_s = now_s() - t_destroy0;
+    times.total_s = now_s() - t_call0;
 #undef TRY_OR_CLEAN
     if (c.diag[57])
         return fail(RBRT_ERR_HIP, "the trace kernel detected corrupt internal state (a path slot without a valid sample index)");
@@ -1415,6 +1687,25 @@ int rbrt_hip_bvh_build_host(const rbrt_mesh_t* mesh, void** nodes_out, size_t* n
     return RBRT_OK;
 }
 void rbrt_hip_free_host(void* p) { std::free(p); }
+
+// Diagnostic: the host builder over n 48-B triangle records in any order (what the background thread of a scene handle
+// runs on the device builder's output, struct Refine). Same outputs as rbrt_hip_bvh_build_host.
+int rbrt_hip_bvh_build_host_records(const void* records, size_t n, void** nodes_out, size_t* n_nodes, void** tris_out,
+                                    size_t* n_tris, uint32_t* max_depth, float* max_e12) {
+    if ((!records && n) || !nodes_out || !n_nodes || !tris_out || !n_tris)
+        return fail(RBRT_ERR_INVALID_ARG, "bvh_build_host_records: null argument");
+    BvhBuildResult r = build_bvh_from_records(static_cast<const BvhTri*>(records), n);
+    *n_nodes = r.nodes.size();
+    *n_tris = r.tris.size();
+    *nodes_out = std::malloc(std::max<size_t>(1, r.nodes.size() * sizeof(BvhNode4)));
+    *tris_out = std::malloc(std::max<size_t>(1, r.tris.size() * sizeof(BvhTri)));
+    if (!*nodes_out || !*tris_out) return fail(RBRT_ERR_OOM, "bvh_build_host_records: malloc failed");
+    std::memcpy(*nodes_out, r.nodes.data(), r.nodes.size() * sizeof(BvhNode4));
+    std::memcpy(*tris_out, r.tris.data(), r.tris.size() * sizeof(BvhTri));
+    if (max_depth) *max_depth = r.max_depth;
+    if (max_e12) *max_e12 = r.max_e12;
+    return RBRT_OK;
+}
 
 // Diagnostic: the GPU builder alone (bvh_device.hip), results copied back in the layout of rbrt_hip_bvh_build_host.
 // *built = 0 when the builder declined the mesh (tiny, or a tree beyond the depth budget); nothing is returned then.

@@ -68,7 +68,8 @@ struct Prim {
     Box box;
     float c[3];
     float e12;
-    uint32_t idx;
+    uint32_t idx;  // reference index (what the leaves are ordered by, what the scan's tie rule compares)
+    uint32_t src;  // where the triangle's nine values are: position in the mesh's SoA arrays, or in the record array
 };
 
 struct ChildInfo {
@@ -90,7 +91,10 @@ constexpr int32_t kTaskRefBase = INT32_MIN + 1;  // child refs kTaskRefBase + k 
 inline bool is_task_ref(int32_t r) { return r != kNoChild && r < -(int32_t(1) << 30) - 1; }
 
 struct Builder {
-    const rbrt_mesh_t& m;
+    const rbrt_mesh_t* m = nullptr;  // the source: a mesh's SoA arrays ...
+    const BvhTri* recs = nullptr;    // ... or n_recs triangle records in any order
+    size_t n_recs = 0;
+    BvhBuildOptions opt;
     std::vector<Prim> prims;
     std::vector<Node2> nodes2;
     BvhBuildResult out;
@@ -103,14 +107,19 @@ struct Builder {
     std::vector<Task> tasks;
     size_t task_grain = 0;  // 0: single-threaded build, no tasks
 
-    explicit Builder(const rbrt_mesh_t& mesh) : m(mesh) {}
+    bool cancelled() const { return opt.cancel && opt.cancel->load(std::memory_order_relaxed); }
 
-    BvhTri make_tri(uint32_t i) const {
+    BvhTri make_tri(const Prim& p) const {
         BvhTri t;
-        t.v0[0] = m.v0x[i], t.v0[1] = m.v0y[i], t.v0[2] = m.v0z[i];
-        t.e1x = m.e1x[i], t.e1yz[0] = m.e1y[i], t.e1yz[1] = m.e1z[i];
-        t.e2xy[0] = m.e2x[i], t.e2xy[1] = m.e2y[i], t.e2z = m.e2z[i];
-        t.index = i;
+        if (recs) {
+            t = recs[p.src];
+        } else {
+            const uint32_t i = p.src;
+            t.v0[0] = m->v0x[i], t.v0[1] = m->v0y[i], t.v0[2] = m->v0z[i];
+            t.e1x = m->e1x[i], t.e1yz[0] = m->e1y[i], t.e1yz[1] = m->e1z[i];
+            t.e2xy[0] = m->e2x[i], t.e2xy[1] = m->e2y[i], t.e2z = m->e2z[i];
+        }
+        t.index = p.idx;
         t.pad[0] = t.pad[1] = 0;
         return t;
     }
@@ -127,7 +136,7 @@ struct Builder {
         // deterministic order inside a leaf: ascending reference index
         std::sort(prims.begin() + b, prims.begin() + e,
                   [](const Prim& x, const Prim& y) { return x.idx < y.idx; });
-        for (size_t i = b; i < e; ++i) sk.tris.push_back(make_tri(prims[i].idx));
+        for (size_t i = b; i < e; ++i) sk.tris.push_back(make_tri(prims[i]));
         ++sk.n_leaves;
         return ChildInfo{~int32_t((first << kLeafBits) | (count - 1)), box, max_e12};
     }
@@ -154,6 +163,7 @@ struct Builder {
             max_e12 = std::max(max_e12, prims[i].e12);
         }
         if (depth > kMaxInnerDepth || count <= 1) return make_leaf(sk, b, e, box, max_e12);
+        if (cancelled()) return make_leaf(sk, b, b + 1, box, max_e12);  // (memory-safe nonsense: the result is thrown away)
 
         // binned SAH over the three axes
         const float parent_area = box.half_area();
@@ -283,6 +293,7 @@ struct Builder {
 
     ChildInfo build_tree() {
         unsigned n_threads = std::thread::hardware_concurrency();
+        if (opt.max_threads != 0) n_threads = std::min(n_threads, opt.max_threads);
         if (const char* e = std::getenv("RBRT_BVH_THREADS")) n_threads = unsigned(std::max(1, std::atoi(e)));
         n_threads = std::min(n_threads, 16u);
         if (n_threads <= 1 || prims.size() < 32768) {
@@ -329,14 +340,22 @@ struct Builder {
     }
 
     void run() {
-        const uint32_t n_tested = (m.n_total / 8u) * 8u;  // triangle.rs:166-167
+        const uint32_t n_tested = recs ? uint32_t(n_recs) : (m->n_total / 8u) * 8u;  // triangle.rs:166-167
         prims.reserve(n_tested);
         for (uint32_t i = 0; i < n_tested; ++i) {
-            if (m.is_padding && m.is_padding[i]) continue;  // triangle.rs:400
+            if (recs ? recs[i].index == 0xFFFFFFFFu : (m->is_padding && m->is_padding[i])) continue;  // triangle.rs:400
             Prim p;
-            float v0[3] = {m.v0x[i], m.v0y[i], m.v0z[i]};
-            float e1[3] = {m.e1x[i], m.e1y[i], m.e1z[i]};
-            float e2[3] = {m.e2x[i], m.e2y[i], m.e2z[i]};
+            float v0[3], e1[3], e2[3];
+            if (recs) {
+                const BvhTri& r = recs[i];
+                v0[0] = r.v0[0], v0[1] = r.v0[1], v0[2] = r.v0[2];
+                e1[0] = r.e1x, e1[1] = r.e1yz[0], e1[2] = r.e1yz[1];
+                e2[0] = r.e2xy[0], e2[1] = r.e2xy[1], e2[2] = r.e2z;
+            } else {
+                v0[0] = m->v0x[i], v0[1] = m->v0y[i], v0[2] = m->v0z[i];
+                e1[0] = m->e1x[i], e1[1] = m->e1y[i], e1[2] = m->e1z[i];
+                e2[0] = m->e2x[i], e2[1] = m->e2y[i], e2[2] = m->e2z[i];
+            }
             // Non-finite v0/e1/e2 can never pass the ordered compares of triangle.rs:198-241
             // (a, u, v or t comes out inf/NaN), so such a triangle is not indexed.
             bool finite = true;
@@ -355,7 +374,8 @@ struct Builder {
             float l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
             float l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
             p.e12 = l1 * l2;
-            p.idx = i;
+            p.idx = recs ? recs[i].index : i;
+            p.src = i;
             prims.push_back(p);
         }
         out.n_indexed = uint32_t(prims.size());
@@ -374,6 +394,10 @@ struct Builder {
         }
         prims.clear();
         prims.shrink_to_fit();
+        if (cancelled()) {
+            out.cancelled = true;
+            return;
+        }
         out.nodes.reserve(nodes2.size() / 2 + 2);
         collapse(0, 0);
         out.stack_need = 3u * (out.max_depth + 1u) + 1u;
@@ -491,8 +515,17 @@ struct Builder {
 
 }  // namespace
 
-BvhBuildResult build_bvh(const rbrt_mesh_t& mesh) {
-    Builder b(mesh);
+BvhBuildResult build_bvh(const rbrt_mesh_t& mesh, const BvhBuildOptions& opt) {
+    Builder b;
+    b.m = &mesh, b.opt = opt;
+    b.run();
+    return std::move(b.out);
+}
+
+BvhBuildResult build_bvh_from_records(const BvhTri* recs, size_t n, const BvhBuildOptions& opt) {
+    Builder b;
+    static const BvhTri none{};
+    b.recs = recs ? recs : &none, b.n_recs = recs ? n : 0, b.opt = opt;
     b.run();
     return std::move(b.out);
 }

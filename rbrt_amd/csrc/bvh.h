@@ -10,6 +10,8 @@
 //     inflation of the node boxes that covers the fp32 error of the Moller-Trumbore test
 //     (DESIGN.md "Why the BVH cannot change the answer").
 #pragma once
+#include <atomic>
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -25,9 +27,21 @@ struct BvhBuildResult {
     uint32_t stack_need = 1;  // traversal stack entries that can ever be live: 3 per level + 1
     uint32_t n_indexed = 0;   // triangles in the BVH
     uint32_t n_leaves = 0;
+    bool cancelled = false;   // BvhBuildOptions::cancel was raised: the arrays are not a tree of the mesh
+};
+
+struct BvhBuildOptions {
+    unsigned max_threads = 0;                    // 0: every hardware thread (at most 16; $RBRT_BVH_THREADS overrides)
+    const std::atomic<bool>* cancel = nullptr;  // polled while building: a build nobody waits for any more ends early
 };
 
 // Builds over the mesh's SoA arrays (host pointers).
-BvhBuildResult build_bvh(const rbrt_mesh_t& mesh);
+BvhBuildResult build_bvh(const rbrt_mesh_t& mesh, const BvhBuildOptions& opt = BvhBuildOptions());
+
+// Builds over n triangle records in ANY order (`index` = the triangle's position in the reference arrays; records whose
+// index is 0xFFFFFFFF are skipped): for the indexed records of a mesh -- e.g. read back from the device builder's output --
+// this is, array for array, the tree build_bvh gives for that mesh (every decision of the build is a function of SETS of
+// triangles; leaves are ordered by reference index).
+BvhBuildResult build_bvh_from_records(const BvhTri* recs, size_t n, const BvhBuildOptions& opt = BvhBuildOptions());
 
 }  // namespace rbrt

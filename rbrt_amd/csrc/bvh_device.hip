@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "bvh_device.h"
 #include "device_types.h"
@@ -459,14 +460,36 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
     QItem* queue[2] = {nullptr, nullptr};
     void *tmp = nullptr, *scan_tmp = nullptr;
     BvhNode4* nodes = nullptr;
+    // ONE allocation for all the scratch (two dozen hipMalloc / hipFree pairs cost more than the kernels of a 70k-triangle
+    // build): sized for n_valid = n_tested, carved up by a bump pointer; the node array, which outlives the build, apart.
+    char* arena = nullptr;
+    size_t arena_used = 0, arena_bytes = 0;
     auto cleanup = [&]() {
-        (void)hipFree(w), (void)hipFree(boxes), (void)hipFree(keys), (void)hipFree(keys2), (void)hipFree(vals), (void)hipFree(sorted);
-        (void)hipFree(order), (void)hipFree(arrived), (void)hipFree(cl[0]), (void)hipFree(cl[1]), (void)hipFree(cl_tmp), (void)hipFree(nn);
-        (void)hipFree(valid), (void)hipFree(pos), (void)hipFree(d_m), (void)hipFree(t.nbox), (void)hipFree(t.left), (void)hipFree(t.right);
-        (void)hipFree(t.size), (void)hipFree(t.parent), (void)hipFree(queue[0]), (void)hipFree(queue[1]), (void)hipFree(tmp), (void)hipFree(scan_tmp);
+        (void)hipFree(arena);
         if (!res->ok) (void)hipFree(nodes);
     };
-    auto alloc = [&](auto** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(**p)); };
+    size_t sort_bytes = 0, scan_bytes = 0;
+    {
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys2, vals, sorted, n_total, 0, 64, stream);
+        if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, scan_bytes, valid, pos, 0u, n_tested, rocprim::plus<uint32_t>(), stream);
+        if (e != hipSuccess) return e;
+    }
+    {
+        const size_t n_ids_max = 2u * size_t(n_tested);
+        const auto r = [](size_t b) { return (b + 255u) & ~size_t(255); };
+        arena_bytes = r(sizeof(Work)) + r(size_t(n_total) * 8u * sizeof(float)) + 2u * r(size_t(n_total) * sizeof(uint64_t)) +
+                      2u * r(size_t(n_total) * sizeof(uint32_t)) + r(sort_bytes + 16u) + r(scan_bytes + 16u) +
+                      r(n_ids_max * 8u * sizeof(float)) + 5u * r(n_ids_max * sizeof(uint32_t)) + 7u * r(size_t(n_tested) * sizeof(uint32_t)) +
+                      2u * r(size_t(node_cap) * sizeof(QItem)) + r(sizeof(uint32_t)) + 4096u;
+    }
+    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&arena), arena_bytes));
+    auto alloc = [&](auto** p, size_t count) {
+        const size_t bytes = (std::max<size_t>(count, 1) * sizeof(**p) + 255u) & ~size_t(255);
+        if (arena_used + bytes > arena_bytes) return hipErrorOutOfMemory;  // (cannot happen: the sizes above bound every request)
+        *p = reinterpret_cast<std::remove_reference_t<decltype(*p)>>(arena + arena_used);
+        arena_used += bytes;
+        return hipSuccess;
+    };
     DEV_TRY(alloc(&w, 1));
     DEV_TRY(alloc(&boxes, size_t(n_total) * 8u));
     DEV_TRY(alloc(&keys, n_total));
@@ -476,10 +499,12 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
     hipLaunchKernelGGL(init_work, dim3(1), dim3(1), 0, stream, w);
     hipLaunchKernelGGL(prim_setup, dim3(blocks(n_total)), dim3(kTpb), 0, stream, m, n_total, n_tested, boxes, w);
     hipLaunchKernelGGL(morton_keys, dim3(blocks(n_total)), dim3(kTpb), 0, stream, boxes, n_total, w, keys, vals);
-    size_t tmp_bytes = 0;
-    DEV_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, sorted, n_total, 0, 64, stream));
-    DEV_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    DEV_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, sorted, n_total, 0, 64, stream));
+    {
+        char* tp = nullptr;
+        DEV_TRY(alloc(&tp, sort_bytes + 16u));
+        tmp = tp;
+    }
+    DEV_TRY(rocprim::radix_sort_pairs(tmp, sort_bytes, keys, keys2, vals, sorted, n_total, 0, 64, stream));
     // n_valid decides the sizes of everything below
     Work hw;
     DEV_TRY(hipMemcpyAsync(&hw, w, sizeof(hw), hipMemcpyDeviceToHost, stream));
@@ -498,7 +523,7 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
     DEV_TRY(alloc(&order, n));
     DEV_TRY(alloc(&queue[0], node_cap));
     DEV_TRY(alloc(&queue[1], node_cap));
-    DEV_TRY(alloc(&nodes, node_cap));
+    DEV_TRY(hipMalloc(reinterpret_cast<void**>(&nodes), size_t(node_cap) * sizeof(BvhNode4)));
     hipLaunchKernelGGL(init_leaves, dim3(blocks(n)), dim3(kTpb), 0, stream, w, sorted, boxes, t);
     bool built = false;
     if (algo == 0) {  // PLOC
@@ -509,9 +534,11 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
         DEV_TRY(alloc(&valid, n));
         DEV_TRY(alloc(&pos, n));
         DEV_TRY(alloc(&d_m, 1));
-        size_t scan_bytes = 0;
-        DEV_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, valid, pos, 0u, n, rocprim::plus<uint32_t>(), stream));
-        DEV_TRY(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 16));
+        {
+            char* tp = nullptr;
+            DEV_TRY(alloc(&tp, scan_bytes + 16u));
+            scan_tmp = tp;
+        }
         hipLaunchKernelGGL(iota_kernel, dim3(blocks(n)), dim3(kTpb), 0, stream, cl[0], n);
         uint32_t mcur = n, radius = uint32_t(kPlocRadius);
         const char* lab = std::getenv("RBRT_HIP_LAB");  // (a lab knob: include/rbrt_hip_debug.h)

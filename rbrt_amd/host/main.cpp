@@ -3,6 +3,7 @@
 //   -c/--config scenes/example_scene.yaml   -s/--samples 5   -h/--help   -V/--version
 // plus, not in the reference: --seed N (default 1), --gpus N (default 1), --gather host|rccl, --oversubscribe,
 // --pass-samples N, --checkpoint FILE, --checkpoint-every N, --report FILE (machine-readable timing of the run).
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -188,8 +189,17 @@ int main(int argc, char** argv) {
             str("bvh_builder", rep.builder), num("bvh_nodes", double(rep.bvh_nodes), "%.0f"), num("bvh_triangles", double(rep.bvh_triangles), "%.0f");
             num("passes", rep.passes, "%.0f"), num("pass_samples", rep.pass_spp, "%.0f");
             num("checkpoints_written", rep.checkpoints_written, "%.0f"), num("resumed_from_sample", rep.resumed_from_sample, "%.0f");
-            num("parse_s", secs(t0, t1)), num("prep_s", secs(t1, t2)), num("upload_build_s", rep.upload_build_s);
-            num("render_s", rep.render_s), num("gather_s", rep.gather_s), num("encode_s", secs(t3, t4)), num("total_s", secs(t0, t4));
+            // where the run's time went; the parts add up to total_s (other_s is what none of them covers: thread start,
+            // checkpoint look-up, the report itself)
+            const rbrt::LoadTimes lt = rbrt::load_times();
+            const double parse_s = secs(t0, t1), prep_s = std::max(0.0, secs(t1, t2) - lt.obj_load_s), encode_s = secs(t3, t4), total_s = secs(t0, t4);
+            const double named = parse_s + lt.obj_load_s + prep_s + rep.hip_init_s + rep.upload_s + rep.bvh_build_s + rep.lanes_s + rep.buffers_s +
+                                 rep.render_s + rep.gather_s + rep.release_s + encode_s;
+            num("parse_s", parse_s), num("obj_load_s", lt.obj_load_s), num("prep_s", prep_s), num("hip_init_s", rep.hip_init_s);
+            num("upload_s", rep.upload_s), num("bvh_build_s", rep.bvh_build_s), num("lanes_s", rep.lanes_s), num("buffers_s", rep.buffers_s);
+            num("render_s", rep.render_s), num("gather_s", rep.gather_s), num("release_s", rep.release_s), num("encode_s", encode_s);
+            num("other_s", std::max(0.0, total_s - named)), num("total_s", total_s);
+            num("upload_build_s", rep.upload_build_s);  // (= hip_init_s' library part + upload_s + bvh_build_s + lanes_s + buffers_s: the name earlier reports used)
             num("mray_samples_per_s", rep.render_s > 0 ? rendered / rep.render_s / 1e6 : 0.0, "%.3f");
             js.resize(js.size() - 2);
             js += "}\n";

@@ -167,6 +167,12 @@ struct Scene {
     AbiView to_abi() const;
 };
 Scene create_scene_from_scene_blueprint(const SceneBlueprint& bp);
+// Where create_scene_from_scene_blueprint spent its time, summed over the meshes of the calling thread's scenes (--report).
+struct LoadTimes {
+    double obj_load_s = 0;   // reading and parsing the .obj files, transforming the vertices (mesh.rs:78-121)
+    double soa_prep_s = 0;   // edges, normals, padding, SoA arrays, bounding box (mesh.rs:41-74, :123-181)
+};
+LoadTimes& load_times();
 
 // ---- image + render --------------------------------------------------------------------------------
 struct ImageBuffer {
@@ -180,7 +186,13 @@ void write_png(const std::string& path, const uint8_t* rgb, uint32_t width, uint
 // What render_scene measured (wall clock; with several GPUs the slowest rank's figure). The reference prints only
 // "Starting rendering..." and a progress line (lib.rs:80,105-110); a 4 ms render needs more than that to be understood.
 struct RenderReport {
-    double upload_build_s = 0;   // scene upload + BVH build (rbrt_hip_scene_create) + buffers
+    double upload_build_s = 0;   // rbrt_hip_scene_create + the render's buffers, the slowest rank's (= the four below + buffers_s)
+    double hip_init_s = 0;       // the HIP runtime's start-up (the process's first HIP call) + device selection
+    double upload_s = 0;         // scene arrays to the device
+    double bvh_build_s = 0;      // BVH construction (whichever builder made the first trees)
+    double lanes_s = 0;          // the library's streams, events, per-wave scratch, device code
+    double buffers_s = 0;        // this host's stream and image buffers
+    double release_s = 0;        // buffers and scene released
     double render_s = 0;         // all passes, incl. checkpoint writes
     double gather_s = 0;         // image to host memory (and the merge of the ranks' tiles)
     uint32_t passes = 0, pass_spp = 0, checkpoints_written = 0, resumed_from_sample = 0;

@@ -32,6 +32,7 @@
 #include <thread>
 
 #include "rbrt.hpp"
+#include "../../include/rbrt_hip_debug.h"
 
 namespace rbrt {
 namespace {
@@ -152,7 +153,9 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     img.radiance.assign(n, 0.0f);
     if (num_samples == 0) throw Error("the number of samples must be at least 1");
 
-    const int n_dev = rbrt_hip_device_count();
+    const auto t_hip0 = std::chrono::steady_clock::now();
+    const int n_dev = rbrt_hip_device_count();  // (the process's first HIP call: the runtime starts here)
+    const double hip_start_s = seconds_since(t_hip0);
     if (n_dev < 1) throw Error(std::string("no HIP device: ") + rbrt_hip_last_error());
     const int world = cfg.n_gpus < 1 ? 1 : cfg.n_gpus;
     if (world > n_dev && !cfg.oversubscribe)
@@ -257,7 +260,8 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     rep.pass_spp = pass_spp;
     rep.gather = world > 1 ? (use_rccl ? "rccl" : "host") : "none";
     if (!rccl_note.empty()) rep.gather = "host (rccl was asked for: " + rccl_note + ")";
-    std::vector<double> t_setup(world, 0.0), t_render(world, 0.0), t_gather(world, 0.0);
+    std::vector<double> t_setup(world, 0.0), t_render(world, 0.0), t_gather(world, 0.0), t_release(world, 0.0);
+    std::vector<rbrt_hip_call_times_t> t_create(world);
 
     auto worker = [&](int rank) {
         rbrt_hip_scene_t* hs = nullptr;
@@ -286,6 +290,8 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
         const size_t npix = world > 1 ? rbrt_hip_packed_pixels(img.width, img.height, o.tile_rank, o.tile_world)
                                       : size_t(img.width) * img.height;
         if (rbrt_hip_scene_create(&view.scene, dev, &hs) != RBRT_OK) fail(rbrt_hip_last_error());
+        std::memset(&t_create[rank], 0, sizeof(t_create[rank]));
+        if (hs) (void)rbrt_hip_scene_create_times(hs, &t_create[rank]);
         // (every pass is followed by a synchronisation here: only the sample batches INSIDE a pass overlap, on three lanes;
         // the library's default of eight is for streams of frames)
         if (hs) (void)rbrt_hip_scene_set_pipeline(hs, 3);
@@ -454,6 +460,7 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
             host_gather();
         }
         t_gather[rank] = seconds_since(t_g);
+        const auto t_rel = std::chrono::steady_clock::now();
         if (d_acc) (void)hipFree(d_acc);
         if (d_rad) (void)hipFree(d_rad);
         if (d_rgb) (void)hipFree(d_rgb);
@@ -461,6 +468,7 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
         if (rank == 0 && d_slots) (void)hipFree(d_slots);
         if (stream) (void)hipStreamDestroy(stream);
         rbrt_hip_scene_destroy(hs);
+        t_release[rank] = seconds_since(t_rel);
     };
     std::vector<std::thread> threads;
     for (int r = 1; r < world; ++r) threads.emplace_back(worker, r);
@@ -477,7 +485,15 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
     if (!cfg.checkpoint_path.empty()) std::remove(cfg.checkpoint_path.c_str());  // (only reached when the render is complete)
     if (!cfg.quiet) std::printf("\rRendering 100%% complete!\n");
     rep.resumed_from_sample = start_sample;
-    rep.upload_build_s = *std::max_element(t_setup.begin(), t_setup.end());
+    {   // the slowest rank's set-up, split (the parts of one rank, so that they add up)
+        const size_t slow = size_t(std::max_element(t_setup.begin(), t_setup.end()) - t_setup.begin());
+        const rbrt_hip_call_times_t& ct = t_create[slow];
+        rep.upload_build_s = t_setup[slow];
+        rep.hip_init_s = hip_start_s + ct.hip_init_s, rep.upload_s = ct.upload_s, rep.bvh_build_s = ct.bvh_build_s;
+        rep.lanes_s = ct.lanes_s + std::max(0.0, ct.create_s - ct.hip_init_s - ct.upload_s - ct.bvh_build_s - ct.lanes_s);
+        rep.buffers_s = std::max(0.0, t_setup[slow] - ct.create_s);
+        rep.release_s = *std::max_element(t_release.begin(), t_release.end());
+    }
     rep.render_s = *std::max_element(t_render.begin(), t_render.end());
     rep.gather_s = *std::max_element(t_gather.begin(), t_gather.end());
     if (cfg.report) *cfg.report = rep;

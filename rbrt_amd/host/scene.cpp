@@ -2,6 +2,7 @@
 // the YAML blueprints, the material factory, the .obj loader and the SoA mesh conversion with its
 // padding rule. Arithmetic keeps the reference's f32 evaluation order: what is computed here is
 // the exact triangle set and camera the kernel sees.
+#include <chrono>
 #include <algorithm>
 #include <array>
 #include <cctype>
@@ -355,9 +356,21 @@ TriangleMesh TriangleMesh::from_triangles(std::vector<std::array<Vec3, 3>> pre_v
     return m;
 }
 
+LoadTimes& load_times() {
+    thread_local LoadTimes t;
+    return t;
+}
+
 TriangleMesh TriangleMesh::create(const std::string& filepath, Vec3 translation, Vec3 rotation, float scale,
                                   Material material) {
-    return from_triangles(load_mesh_vertices_from_file(filepath, translation, rotation, scale), material);
+    const auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
+    auto tris = load_mesh_vertices_from_file(filepath, translation, rotation, scale);
+    const auto t1 = now();
+    TriangleMesh m = from_triangles(std::move(tris), material);
+    load_times().obj_load_s += std::chrono::duration<double>(t1 - t0).count();
+    load_times().soa_prep_s += std::chrono::duration<double>(now() - t1).count();
+    return m;
 }
 
 rbrt_mesh_t TriangleMesh::to_abi() const {
