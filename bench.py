@@ -223,6 +223,11 @@ def parse_args():
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="WORLD",
                     help="single process: time only rank 0's share of a WORLD-GPU run (its tiles, no gather); a "
                          "scaling estimate for one-GPU boxes, not a benchmark result")
+    ap.add_argument("--emulate-rank", type=int, default=0, metavar="R", help="with --emulate-rank-of WORLD: the rank whose share is timed (default 0)")
+    ap.add_argument("--emulate-all", default="", metavar="WORLDS",
+                    help="single process, e.g. '2,4,8': time EVERY rank's share of a WORLD-GPU run, one after the other on one scene (its "
+                         "tiles, no gather), and print one JSON record with per-rank ms per step, their max and mean, and predicted_scaling = "
+                         "the whole frame's ms / the slowest rank's -- the step of an N-GPU run is the MAX over its ranks; not a benchmark line")
     ap.add_argument("--gather", choices=("auto", "rccl", "ipc"), default="auto",
                     help="N > 1: how rank 0 gets the other ranks' tiles. rccl: dist.gather (copy KERNELS, which need wave slots "
                          "beside the persistent trace launches); ipc: rank 0 maps the peers' buffers (HIP IPC) and pulls them with "
@@ -338,7 +343,9 @@ def main():
     refine_state, refine_s = scene.refine_wait(300.0)
     setup_total_s = time.perf_counter() - t0
     emu = args.emulate_rank_of if world == 1 and args.emulate_rank_of > 1 else 0
-    opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=emu if emu else world)
+    if emu and not 0 <= args.emulate_rank < emu:
+        raise SystemExit("--emulate-rank must be a rank of --emulate-rank-of")
+    opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=args.emulate_rank if emu else rank, tile_world=emu if emu else world)
     if os.environ.get("RBRT_BENCH_MAX_DEPTH"):  # diagnosis only (changes the image)
         opts.max_depth = int(os.environ["RBRT_BENCH_MAX_DEPTH"])
     stream = torch.cuda.current_stream().cuda_stream
@@ -482,7 +489,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- counting pass (untimed): the work counters behind the algorithmic-bytes figure ----------
-    stats_opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=rank, tile_world=emu if emu else world,
+    stats_opts = abi.default_opts(spp=spp, seed=args.seed, tile_rank=args.emulate_rank if emu else rank, tile_world=emu if emu else world,
                                   flags=abi.FLAG_COLLECT_STATS)
     n_out = rbrt_amd.packed_pixels(W, H, rank, world) * 3 if world > 1 else W * H * 3
     scratch = torch.empty(n_out, dtype=torch.float32, device=dev)
@@ -537,6 +544,33 @@ def main():
             step(True)
         fence()
     guarded(prime_pipeline)
+    if world == 1 and args.emulate_all:
+        # Every rank's share, not rank 0's: the step of an N-GPU run is the MAX over its ranks, and with tiles dealt round-robin
+        # over the row-major tile index a rank's tiles are fixed columns of the image, over which the mesh and the glass sphere
+        # are not spread evenly (the reference balances by work stealing, lib.rs:84-88).
+        worlds = [int(x) for x in args.emulate_all.split(",") if x.strip()]
+        table = {}
+        whole = None
+        for wd in [1] + [w_ for w_ in worlds if w_ > 1]:
+            per_rank = []
+            for r in range(wd):
+                opts.tile_rank, opts.tile_world = r, wd
+                el = timed_leg(args.warmup, args.steps, True)[0]
+                per_rank.append(round(el / args.steps * 1e3, 4))
+            if wd == 1:
+                whole = per_rank[0]
+                continue
+            table[str(wd)] = {"ms_per_rank": per_rank, "max_ms": max(per_rank), "mean_ms": round(sum(per_rank) / wd, 4),
+                              "max_over_mean": round(max(per_rank) / (sum(per_rank) / wd), 4),
+                              "predicted_scaling": round(whole / max(per_rank), 3),
+                              "local_tiles": [rbrt_amd.packed_pixels(W, H, r, wd) // 64 for r in range(wd)]}
+        opts.tile_rank, opts.tile_world = 0, 1
+        scene.check()
+        print(json.dumps({"what": "every rank's share of an N-GPU run timed on ONE GPU, one rank after the other (no gather): ms per step of "
+                                  f"{args.steps} pipelined steps, every step a new camera; predicted_scaling = whole frame / slowest rank",
+                          "workload": f"{args.triangles}-triangle {'stand-in' if args.mesh == 'smooth' else 'ROUGH stand-in'}, {W}x{H}, {spp} spp, config {args.config}",
+                          "whole_frame_ms": whole, "worlds": table, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return
     # ---- N > 1, --gather auto: both gathers for a few untimed steps each, the faster one is used from here on ----
     gather_probe = None
     if world > 1 and args.gather == "auto" and ipc["ok"]:

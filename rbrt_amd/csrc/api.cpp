@@ -639,14 +639,21 @@ struct CreateHint {
 };
 
 // Which builder makes a mesh's FIRST tree: the one that costs the call less. Measured on an MI355X box (tools/create_sweep.py,
-// profiles/r05_create_sweep.txt): the host builder takes kHostBuildSecPerTri per entry on the box's cores, the device builder
-// kDeviceBuildSec0 + kDeviceBuildSecPerTri per entry (uploads included); frames through the device's tree take
-// kDeviceTreeSlowdown longer. A handle starts with the cheaper build and, where that was the device's, gets the host's tree
+// profiles/r05_create_sweep.txt; the table below); frames through the device's tree take kDeviceTreeSlowdown longer
+// (2.5-3.5 % measured). A handle starts with the cheaper build and, where that was the device's, gets the host's tree
 // in the background (struct Refine); a one-shot call adds what the slower frames of ITS render would cost.
-constexpr double kHostBuildSecPerTri = 1.1e-6, kDeviceBuildSec0 = 1.5e-3, kDeviceBuildSecPerTri = 1.2e-8, kDeviceTreeSlowdown = 0.04;
+//   entries        500   2000   8000   32000   69451   262144   871414
+//   host, ms      0.22   0.68   2.68   11.3     8.2     39.5    143.5    (build + upload; threaded from 32768 entries, 16 threads)
+//   device, ms    1.18   1.56   1.91    2.55    3.16     4.60     6.57   (upload + build: a dozen dependent stages, then ~25 rounds)
+constexpr double kHostBuildSecPerTri = 0.33e-6, kHostThreadedFrom = 32768.0, kDeviceBuildSec0 = 1.0e-3, kDeviceBuildSecPerDoubling = 0.28e-3,
+                 kDeviceBuildSecPerTri = 3.0e-9, kDeviceTreeSlowdown = 0.04;
 bool device_builder_is_cheaper(uint32_t n_total, const CreateHint& hint) {
-    const double host_s = kHostBuildSecPerTri * n_total;
-    const double device_s = kDeviceBuildSec0 + kDeviceBuildSecPerTri * n_total + (hint.one_shot ? kDeviceTreeSlowdown * hint.render_s_est : 0.0);
+    const double n = double(n_total);
+    const double threads = double(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+    // (the top of the host's tree is built by one thread: 16 threads halve the time, they do not divide it by 16)
+    const double host_s = kHostBuildSecPerTri * n * (n < kHostThreadedFrom ? 1.0 : 0.35 + 1.3 / threads);
+    const double device_s = kDeviceBuildSec0 + kDeviceBuildSecPerDoubling * std::log2(std::max(n, 500.0) / 500.0) + kDeviceBuildSecPerTri * n +
+                            (hint.one_shot ? kDeviceTreeSlowdown * hint.render_s_est : 0.0);
     return n_total >= 8u && device_s < host_s;
 }
 
@@ -838,6 +845,7 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
     }
     std::vector<uint8_t> device_built(scene->n_meshes, 0);
     std::vector<uint32_t> n_valid_of(scene->n_meshes, 0);
+    const double t_meshes0 = now_s();
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         const rbrt_mesh_t& m = scene->meshes[i];
         put_mat(n_elem + i, m.mat);
@@ -915,6 +923,7 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
         dm.radius = std::sqrt(diag2) * 1.0001f;
         if (!std::isfinite(dm.radius)) dm.radius = std::numeric_limits<float>::max();
     }
+    const double t_meshes1 = now_s();
     if (int rc = upload(s, spheres, &s->d_spheres)) return bail(rc);
     if (scene->n_triangles != 0) {
         if (int rc = upload(s, etris, &s->d_elem_tris)) return bail(rc);
@@ -968,6 +977,10 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
         // lanes up front: rbrt_hip_render_device then never allocates lanes (which synchronises the device); a one-shot
         // call makes the lanes its batches will use (rbrt_hip_render)
         const double t_lanes0 = now_s();
+        if (lab_env("RBRT_TRACE_CREATE"))
+            std::fprintf(stderr, "[rbrt_hip] scene_create: device %.3f ms, record array %.3f, meshes %.3f (upload %.3f, build %.3f), tables + properties %.3f\n",
+                         s->create_times.hip_init_s * 1e3, (t_meshes0 - t_create0 - s->create_times.hip_init_s) * 1e3, (t_meshes1 - t_meshes0) * 1e3,
+                         t_upload * 1e3, t_build * 1e3, (t_lanes0 - t_meshes1) * 1e3);
         if (int rc = ensure_lanes(s, std::max(hint.one_shot ? 1u : kLanesAtCreate, s->pipeline))) return bail(rc);
         // (the library's device code, loaded now instead of inside the first render)
         if (launch_code_load(nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess)

@@ -321,6 +321,7 @@ struct Builder {
         worker();
         for (auto& th : pool) th.join();
         task_grain = 0;
+        if (cancelled()) return top_root;  // (what a cancelled build leaves is not a tree: nothing of it is walked, run() drops it)
         nodes2.reserve(prims.size() / 2 + 2);
         out.tris.reserve(prims.size() + 2);
         return splice(top, top_root.ref, top_root.box, top_root.max_e12);
@@ -385,6 +386,10 @@ struct Builder {
             set_node(nodes2, 0, d0, d0);
         } else {
             ChildInfo root = build_tree();
+            if (cancelled()) {
+                out.cancelled = true;
+                return;
+            }
             if (root.ref < 0) {  // whole mesh fits one leaf
                 nodes2.emplace_back();
                 ChildInfo d = make_dummy();

@@ -12,6 +12,10 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <cstring>
 #include "../../rbrt_amd/csrc/bvh.h"
 #include "../../rbrt_amd/host/rbrt.hpp"
 
@@ -195,6 +199,32 @@ int main(int argc, char** argv) {
         std::vector<std::array<rbrt::Vec3, 3>> same(5000, {rbrt::Vec3(0, 0, -5), rbrt::Vec3(1, 0, -5), rbrt::Vec3(0, 1, -5)});
         rbrt::TriangleMesh tm2 = rbrt::TriangleMesh::from_triangles(same, rbrt::Material::metal(rbrt::Vec3(1, 1, 1), 0.1f));
         check_bvh(tm2.to_abi());
+        // ---- a build from records in another order (what a scene handle's background thread runs), and cancelling it ----
+        const rbrt::BvhBuildResult ref = rbrt::build_bvh(m);
+        std::vector<rbrt::BvhTri> recs(ref.tris.rbegin(), ref.tris.rend());
+        const rbrt::BvhBuildResult again = rbrt::build_bvh_from_records(recs.data(), recs.size());
+        CHECK(again.nodes.size() == ref.nodes.size() && again.tris.size() == ref.tris.size());
+        CHECK(!std::memcmp(again.nodes.data(), ref.nodes.data(), ref.nodes.size() * sizeof(rbrt::BvhNode4)));
+        CHECK(!std::memcmp(again.tris.data(), ref.tris.data(), ref.tris.size() * sizeof(rbrt::BvhTri)));
+        // raised at every stage of the build (before it, inside the single-threaded top, among the workers, after them):
+        // the build returns, flagged, without touching anything out of bounds; an unraised flag changes nothing
+        for (int delay_us : {0, 50, 200, 1000, 3000, 8000, 20000, 1000000}) {
+            std::atomic<bool> cancel{false};
+            rbrt::BvhBuildOptions opt;
+            opt.cancel = &cancel;
+            std::thread raiser([&] {
+                std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
+                if (delay_us < 1000000) cancel.store(true);
+            });
+            if (delay_us == 1000000) raiser.join();  // (never raised)
+            const rbrt::BvhBuildResult r = rbrt::build_bvh_from_records(recs.data(), recs.size(), opt);
+            if (raiser.joinable()) raiser.join();
+            if (!r.cancelled) {
+                CHECK(r.nodes.size() == ref.nodes.size() && !std::memcmp(r.nodes.data(), ref.nodes.data(), ref.nodes.size() * sizeof(rbrt::BvhNode4)));
+            }
+            CHECK(delay_us != 0 || r.cancelled);
+            CHECK(delay_us != 1000000 || !r.cancelled);
+        }
     }
     if (g_failed) {
         std::fprintf(stderr, "host_selftest: %d check(s) failed\n", g_failed);

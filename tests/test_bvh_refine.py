@@ -54,7 +54,7 @@ def _rays(sc, rng, n=20000):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_tris", [3003, 20000])
+@pytest.mark.parametrize("n_tris", [9003, 20000])
 def test_a_handle_renders_the_oracle_image_through_its_first_tree_and_through_the_adopted_one(hip, oracle, monkeypatch, n_tris):
     import torch
     monkeypatch.delenv("RBRT_BVH_BUILDER", raising=False)
