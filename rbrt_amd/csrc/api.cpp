@@ -23,7 +23,7 @@
 namespace rbrt {
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats, bool share,
                                    hipStream_t stream);
-size_t megakernel_gseq_bytes(uint32_t n_waves);
+size_t megakernel_gseq_bytes(uint32_t n_waves, uint32_t pool);
 size_t megakernel_gstack_bytes(uint32_t n_waves);
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes, uint32_t n_elem_tris);
 int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes);
@@ -507,20 +507,16 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
     while (s->lanes.size() < depth) {
         rbrt_hip_scene::Lane L;
         void* p = nullptr;
-        const size_t counter_bytes = sizeof(unsigned long long) * kWorkShards * kWorkCounterStride;
+        constexpr size_t counter_bytes = sizeof(unsigned long long) * kWorkShards * kWorkCounterStride;
+        // (zeroed by a copy, not a memset: a process's first hipMemset loads the runtime's fill kernels, 20 ms in the CLI's
+        // one render; the per-wave scratch -- 50 MB per lane -- is made when the lane first gets a launch, size_lane)
+        static const unsigned long long zeros[kWorkShards * kWorkCounterStride] = {};
         for (auto& B : L.bufs) {
             HIP_TRY(hipMalloc(&p, counter_bytes));
             s->allocs.push_back(p);
             B.d_work_counter = static_cast<unsigned long long*>(p);
-            HIP_TRY(hipMemset(p, 0, counter_bytes));
+            HIP_TRY(hipMemcpy(p, zeros, counter_bytes, hipMemcpyHostToDevice));
         }
-        HIP_TRY(hipMalloc(&p, megakernel_gseq_bytes(s->scratch_waves)));
-        s->allocs.push_back(p);
-        L.d_gseq = static_cast<uint32_t*>(p);
-        HIP_TRY(hipMemset(p, 0, megakernel_gseq_bytes(s->scratch_waves)));
-        HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
-        s->allocs.push_back(p);
-        L.d_gstack = static_cast<uint32_t*>(p);
         // the lane is recorded before its stream and events exist, so that a failure below leaves them to
         // rbrt_hip_scene_destroy instead of leaking them (a lane without a stream is never selected: the caller
         // gets the error)
@@ -545,8 +541,7 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
             return fail(RBRT_ERR_HIP, std::string("pipeline lane: ") + hipGetErrorString(e));
         }
     }
-    // the memsets above ran on the null stream, which the lanes' non-blocking streams do not wait for
-    if (s->lanes.size() != had) HIP_TRY(hipDeviceSynchronize());
+    (void)had;  // (the counters were zeroed by blocking copies: nothing of the new lanes is in flight)
     return RBRT_OK;
 }
 
@@ -825,8 +820,7 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
         const size_t bytes = std::max<size_t>(size_t(tri_total) * sizeof(BvhTri), 64);
         HIP_TRY_BAIL(hipMalloc(&p, bytes));
         s->allocs.push_back(p);
-        s->d_tris = static_cast<BvhTri*>(p);
-        HIP_TRY_BAIL(hipMemset(p, 0, bytes));  // (records no leaf points at: zero-area triangles)
+        s->d_tris = static_cast<BvhTri*>(p);  // (records no leaf points at are never read: left as they are)
     }
     // Builder of each mesh's first tree: whichever costs this call less (device_builder_is_cheaper), the host's tree
     // following in the background for a handle (struct Refine); RBRT_BVH_BUILDER = host | device forces one and nothing
@@ -1203,6 +1197,16 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     const size_t lists_need = size_t(kTileListHeader) + 2u * size_t(n_local);
     const auto size_lane = [&](uint32_t li) -> int {
         rbrt_hip_scene::Lane& L = s->lanes[li];
+        if (!L.d_gseq) {  // the lane's per-wave scratch: scatter records beyond the four in LDS (written before they are read: no
+                          // initial value), the overflow of the LDS stacks
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, megakernel_gseq_bytes(s->scratch_waves, s->pool)));
+            s->allocs.push_back(p);
+            L.d_gseq = static_cast<uint32_t*>(p);
+            HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
+            s->allocs.push_back(p);
+            L.d_gstack = static_cast<uint32_t*>(p);
+        }
         for (auto& B : L.bufs) {
             if (need <= B.sample_buf_bytes) continue;
             if (B.d_sample_buf) {

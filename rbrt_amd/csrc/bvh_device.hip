@@ -310,9 +310,12 @@ struct QItem {
 // a leaf, a larger one may be opened into its two children (the left child's triangles come first in the output).
 __global__ __launch_bounds__(kTpb) void collapse_level(Work* w, Tree t, uint32_t n_leaves, const uint32_t* __restrict__ sorted,
                                                        uint32_t* __restrict__ order, const QItem* __restrict__ q_in, uint32_t n_in,
-                                                       QItem* __restrict__ q_out, uint32_t* q_out_count, BvhNode4* __restrict__ nodes,
-                                                       uint32_t node_cap, uint32_t tri_base, uint32_t depth) {
+                                                       QItem* __restrict__ q_out, uint32_t* q_out_count, uint32_t* q_in_count,
+                                                       BvhNode4* __restrict__ nodes, uint32_t node_cap, uint32_t tri_base, uint32_t depth) {
     const uint32_t tid = blockIdx.x * kTpb + threadIdx.x;
+    // (this level's input count came in by value: its word is the NEXT level's output count, zeroed here instead of by a
+    // hipMemsetAsync per level -- whose first use in a process loads the runtime's fill kernels)
+    if (tid == 0) *q_in_count = 0u;
     if (tid >= n_in) return;
     const QItem it = q_in[tid];
     uint32_t c[4] = {uint32_t(t.left[it.bnode]), uint32_t(t.right[it.bnode]), 0u, 0u};
@@ -583,9 +586,8 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
     uint32_t* d_q_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(w) + offsetof(Work, q_count));
     while (n_in != 0 && depth <= uint32_t(kMaxBvhDepth)) {
         const int curq = int(depth & 1u);
-        DEV_TRY(hipMemsetAsync(d_q_count + (curq ^ 1), 0, sizeof(uint32_t), stream));
         hipLaunchKernelGGL(collapse_level, dim3(blocks(n_in)), dim3(kTpb), 0, stream, w, t, n, sorted, order, queue[curq], n_in,
-                           queue[curq ^ 1], d_q_count + (curq ^ 1), nodes, node_cap, tri_base, depth);
+                           queue[curq ^ 1], d_q_count + (curq ^ 1), d_q_count + curq, nodes, node_cap, tri_base, depth);
         DEV_TRY(hipMemcpyAsync(&n_in, d_q_count + (curq ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         DEV_TRY(hipStreamSynchronize(stream));
         if (n_in > node_cap) n_in = node_cap;  // (overflow is flagged in w)

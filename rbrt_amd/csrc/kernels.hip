@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(kBlock) void scatter_debug_kernel(const DevMaterial
 // ---------------------------------------------------------------------------------------------
 // Launch wrappers (called from api.cpp, which is plain C++)
 // ---------------------------------------------------------------------------------------------
-size_t megakernel_gseq_bytes(uint32_t n_waves) { return size_t(n_waves) * kPoolMax * kSeqWords * sizeof(uint32_t); }
+size_t megakernel_gseq_bytes(uint32_t n_waves, uint32_t pool) { return size_t(n_waves) * pool * kSeqWords * sizeof(uint32_t); }
 size_t megakernel_gstack_bytes(uint32_t n_waves) { return size_t(n_waves) * kStackMax * 64u * sizeof(uint32_t); }
 
 __host__ __device__ inline uint32_t megakernel_lds_dwords(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes,

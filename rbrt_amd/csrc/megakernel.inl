@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         rt_cur = next;
     };
 #endif
-    uint32_t* const gseq = P.gseq + size_t(blockIdx.x) * kPoolMax * kSeqWords;
+    uint32_t* const gseq = P.gseq + size_t(blockIdx.x) * uint32_t(POOLN) * kSeqWords;
 #define POOL(f, s) pool[(f) * POOLN + (s)]
 
     for (uint32_t s = lane; s < kPoolPad; s += 64) status[s] = s < uint32_t(POOLN) ? ST_EMPTY : ST_BUSY;  // pad slots never match

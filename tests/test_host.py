@@ -162,6 +162,32 @@ def test_png_roundtrip(tmp_path):
     assert back.shape == img.shape and np.array_equal(back, img)
 
 
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+def test_png_deflated_in_pieces_by_several_threads_is_one_valid_stream(tmp_path, monkeypatch, threads):
+    """The encoder deflates 128-KiB pieces on several threads and concatenates them behind one zlib header (png.cpp): the
+    file must decode with a stock inflater (PIL's, and zlib's one-call decompress of the IDAT payload, which also checks
+    the combined Adler-32), whatever the thread count; part noise, part flat, sizes that are and are not multiples of a piece."""
+    import struct
+    import zlib
+    from PIL import Image
+    monkeypatch.setenv("RBRT_PNG_THREADS", threads)
+    rng = np.random.default_rng(int(threads))
+    for (h, w) in ((300, 437), (768, 1024), (1, 1), (43, 1016)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img[h // 3:2 * h // 3] = 77  # a compressible band
+        path = tmp_path / f"p{h}x{w}.png"
+        abi.write_png(path, img)
+        assert np.array_equal(np.array(Image.open(path)), img)
+        data, pos, idat = path.read_bytes(), 8, b""
+        while pos < len(data):
+            n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+            if typ == b"IDAT":
+                idat += data[pos + 8:pos + 8 + n]
+            pos += 12 + n
+        raw = zlib.decompress(idat)
+        assert len(raw) == h * (3 * w + 1)
+
+
 @pytest.mark.parametrize("ext", ["png", "ppm", "pnm", "bmp", "tga", "tif", "tiff", "qoi", "PNG"])
 def test_image_formats_by_extension_decode_to_the_same_pixels(tmp_path, ext):
     """src/main.rs:86: `img_buf.save(path)` picks the encoder from the extension (image crate). The lossless 8-bit RGB
