@@ -807,12 +807,13 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
         put_mat(e, (elems[e] >> 31) ? scene->triangles[elems[e] & 0x7FFFFFFFu].mat : scene->spheres[elems[e]].mat);
     std::vector<DevMesh> meshes(scene->n_meshes);
     // One triangle array for the scene (leaf links are absolute positions in it): mesh i owns the records
-    // [tri_base[i], tri_base[i] + cap[i]), cap = what its builder can emit at most (the scan-visible entries + a dummy).
+    // [tri_base[i], tri_base[i] + cap[i]), cap = what its builder can emit at most (bvh.h bvh_record_capacity: the scan-visible
+    // entries, the host builder's duplicated references, a dummy).
     std::vector<uint32_t> tri_base(scene->n_meshes, 0);
     uint64_t tri_total = 0;
     for (uint32_t i = 0; i < scene->n_meshes; ++i) {
         tri_base[i] = uint32_t(tri_total);
-        tri_total += uint64_t(scene->meshes[i].n_total / 8u) * 8u + 1u;
+        tri_total += bvh_record_capacity(scene->meshes[i].n_total);
         if (tri_total >= (1ull << 25)) return bail(fail(RBRT_ERR_UNSUPPORTED, "more than 2^25 triangle records in one scene"));
     }
     {

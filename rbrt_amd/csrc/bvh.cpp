@@ -90,17 +90,39 @@ struct Sink {
 constexpr int32_t kTaskRefBase = INT32_MIN + 1;  // child refs kTaskRefBase + k stand for task k until the splice
 inline bool is_task_ref(int32_t r) { return r != kNoChild && r < -(int32_t(1) << 30) - 1; }
 
+// Spatial splits (Stich, Friedrich, Dietrich 2009, "Spatial Splits in Bounding Volume Hierarchies"). A long, thin or
+// diagonal triangle -- a fin, a spike, the seam of a fold -- makes every box that holds it large, and an object split can
+// only choose which side gets the whole of it. A spatial split cuts the node's box with a plane and gives each side a
+// REFERENCE to the triangle with the box of the part on that side: the same record is then in two leaves. That is legal
+// here because the leaf rounds merge with a lexicographic (t, index) minimum -- the same triangle found twice is the same
+// key -- and because the parts' boxes cover the triangle: the point where the fp32 test accepts a hit lies (to within the
+// traversal's pad) in at least one part, and the walk reaches that part's leaf (bvh.h). Duplicated references are capped
+// at kSpatialBudget of the mesh's triangles, dealt down the tree in proportion to the subtrees' sizes, so that the tree is
+// a function of the SET of triangles (any thread count, any order of the input).
+constexpr int kSpatialBins = 32;
+constexpr float kSpatialAlpha = 1e-4f;  // try a spatial split when the object split's children overlap by more than this share of the root's surface
+float spatial_budget_frac() {
+    static const float v = [] {
+        const char* lab = std::getenv("RBRT_HIP_LAB");  // (a lab knob: include/rbrt_hip_debug.h)
+        const char* e = (lab && lab[0] == '1') ? std::getenv("RBRT_BVH_SPATIAL") : nullptr;
+        const float x = e ? float(std::atof(e)) : kSpatialBudget;
+        return x >= 0.0f && x <= kSpatialBudget ? x : kSpatialBudget;  // (the record array is sized for kSpatialBudget)
+    }();
+    return v;
+}
+
 struct Builder {
     const rbrt_mesh_t* m = nullptr;  // the source: a mesh's SoA arrays ...
     const BvhTri* recs = nullptr;    // ... or n_recs triangle records in any order
     size_t n_recs = 0;
     BvhBuildOptions opt;
-    std::vector<Prim> prims;
     std::vector<Node2> nodes2;
     BvhBuildResult out;
+    float root_area = 0.0f;
     struct Task {
-        size_t b, e;
+        std::vector<Prim> refs;
         int depth;
+        int64_t budget;
         Sink sink;
         ChildInfo root;
     };
@@ -108,6 +130,25 @@ struct Builder {
     size_t task_grain = 0;  // 0: single-threaded build, no tasks
 
     bool cancelled() const { return opt.cancel && opt.cancel->load(std::memory_order_relaxed); }
+
+    void corners(uint32_t src, float v[3][3]) const {  // the triangle as the boxes see it: v0, v0 + e1, v0 + e2 in float
+        float e1[3], e2[3];
+        if (recs) {
+            const BvhTri& r = recs[src];
+            v[0][0] = r.v0[0], v[0][1] = r.v0[1], v[0][2] = r.v0[2];
+            e1[0] = r.e1x, e1[1] = r.e1yz[0], e1[2] = r.e1yz[1];
+            e2[0] = r.e2xy[0], e2[1] = r.e2xy[1], e2[2] = r.e2z;
+        } else {
+            v[0][0] = m->v0x[src], v[0][1] = m->v0y[src], v[0][2] = m->v0z[src];
+            e1[0] = m->e1x[src], e1[1] = m->e1y[src], e1[2] = m->e1z[src];
+            e2[0] = m->e2x[src], e2[1] = m->e2y[src], e2[2] = m->e2z[src];
+        }
+        const float fmax = std::numeric_limits<float>::max();
+        for (int k = 0; k < 3; ++k) {  // clamp in case v0 + e overflows
+            v[1][k] = std::min(std::max(v[0][k] + e1[k], -fmax), fmax);
+            v[2][k] = std::min(std::max(v[0][k] + e2[k], -fmax), fmax);
+        }
+    }
 
     BvhTri make_tri(const Prim& p) const {
         BvhTri t;
@@ -130,23 +171,58 @@ struct Builder {
         return uint64_t(kLeafMax) << (kMaxInnerDepth - depth + 1);
     }
 
-    ChildInfo make_leaf(Sink& sk, size_t b, size_t e, const Box& box, float max_e12) {
+    ChildInfo make_leaf(Sink& sk, std::vector<Prim>& refs, size_t count, const Box& box, float max_e12) {
         uint32_t first = uint32_t(sk.tris.size());
-        uint32_t count = uint32_t(e - b);
         // deterministic order inside a leaf: ascending reference index
-        std::sort(prims.begin() + b, prims.begin() + e,
-                  [](const Prim& x, const Prim& y) { return x.idx < y.idx; });
-        for (size_t i = b; i < e; ++i) sk.tris.push_back(make_tri(prims[i]));
+        std::sort(refs.begin(), refs.begin() + count, [](const Prim& x, const Prim& y) { return x.idx < y.idx; });
+        for (size_t i = 0; i < count; ++i) sk.tris.push_back(make_tri(refs[i]));
         ++sk.n_leaves;
-        return ChildInfo{~int32_t((first << kLeafBits) | (count - 1)), box, max_e12};
+        return ChildInfo{~int32_t((first << kLeafBits) | (uint32_t(count) - 1u)), box, max_e12};
     }
 
-    // `top`: this call belongs to the single-threaded top of the tree; ranges of at most task_grain
-    // triangles are not built here but queued as tasks (a placeholder ref is returned).
-    ChildInfo build_range(Sink& sk, size_t b, size_t e, int depth, bool top) {
-        const size_t count = e - b;
+    // The boxes of the two parts of reference p's triangle on either side of the plane x[axis] = plane, each inside p's
+    // own box (which earlier cuts may have made smaller than the triangle's). The split coordinate of a crossing point is
+    // the plane itself, so the two parts meet exactly; the other two coordinates of a crossing point are widened by a few
+    // units in the last place: a part's box may be a little too large, never too small.
+    void split_ref(const Prim& p, int axis, float plane, Box& lb, Box& rb) const {
+        float v[3][3];
+        corners(p.src, v);
+        lb.reset(), rb.reset();
+        for (int i = 0; i < 3; ++i) {
+            const float* a = v[i];
+            const float* b = v[(i + 1) % 3];
+            if (a[axis] <= plane) lb.grow(a);
+            if (a[axis] >= plane) rb.grow(a);
+            if ((a[axis] < plane && b[axis] > plane) || (a[axis] > plane && b[axis] < plane)) {
+                const float t = (plane - a[axis]) / (b[axis] - a[axis]);
+                float lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) {
+                    const float x = a[k] + (b[k] - a[k]) * t;
+                    const float slack = 4.0f * 1.1920929e-7f * (std::fabs(a[k]) + std::fabs(b[k])) + 1e-30f;
+                    lo[k] = std::min(std::max(x - slack, std::min(a[k], b[k])), std::max(a[k], b[k]));
+                    hi[k] = std::max(std::min(x + slack, std::max(a[k], b[k])), std::min(a[k], b[k]));
+                }
+                lo[axis] = hi[axis] = plane;
+                lb.grow(lo), lb.grow(hi), rb.grow(lo), rb.grow(hi);
+            }
+        }
+        lb.hi[axis] = std::min(lb.hi[axis], plane), rb.lo[axis] = std::max(rb.lo[axis], plane);
+        for (int k = 0; k < 3; ++k) {  // inside the reference's own box
+            lb.lo[k] = std::max(lb.lo[k], p.box.lo[k]), lb.hi[k] = std::min(lb.hi[k], p.box.hi[k]);
+            rb.lo[k] = std::max(rb.lo[k], p.box.lo[k]), rb.hi[k] = std::min(rb.hi[k], p.box.hi[k]);
+        }
+    }
+    static bool box_ok(const Box& b) { return b.lo[0] <= b.hi[0] && b.lo[1] <= b.hi[1] && b.lo[2] <= b.hi[2]; }
+    static void set_centroid(Prim& p) {
+        for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * p.box.lo[k] + 0.5f * p.box.hi[k];
+    }
+
+    // `top`: this call belongs to the single-threaded top of the tree; lists of at most task_grain references are not
+    // built here but queued as tasks (a placeholder ref is returned). `budget`: references this subtree may still add.
+    ChildInfo build_node(Sink& sk, std::vector<Prim> refs, int depth, bool top, int64_t budget) {
+        const size_t count = refs.size();
         if (top && count <= task_grain) {
-            tasks.push_back(Task{b, e, depth, Sink(), ChildInfo()});
+            tasks.push_back(Task{std::move(refs), depth, budget, Sink(), ChildInfo()});
             ChildInfo c;
             c.ref = kTaskRefBase + int32_t(tasks.size() - 1);
             c.box.reset();
@@ -157,18 +233,20 @@ struct Builder {
         box.reset();
         cbox.reset();
         float max_e12 = 0.0f;
-        for (size_t i = b; i < e; ++i) {
-            box.grow(prims[i].box);
-            cbox.grow(prims[i].c);
-            max_e12 = std::max(max_e12, prims[i].e12);
+        for (const Prim& p : refs) {
+            box.grow(p.box);
+            cbox.grow(p.c);
+            max_e12 = std::max(max_e12, p.e12);
         }
-        if (depth > kMaxInnerDepth || count <= 1) return make_leaf(sk, b, e, box, max_e12);
-        if (cancelled()) return make_leaf(sk, b, b + 1, box, max_e12);  // (memory-safe nonsense: the result is thrown away)
+        if (depth > kMaxInnerDepth || count <= 1) return make_leaf(sk, refs, count, box, max_e12);
+        if (cancelled()) return make_leaf(sk, refs, 1, box, max_e12);  // (memory-safe nonsense: the result is thrown away)
 
-        // binned SAH over the three axes
+        // ---- object split: binned SAH over the three axes (centroids of the references' boxes) ----
         const float parent_area = box.half_area();
         float best_cost = std::numeric_limits<float>::infinity();
         int best_axis = -1, best_split = -1;
+        Box best_lbox, best_rbox;
+        best_lbox.reset(), best_rbox.reset();
         for (int axis = 0; axis < 3; ++axis) {
             const float cmin = cbox.lo[axis], cext = cbox.hi[axis] - cbox.lo[axis];
             if (!(cext > 0.0f)) continue;
@@ -176,12 +254,12 @@ struct Builder {
             Box bin_box[kBins];
             uint32_t bin_cnt[kBins] = {0};
             for (auto& bb : bin_box) bb.reset();
-            for (size_t i = b; i < e; ++i) {
-                int bi = std::min(kBins - 1, std::max(0, int((prims[i].c[axis] - cmin) * scale)));
-                bin_box[bi].grow(prims[i].box);
+            for (const Prim& p : refs) {
+                int bi = std::min(kBins - 1, std::max(0, int((p.c[axis] - cmin) * scale)));
+                bin_box[bi].grow(p.box);
                 ++bin_cnt[bi];
             }
-            float right_area[kBins];
+            Box right_box[kBins];
             uint32_t right_cnt[kBins];
             Box acc;
             acc.reset();
@@ -189,7 +267,7 @@ struct Builder {
             for (int i = kBins - 1; i > 0; --i) {
                 acc.grow(bin_box[i]);
                 n += bin_cnt[i];
-                right_area[i] = acc.half_area();
+                right_box[i] = acc;
                 right_cnt[i] = n;
             }
             acc.reset();
@@ -198,46 +276,156 @@ struct Builder {
                 acc.grow(bin_box[i - 1]);
                 n += bin_cnt[i - 1];
                 if (n == 0 || right_cnt[i] == 0) continue;
-                float cost = acc.half_area() * float(n) + right_area[i] * float(right_cnt[i]);
+                float cost = acc.half_area() * float(n) + right_box[i].half_area() * float(right_cnt[i]);
                 if (cost < best_cost) {
                     best_cost = cost;
                     best_axis = axis;
                     best_split = i;
+                    best_lbox = acc, best_rbox = right_box[i];
+                }
+            }
+        }
+        // ---- spatial split: only where the object split leaves its children overlapping, and while references may be added ----
+        float sp_cost = std::numeric_limits<float>::infinity(), sp_plane = 0.0f;
+        int sp_axis = -1;
+        Box sp_lbox, sp_rbox;
+        uint32_t sp_nl = 0, sp_nr = 0;
+        sp_lbox.reset(), sp_rbox.reset();
+        if (budget > 0 && count > size_t(kLeafMax) && best_axis >= 0 && parent_area > 0.0f && root_area > 0.0f) {
+            Box ov;
+            for (int k = 0; k < 3; ++k) ov.lo[k] = std::max(best_lbox.lo[k], best_rbox.lo[k]), ov.hi[k] = std::min(best_lbox.hi[k], best_rbox.hi[k]);
+            if (box_ok(ov) && ov.half_area() > kSpatialAlpha * root_area) {
+                for (int axis = 0; axis < 3; ++axis) {
+                    const float lo = box.lo[axis], ext = box.hi[axis] - box.lo[axis];
+                    if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
+                    const float scale = float(kSpatialBins) / ext;
+                    float planes[kSpatialBins + 1];
+                    for (int j = 0; j <= kSpatialBins; ++j) planes[j] = j == kSpatialBins ? box.hi[axis] : lo + ext * (float(j) / float(kSpatialBins));
+                    Box bin_box[kSpatialBins];
+                    uint32_t enter[kSpatialBins] = {0}, leave[kSpatialBins] = {0};
+                    for (auto& bb : bin_box) bb.reset();
+                    for (const Prim& p : refs) {
+                        int b0 = std::min(kSpatialBins - 1, std::max(0, int((p.box.lo[axis] - lo) * scale)));
+                        int b1 = std::min(kSpatialBins - 1, std::max(b0, int((p.box.hi[axis] - lo) * scale)));
+                        while (b1 > b0 && p.box.hi[axis] <= planes[b1]) --b1;      // (a box that ends ON a plane is not beyond it)
+                        while (b0 < b1 && p.box.lo[axis] >= planes[b0 + 1]) ++b0;
+                        ++enter[b0], ++leave[b1];
+                        if (b0 == b1) {
+                            bin_box[b0].grow(p.box);
+                        } else {  // chopped into the bins it crosses
+                            Prim cur = p;
+                            for (int bb = b0; bb < b1; ++bb) {
+                                Box l, r;
+                                split_ref(cur, axis, planes[bb + 1], l, r);
+                                if (box_ok(l)) bin_box[bb].grow(l);
+                                if (!box_ok(r)) break;
+                                cur.box = r;
+                                if (bb + 1 == b1) bin_box[b1].grow(r);
+                            }
+                        }
+                    }
+                    Box right_box[kSpatialBins];
+                    uint32_t right_cnt[kSpatialBins];
+                    Box acc;
+                    acc.reset();
+                    uint32_t n = 0;
+                    for (int i = kSpatialBins - 1; i > 0; --i) {
+                        acc.grow(bin_box[i]);
+                        n += leave[i];
+                        right_box[i] = acc, right_cnt[i] = n;
+                    }
+                    acc.reset();
+                    n = 0;
+                    for (int i = 1; i < kSpatialBins; ++i) {  // the plane between bins i - 1 and i
+                        acc.grow(bin_box[i - 1]);
+                        n += enter[i - 1];
+                        if (n == 0 || right_cnt[i] == 0 || n == count || right_cnt[i] == count) continue;
+                        const float cost = acc.half_area() * float(n) + right_box[i].half_area() * float(right_cnt[i]);
+                        if (cost < sp_cost) sp_cost = cost, sp_axis = axis, sp_plane = planes[i], sp_lbox = acc, sp_rbox = right_box[i], sp_nl = n, sp_nr = right_cnt[i];
+                    }
                 }
             }
         }
         const float leaf_cost = kCostTri * float(count);
         float split_cost = std::numeric_limits<float>::infinity();
-        if (best_axis >= 0 && parent_area > 0.0f)
-            split_cost = cost_traverse() + kCostTri * best_cost / parent_area;
-        if (count <= size_t(kLeafMax) && leaf_cost <= split_cost) return make_leaf(sk, b, e, box, max_e12);
+        if (best_axis >= 0 && parent_area > 0.0f) split_cost = cost_traverse() + kCostTri * std::min(best_cost, sp_cost) / parent_area;
+        if (count <= size_t(kLeafMax) && leaf_cost <= split_cost) return make_leaf(sk, refs, count, box, max_e12);
 
-        size_t mid = b;
-        if (best_axis >= 0) {
-            const float cmin = cbox.lo[best_axis];
-            const float scale = float(kBins) / (cbox.hi[best_axis] - cbox.lo[best_axis]);
-            auto it = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim& p) {
-                int bi = std::min(kBins - 1, std::max(0, int((p.c[best_axis] - cmin) * scale)));
-                return bi < best_split;
-            });
-            mid = size_t(it - prims.begin());
-        }
+        std::vector<Prim> left, right;
         const uint64_t cap = capacity(depth + 1);
-        if (mid == b || mid == e || (mid - b) > cap || (e - mid) > cap) {
-            // degenerate or too unbalanced for the depth budget: median split along the widest axis
-            int axis = 0;
-            for (int k = 1; k < 3; ++k)
-                if (cbox.hi[k] - cbox.lo[k] > cbox.hi[axis] - cbox.lo[axis]) axis = k;
-            mid = b + count / 2;
-            std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
-                             [axis](const Prim& x, const Prim& y) {
-                                 return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
-                             });
+        int64_t used = 0;
+        if (sp_axis >= 0 && sp_cost < best_cost) {
+            // ---- partition by the plane; a reference that crosses it goes to both sides with the boxes of its parts, unless
+            // keeping it whole on one side is cheaper (judged against the sides the sweep found: the same for every order) ----
+            left.reserve(sp_nl), right.reserve(sp_nr);
+            const float a_l = sp_lbox.half_area(), a_r = sp_rbox.half_area();
+            for (const Prim& p : refs) {
+                if (p.box.hi[sp_axis] <= sp_plane) {
+                    left.push_back(p);
+                } else if (p.box.lo[sp_axis] >= sp_plane) {
+                    right.push_back(p);
+                } else {
+                    Box lb, rb;
+                    split_ref(p, sp_axis, sp_plane, lb, rb);
+                    const bool l_ok = box_ok(lb), r_ok = box_ok(rb);
+                    Box wl = sp_lbox, wr = sp_rbox;
+                    wl.grow(p.box), wr.grow(p.box);
+                    const float c_split = a_l * float(sp_nl) + a_r * float(sp_nr);
+                    const float c_left = wl.half_area() * float(sp_nl) + a_r * float(sp_nr - 1u);
+                    const float c_right = a_l * float(sp_nl - 1u) + wr.half_area() * float(sp_nr);
+                    if (!r_ok || (l_ok && c_left <= c_split && c_left <= c_right)) {
+                        left.push_back(p);
+                    } else if (!l_ok || (c_right <= c_split)) {
+                        right.push_back(p);
+                    } else {
+                        Prim pl = p, pr = p;
+                        pl.box = lb, pr.box = rb;
+                        set_centroid(pl), set_centroid(pr);
+                        left.push_back(pl), right.push_back(pr);
+                    }
+                }
+            }
+            used = int64_t(left.size() + right.size()) - int64_t(count);
+            if (left.empty() || right.empty() || left.size() == count || right.size() == count || used > budget || left.size() > cap ||
+                right.size() > cap)
+                left.clear(), right.clear(), used = 0;  // (no gain, or beyond the budget: the object split after all)
         }
+        if (left.empty()) {
+            size_t mid = 0;
+            if (best_axis >= 0) {
+                const float cmin = cbox.lo[best_axis];
+                const float scale = float(kBins) / (cbox.hi[best_axis] - cbox.lo[best_axis]);
+                auto it = std::partition(refs.begin(), refs.end(), [&](const Prim& p) {
+                    int bi = std::min(kBins - 1, std::max(0, int((p.c[best_axis] - cmin) * scale)));
+                    return bi < best_split;
+                });
+                mid = size_t(it - refs.begin());
+            }
+            if (mid == 0 || mid == count || mid > cap || (count - mid) > cap) {
+                // degenerate or too unbalanced for the depth budget: median split along the widest axis
+                int axis = 0;
+                for (int k = 1; k < 3; ++k)
+                    if (cbox.hi[k] - cbox.lo[k] > cbox.hi[axis] - cbox.lo[axis]) axis = k;
+                mid = count / 2;
+                std::nth_element(refs.begin(), refs.begin() + mid, refs.end(), [axis](const Prim& x, const Prim& y) {
+                    return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
+                });
+            }
+            left.assign(refs.begin(), refs.begin() + mid);
+            right.assign(refs.begin() + mid, refs.end());
+        }
+        std::vector<Prim>().swap(refs);  // (the list is in its two halves now)
+        const int64_t rest = std::max<int64_t>(0, budget - used);
+        // (dealt by the surface of the references' boxes, not by their number: the triangles that gain from being cut are the
+        // large ones, and a fin of a few hundred of them would get next to nothing of a budget dealt by count)
+        double w_l = 0.0, w_r = 0.0;
+        for (const Prim& p : left) w_l += double(p.box.half_area());
+        for (const Prim& p : right) w_r += double(p.box.half_area());
+        const int64_t b_left = w_l + w_r > 0.0 ? int64_t(double(rest) * (w_l / (w_l + w_r))) : rest / 2;
         const uint32_t node = uint32_t(sk.nodes2.size());
         sk.nodes2.emplace_back();
-        ChildInfo l = build_range(sk, b, mid, depth + 1, top);
-        ChildInfo r = build_range(sk, mid, e, depth + 1, top);
+        ChildInfo l = build_node(sk, std::move(left), depth + 1, top, b_left);
+        ChildInfo r = build_node(sk, std::move(right), depth + 1, top, rest - b_left);
         set_node(sk.nodes2, node, l, r);
         return ChildInfo{int32_t(node), box, max_e12};
     }
@@ -291,29 +479,37 @@ struct Builder {
         return ChildInfo{int32_t(me), box, max_e12};
     }
 
-    ChildInfo build_tree() {
+    ChildInfo build_tree(std::vector<Prim> prims) {
         unsigned n_threads = std::thread::hardware_concurrency();
         if (opt.max_threads != 0) n_threads = std::min(n_threads, opt.max_threads);
         if (const char* e = std::getenv("RBRT_BVH_THREADS")) n_threads = unsigned(std::max(1, std::atoi(e)));
         n_threads = std::min(n_threads, 16u);
-        if (n_threads <= 1 || prims.size() < 32768) {
+        const size_t n_prims = prims.size();
+        const int64_t budget = int64_t(double(spatial_budget_frac()) * double(n_prims));
+        {
+            Box all;
+            all.reset();
+            for (const Prim& p : prims) all.grow(p.box);
+            root_area = all.half_area();
+        }
+        if (n_threads <= 1 || n_prims < 32768) {
             Sink sk;
-            sk.nodes2.reserve(prims.size() / 2 + 2);
-            sk.tris.reserve(prims.size() + 2);
-            const ChildInfo root = build_range(sk, 0, prims.size(), 0, false);
+            sk.nodes2.reserve(n_prims / 2 + 2);
+            sk.tris.reserve(n_prims + size_t(budget) + 2);
+            const ChildInfo root = build_node(sk, std::move(prims), 0, false, budget);
             nodes2 = std::move(sk.nodes2);
             out.tris = std::move(sk.tris);
             out.n_leaves = sk.n_leaves;
             return root;
         }
-        task_grain = std::max<size_t>(4096, prims.size() / (8u * n_threads));
+        task_grain = std::max<size_t>(4096, n_prims / (8u * n_threads));
         Sink top;
-        const ChildInfo top_root = build_range(top, 0, prims.size(), 0, true);
+        const ChildInfo top_root = build_node(top, std::move(prims), 0, true, budget);
         std::atomic<size_t> next{0};
         auto worker = [&]() {
             for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
                 Task& t = tasks[k];
-                t.root = build_range(t.sink, t.b, t.e, t.depth, false);  // disjoint prim ranges: no sharing
+                t.root = build_node(t.sink, std::move(t.refs), t.depth, false, t.budget);  // disjoint lists: no sharing
             }
         };
         std::vector<std::thread> pool;
@@ -322,8 +518,8 @@ struct Builder {
         for (auto& th : pool) th.join();
         task_grain = 0;
         if (cancelled()) return top_root;  // (what a cancelled build leaves is not a tree: nothing of it is walked, run() drops it)
-        nodes2.reserve(prims.size() / 2 + 2);
-        out.tris.reserve(prims.size() + 2);
+        nodes2.reserve(n_prims / 2 + 2);
+        out.tris.reserve(n_prims + size_t(budget) + 2);
         return splice(top, top_root.ref, top_root.box, top_root.max_e12);
     }
 
@@ -342,6 +538,7 @@ struct Builder {
 
     void run() {
         const uint32_t n_tested = recs ? uint32_t(n_recs) : (m->n_total / 8u) * 8u;  // triangle.rs:166-167
+        std::vector<Prim> prims;
         prims.reserve(n_tested);
         for (uint32_t i = 0; i < n_tested; ++i) {
             if (recs ? recs[i].index == 0xFFFFFFFFu : (m->is_padding && m->is_padding[i])) continue;  // triangle.rs:400
@@ -385,7 +582,7 @@ struct Builder {
             ChildInfo d0 = make_dummy();
             set_node(nodes2, 0, d0, d0);
         } else {
-            ChildInfo root = build_tree();
+            ChildInfo root = build_tree(std::move(prims));
             if (cancelled()) {
                 out.cancelled = true;
                 return;
@@ -397,8 +594,6 @@ struct Builder {
             }
             out.max_e12 = root.max_e12;
         }
-        prims.clear();
-        prims.shrink_to_fit();
         if (cancelled()) {
             out.cancelled = true;
             return;
@@ -472,6 +667,11 @@ struct Builder {
                         dst.e12 = std::max(dst.e12, te12[i]);
                         na += uint32_t(half);
                     }
+            // (a reference cut by a spatial split: its part lies in the leaf's box, which is smaller than the triangle's)
+            for (int k = 0; k < 3; ++k) {
+                a.box.lo[k] = std::max(a.box.lo[k], leaf.box.lo[k]), a.box.hi[k] = std::min(a.box.hi[k], leaf.box.hi[k]);
+                b.box.lo[k] = std::max(b.box.lo[k], leaf.box.lo[k]), b.box.hi[k] = std::min(b.box.hi[k], leaf.box.hi[k]);
+            }
             a.ref = ~int32_t((first << kLeafBits) | (na - 1u));
             b.ref = ~int32_t(((first + na) << kLeafBits) | (count - na - 1u));
             ++out.n_leaves;

@@ -19,13 +19,22 @@
 
 namespace rbrt {
 
+// The host builder may reference a triangle from more than one leaf (spatial splits, bvh.cpp): at most kSpatialBudget
+// duplicated references per indexed triangle. A mesh of n_total entries never needs more than bvh_record_capacity records
+// (the scan-visible entries, their duplicates, one dummy record of a degenerate tree).
+constexpr float kSpatialBudget = 0.30f;
+inline uint64_t bvh_record_capacity(uint32_t n_total) {
+    const uint64_t n_tested = uint64_t(n_total / 8u) * 8u;
+    return n_tested + uint64_t(double(kSpatialBudget) * double(n_tested)) + 2u;
+}
+
 struct BvhBuildResult {
     std::vector<BvhNode4> nodes;  // nodes[0] = root
-    std::vector<BvhTri> tris;     // leaf order
+    std::vector<BvhTri> tris;     // leaf order (a triangle cut by spatial splits appears once per leaf that references it)
     float max_e12 = 0.0f;
     uint32_t max_depth = 0;   // depth of the deepest 4-wide node (root = 0)
     uint32_t stack_need = 1;  // traversal stack entries that can ever be live: 3 per level + 1
-    uint32_t n_indexed = 0;   // triangles in the BVH
+    uint32_t n_indexed = 0;   // triangles in the BVH (tris.size() - n_indexed - [dummy] = duplicated references)
     uint32_t n_leaves = 0;
     bool cancelled = false;   // BvhBuildOptions::cancel was raised: the arrays are not a tree of the mesh
 };

@@ -41,8 +41,29 @@ def test_bvh4_invariants(oracle, n_tris):
     check_invariants(md, *build(md))
 
 
+def test_bvh4_invariants_with_spatial_splits(oracle):
+    """Meshes where the builder does cut triangles: the rough stand-in (fins, spikes, folds) and a cloud of small triangles
+    with long needles through it. Boxes nest, parts cover their triangles, duplicates stay inside the budget."""
+    md = scenes.standin_mesh(oracle, 6003, kind="rough", **scenes.EXAMPLE_MESH)
+    N, T, depth, me = build(md)
+    assert len(T) > 6003  # some references are duplicated
+    check_invariants(md, N, T, depth, me)
+    rng = np.random.default_rng(11)
+    a = rng.uniform(-1, 1, (120, 3))
+    dirs = rng.normal(size=(120, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    needles = np.stack([a, a + dirs * rng.uniform(0.5, 2.0, (120, 1)), a + dirs * 0.01 + rng.normal(size=(120, 3)) * 0.02], 1)
+    soup = np.concatenate([scenes.random_soup(rng, 1880, extent=1.0, size=0.04), needles.astype(np.float32)])
+    md = oracle.mesh_prep(soup[rng.permutation(len(soup))])
+    N, T, depth, me = build(md)
+    assert len(T) > 2000 + 100  # the needles are cut many times
+    check_invariants(md, N, T, depth, me)
+
+
 def check_invariants(md, N, T, depth, max_e12):
-    """What every builder (host bvh.cpp, GPU bvh_device.hip) owes the traversal: bvh.h's contract."""
+    """What every builder (host bvh.cpp, GPU bvh_device.hip) owes the traversal: bvh.h's contract. The host builder may
+    reference a triangle from several leaves (spatial splits), each with the box of the PART of the triangle it covers:
+    boxes nest, and the parts' boxes together cover the triangle."""
     import sys
     sys.setrecursionlimit(10000)
     child = N[:, 24:28].view(np.int32)
@@ -50,16 +71,18 @@ def check_invariants(md, N, T, depth, max_e12):
     want = [i for i in range(n_tested) if not md.is_padding[i]]   # triangle.rs:166-167, :400
     idx = T[:, 9].view(np.uint32)
     real = idx != 0xFFFFFFFF
-    assert sorted(idx[real].tolist()) == want                      # every returnable triangle exactly once
+    assert sorted(set(idx[real].tolist())) == want                 # every returnable triangle, and nothing else
+    assert real.sum() <= len(want) + int(0.30 * len(want)) + 1     # duplicated references within the budget (bvh.h kSpatialBudget)
     for i in np.nonzero(real)[0]:                                  # records are bit copies of the SoA streams
         j = idx[i]
         assert T[i, 0] == md.arrays["v0x"][j] and T[i, 4] == md.arrays["e1y"][j] and T[i, 8] == md.arrays["e2z"][j]
-    tlo, thi = tri_boxes(T)
     e12 = np.linalg.norm(T[:, 3:6], axis=1) * np.linalg.norm(T[:, 6:9], axis=1)
     assert depth <= 20 and len(N) >= 1
+    leaf_boxes = {}  # reference index -> boxes of the leaves that hold it
 
     def check(node, d):
-        """returns (lo, hi, e12) of everything below `node`; asserts the stored child boxes contain it"""
+        """returns (lo, hi, e12) of everything below `node`: the union of its stored child boxes, which the parent's box
+        of this node has to contain"""
         assert d <= depth
         lo_all, hi_all, e_all = np.full(3, np.inf), np.full(3, -np.inf), 0.0
         for k in range(4):
@@ -71,25 +94,46 @@ def check_invariants(md, N, T, depth, max_e12):
             bhi = N[node, [12 + k, 16 + k, 20 + k]]
             if c >= 0:
                 lo, hi, e = check(c, d + 1)
+                assert (blo <= lo).all() and (bhi >= hi).all()
             else:
                 first, cnt = (~c) >> LEAF_BITS, ((~c) & (LEAF_MAX - 1)) + 1
-                lo, hi = tlo[first:first + cnt].min(0), thi[first:first + cnt].max(0)
                 e = e12[first:first + cnt].max()
                 assert (np.diff(idx[first:first + cnt].astype(np.int64)) > 0).all()  # ascending index inside a leaf
-            assert (blo <= lo).all() and (bhi >= hi).all()
+                for j in idx[first:first + cnt]:
+                    if j != 0xFFFFFFFF:
+                        leaf_boxes.setdefault(int(j), []).append((blo.astype(np.float64), bhi.astype(np.float64)))
             assert N[node, 28 + k] >= e * (1 - 1e-6)
             lo_all, hi_all, e_all = np.minimum(lo_all, blo), np.maximum(hi_all, bhi), max(e_all, N[node, 28 + k])
         return lo_all, hi_all, e_all
 
     check(0, 0)
+    # coverage: points of every triangle (corners, edge points, interior points) lie in the box of a leaf that references it
+    first_rec = {}
+    for i in np.nonzero(real)[0]:
+        first_rec.setdefault(int(idx[i]), i)
+    bary = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [.5, .5, 0], [0, .5, .5], [.5, 0, .5], [1 / 3, 1 / 3, 1 / 3], [.8, .1, .1], [.1, .8, .1],
+                     [.1, .1, .8], [.25, .75, 0], [0, .25, .75], [.75, 0, .25], [.6, .3, .1], [.05, .5, .45]])
+    for j, boxes in leaf_boxes.items():
+        r = T[first_rec[j]]
+        v0 = r[0:3].astype(np.float32)
+        v1, v2 = (v0 + r[3:6].astype(np.float32)).astype(np.float64), (v0 + r[6:9].astype(np.float32)).astype(np.float64)
+        pts = bary[:, :1] * v0.astype(np.float64) + bary[:, 1:2] * v1 + bary[:, 2:3] * v2
+        tol = 1e-5 * (np.abs(pts).max() + 1e-30)
+        inside = np.zeros(len(pts), bool)
+        for (lo, hi) in boxes:
+            inside |= ((pts >= lo - tol) & (pts <= hi + tol)).all(1)
+        assert inside.all(), (j, len(boxes))
 
 
-def test_bvh_culling_keeps_the_brute_force_winner(oracle):
+@pytest.mark.parametrize("kind", ["smooth", "rough"])
+def test_bvh_culling_keeps_the_brute_force_winner(oracle, kind):
     """CPU walk of the BVH with the kernel's pad formula: the scan's winning triangle (oracle) is always
     among the triangles of the leaves the walk reaches, for rays from near and far, unit and non-unit."""
-    sc = scenes.example_scene(oracle, 3001)
+    sc = scenes.example_scene(oracle, 3001, kind=kind)
     md = sc.meshes[0]
     N, T, _, _ = build(md)
+    if kind == "rough":  # (the case spatial splits are for: some references must have been duplicated)
+        assert len(T) > len(np.unique(T[:, 9].view(np.uint32)))
     child = N[:, 24:28].view(np.int32)
     idx = T[:, 9].view(np.uint32)
     rng = np.random.default_rng(3)
