@@ -3,7 +3,7 @@
 # process (tools/endsweep.py, default knobs), alternating for PASSES passes. usage: tools/ab_variants.sh TAG name1 [name2 ...]
 set -o pipefail
 TAG=$1; shift
-O=gpurun_out/r4; mkdir -p $O; : > $O/ab_$TAG.log
+O=gpurun_out/${RDIR:-r5}; mkdir -p $O; : > $O/ab_$TAG.log
 for pass in $(seq 1 ${PASSES:-2}); do
   for n in product "$@"; do
     lib=rbrt_amd/lib/librbrt_hip.so; [ "$n" != product ] && lib=rbrt_amd/lib/variants/librbrt_hip_$n.so

@@ -35,6 +35,7 @@ def main():
     finally:
         os.dup2(saved, 1)
     scene = rbrt_amd.HipScene(hs)
+    scene.refine_wait(300.0)  # (measured on the tree a handle goes on with: api.cpp struct Refine)
     info = scene.info()
     t = scene.primary_cull(hs.camera)
     n = t.size

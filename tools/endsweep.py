@@ -104,6 +104,7 @@ def main():
                     else:
                         os.environ[k] = val
             scene = rbrt_amd.HipScene(hs)
+            scene.refine_wait(300.0)  # (measured on the tree a handle goes on with: api.cpp struct Refine)
             for w in worlds:
                 opts = abi.default_opts(spp=args.spp, seed=1, tile_rank=0, tile_world=w)
                 if "DEPTH" in pseudo:

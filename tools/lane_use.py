@@ -38,6 +38,7 @@ def main():
     finally:
         os.dup2(saved, 1)
     scene = rbrt_amd.HipScene(hs)
+    scene.refine_wait(300.0)  # (measured on the tree a handle goes on with: api.cpp struct Refine)
     img = torch.empty((args.height, args.width, 3), dtype=torch.float32, device="cuda")
     so = abi.default_opts(spp=args.spp, seed=1, tile_rank=0, tile_world=args.world, flags=abi.FLAG_COLLECT_STATS)
     scene.render_device(hs.camera, so, img.data_ptr(), None, torch.cuda.current_stream().cuda_stream)

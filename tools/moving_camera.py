@@ -36,6 +36,7 @@ def main():
     finally:
         os.dup2(saved, 1)
     scene = rbrt_amd.HipScene(hs)
+    scene.refine_wait(300.0)  # (measured on the tree a handle goes on with: api.cpp struct Refine)
     opts = abi.default_opts(spp=50, seed=1)
     img = torch.empty((768, 1024, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream

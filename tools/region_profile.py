@@ -45,6 +45,7 @@ def main():
     finally:
         os.dup2(saved, 1)
     scene = rbrt_amd.HipScene(hs)
+    scene.refine_wait(300.0)  # (measured on the tree a handle goes on with: api.cpp struct Refine)
     scene.set_pipeline(1)
     print("# scene:", scene.info())
     world = args.emulate_rank_of or 1

@@ -31,6 +31,7 @@ def main():
     finally:
         os.dup2(saved, 1)
     scene = rbrt_amd.HipScene(host_scene, device=0)
+    scene.refine_wait(300.0)  # (measured on the tree a handle goes on with: api.cpp struct Refine)
     stream = torch.cuda.current_stream().cuda_stream
     a = torch.randn(512, 512, device="cuda")
     b = torch.randn(512, 512, device="cuda")
