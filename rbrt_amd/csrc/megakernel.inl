@@ -46,9 +46,6 @@ enum { RBRT_REGIONS(RBRT_REGION_ENUM) kNumRegions };
 #ifndef RBRT_SPHERE_BOUND
 #define RBRT_SPHERE_BOUND 1  // the triangle search of a ray that has hit a sphere starts at that hit's distance
 #endif
-#ifndef RBRT_MESH_SHORTCUT
-#define RBRT_MESH_SHORTCUT 1  // a mesh none of whose triangles a ray can hit (|d| max|e1||e2| < eps) is not walked for it
-#endif
 #ifndef RBRT_MK_WAVES_PER_SIMD
 #define RBRT_MK_WAVES_PER_SIMD 4  // register budget: 512 / 4 = 128 VGPRs per lane
 #endif
@@ -86,10 +83,9 @@ __device__ __forceinline__ uint32_t pack_meta(uint32_t depth, uint32_t nrec, int
 constexpr uint32_t kSphDw = sizeof(DevSphere) / 4, kMatDw = sizeof(DevMaterial) / 4, kMeshDw = sizeof(DevMesh) / 4;
 constexpr uint32_t kTriDw = sizeof(DevTriangle) / 4;  // v0, e0, e1, normal
 static_assert(sizeof(DevSphere) == 16 && sizeof(DevMaterial) == 20 && sizeof(DevMesh) == 80, "LDS scene table layout");
-enum { MD_NODES = 0, MD_TRIS = 2, MD_NORMALS = 4, MD_BBOX_LO = 6, MD_BBOX_HI = 9, MD_CENTER = 12, MD_RADIUS = 15, MD_MAX_E12 = 16 };
+enum { MD_NODES = 0, MD_TRIS = 2, MD_NORMALS = 4, MD_BBOX_LO = 6, MD_BBOX_HI = 9, MD_CENTER = 12, MD_RADIUS = 15 };
 static_assert(offsetof(DevMesh, tris) == 8 && offsetof(DevMesh, normals) == 16 && offsetof(DevMesh, bbox_lo) == 24 &&
-                  offsetof(DevMesh, bbox_hi) == 36 && offsetof(DevMesh, center) == 48 && offsetof(DevMesh, radius) == 60 &&
-                  offsetof(DevMesh, max_e12) == 64,
+                  offsetof(DevMesh, bbox_hi) == 36 && offsetof(DevMesh, center) == 48 && offsetof(DevMesh, radius) == 60,
               "LDS scene table layout");
 // path-generation parameters in LDS (behind the scene tables), as dword indices
 enum { G_POS = 0, G_RIGHT = 3, G_UP = 6, G_CENTER = 9, G_MMH = 12, G_MMV, G_W, G_H, G_BATCH, G_BATCH_MAGIC, G_TILES_X,
@@ -116,18 +112,9 @@ __device__ __forceinline__ uint32_t next_gated_mesh(const SceneLds& sc, uint32_t
                              ? closest * 1.001f + 0.001f * (1.0f + __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)),
                                                                                   __builtin_fabsf(o.z)))
                              : __builtin_inff();
-    // A mesh none of whose triangles this ray can hit needs no walk: the packet test accepts only |a| >= eps
-    // (triangle.rs:198-200) with a = e1 . (d x e2), and |a| <= |e1||d||e2| (1 + 1e-6) in fp32 whatever the triangle's
-    // position -- so when |d| * max |e1||e2| of the mesh stays 1 % below eps no triangle of it passes (a finely tessellated
-    // mesh at a small scale: BASELINE config 4's 871,414 triangles at the example scene's scale 45 are all of that kind,
-    // and the reference's image shows no mesh). Squared, so that no root is taken; NaN compares false: the walk decides;
-    // a mesh without a triangle of non-zero size has the threshold +inf.
-    // (the LDS copy of the mesh table holds the threshold on |d|^2 in max_e12's place: 0.98 eps^2 / max_e12^2, kernel start)
-    const float dd = RBRT_MESH_SHORTCUT ? dot(d, d) : 0.0f;
     uint32_t m = m0;
     for (; m < n_meshes; ++m) {
         const float* md = reinterpret_cast<const float*>(sc.mesh + m * kMeshDw);
-        if (RBRT_MESH_SHORTCUT && dd < md[MD_MAX_E12]) continue;
         if (RBRT_FAST_GATE ? bbox_gate_fast(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d, beyond) : bbox_gate(md + MD_BBOX_LO, md + MD_BBOX_HI, o, d)) {
             if (STATS) ++lc.gate;
             break;
@@ -284,14 +271,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         dst += P.n_spheres * kSphDw;
         for (uint32_t i = lane; i < n_obj * kMatDw; i += 64) dst[i] = gm[i];
         dst += n_obj * kMatDw;
-        for (uint32_t i = lane; i < P.n_meshes * kMeshDw; i += 64) {
-            uint32_t w = gh[i];
-            if (i % kMeshDw == uint32_t(MD_MAX_E12)) {  // max |e1||e2| -> the |d|^2 below which no triangle of the mesh can be hit (next_gated_mesh)
-                const float e12 = __uint_as_float(w);
-                w = __float_as_uint(0.98f / ((e12 * P.eps_frac) * (e12 * P.eps_frac)));
-            }
-            dst[i] = w;
-        }
+        for (uint32_t i = lane; i < P.n_meshes * kMeshDw; i += 64) dst[i] = gh[i];
         // what path generation reads (camera, work decomposition): kept in LDS rather than in ~30 SGPRs that the
         // rest of the kernel would have to spill around (the spill code is VALU: v_readlane / v_writelane)
         dst += P.n_meshes * kMeshDw;
