@@ -521,6 +521,8 @@ def main():
             os._exit(4)
 
     # ---- the timed region: K steps, every one with a camera the library has not seen (the tile pass runs every step) ----
+    helpers_issued = [0]  # helper launches of the last timed leg (the library's elastic launches: more waves for launches already running)
+
     def timed_leg(n_warm, n_steps, new_camera):
         for _ in range(n_warm):
             step(new_camera)
@@ -534,6 +536,7 @@ def main():
         el = max_over_ranks(time.perf_counter() - t0)
         tr, rs, nl = scene.kernel_ms()
         mix = scene.launch_mix()  # the grid of a launch depends on what was in flight when it was issued
+        helpers_issued[0] = scene.helper_launches()
         scene.set_timing(False)
         return el, enq, tr, rs, nl, mix
 
@@ -590,6 +593,7 @@ def main():
         gather_probe = guarded(probe)
         gather_mode[0] = "ipc" if gather_probe["ipc"] < gather_probe["rccl"] else "rccl"
     elapsed, enqueue_s, trace_ms, resolve_ms, n_launches, (mix_full, mix_half) = guarded(lambda: timed_leg(args.warmup, args.steps, True))
+    helpers_timed = helpers_issued[0]
     scene.check()  # a NaN sphere discriminant (sphere.rs:33 panics) or corrupt path state fails the run loudly
     # per-rank split of a step (N > 1): spans on this rank's streams, means over the timed steps
     phases = None
@@ -848,6 +852,9 @@ def main():
                    "pipeline": pipeline_note(args.pipeline),
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                    "launch_mix_timed_region": {"full_grid": mix_full, "half_grid": mix_half},
+                   # (the library's elastic launches: when the caller stops issuing and the launches in flight leave wave slots
+                   # free -- the end of the timed region's stream --, a watcher thread gives them more waves: helper launches)
+                   "helper_launches_timed_region": helpers_timed,
                    # which tiles the trace kernel never sees (DESIGN.md "The tile pass"): every sample of theirs is still
                    # produced -- by sky_resolve_kernel, inside the timed region -- and counted in `value`
                    "tile_pass": tile_pass,

@@ -25,7 +25,10 @@
  *   RBRT_TILE_TAIL_DIV=1..1024   mode 4: the share of the work list (1/n, 8) that is handed out last, from light tiles
  *   RBRT_OVERLAP_WAVES_PER_CU=0..16  waves per CU of a launch of a stream (0: 24 / launches side by side, rounded up, and
  *                                4 instead of 3 for a launch of 8 M work items or more)
- *   RBRT_TRACE_LAUNCHES=1        one stderr line per trace launch and per tile pass (which lane, grid, table set)
+ *   RBRT_TRACE_LAUNCHES=1        one stderr line per trace launch, tile pass and helper launch (which lane, grid, table set)
+ *   RBRT_HELPERS=0|1|2           helper launches (elastic launches): never, by the watcher (1), one with every overlapped launch (tests)
+ *   RBRT_BVH_SPATIAL=0..0.3      the host builder's budget of duplicated references (spatial splits), as a share of the triangles
+ *   RBRT_TRACE_CREATE=1          one stderr line per rbrt_hip_scene_create: where its time went
  */
 #ifndef RBRT_HIP_DEBUG_H
 #define RBRT_HIP_DEBUG_H
@@ -122,6 +125,10 @@ int rbrt_hip_scene_kernel_ms(rbrt_hip_scene_t* scene, float* trace_ms_total, flo
 /* Trace launches since set_timing(scene, 1), by grid: the full grid, or the part of the wave slots a launch of a stream
  * takes (rbrt_hip_scene_set_pipeline; "half" is round 2's name for it), so the mix depends on host timing. */
 int rbrt_hip_scene_launch_mix(rbrt_hip_scene_t* scene, uint32_t* n_full_grid, uint32_t* n_half_grid);
+
+/* Helper launches since set_timing(scene, 1): more waves given to launches already running when the GPU has room and the
+ * caller has stopped issuing (api.cpp "Elastic launches"; lab knob RBRT_HELPERS=0|1|2: never, automatic, with every launch). */
+int rbrt_hip_scene_helper_launches(rbrt_hip_scene_t* scene, uint32_t* n);
 
 /* Where the wall-clock time of rbrt_hip_scene_create (and, for the one-shot rbrt_hip_render, of the whole call) went, in
  * seconds. The parts of create_s: hip_init_s + upload_s + bvh_build_s + lanes_s (+ a remainder of validation and small

@@ -108,6 +108,12 @@ class HipScene:
         abi.check(self._lib.rbrt_hip_scene_launch_mix(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def helper_launches(self) -> int:
+        """Helper launches since set_timing(True) (rbrt_hip_scene_helper_launches)."""
+        n = C.c_uint32()
+        abi.check(self._lib.rbrt_hip_scene_helper_launches(self._h, C.byref(n)))
+        return n.value
+
     def create_times(self) -> dict:
         """Where the time of rbrt_hip_scene_create went (rbrt_hip_scene_create_times)."""
         t = abi.CallTimes()

@@ -182,6 +182,7 @@ DEBUG_SYMBOLS = {
     "rbrt_hip_debug_scatter": (C.c_int, [C.POINTER(Material), f32p, f32p, f32p, C.POINTER(C.c_uint32), C.c_size_t, f32p, u8p,
                                         C.POINTER(C.c_uint32)]),
     "rbrt_hip_debug_primary_cull": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(C.c_uint32), C.c_size_t]),
+    "rbrt_hip_scene_helper_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rbrt_hip_scene_create_times": (C.c_int, [C.c_void_p, C.POINTER(CallTimes)]),
     "rbrt_hip_last_render_times": (C.c_int, [C.POINTER(CallTimes)]),
     "rbrt_hip_scene_refine_wait": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]),

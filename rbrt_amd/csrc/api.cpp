@@ -9,8 +9,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,6 +25,7 @@
 namespace rbrt {
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats, bool share,
                                    hipStream_t stream);
+hipError_t launch_trace_helper(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool share, hipStream_t stream);
 size_t megakernel_gseq_bytes(uint32_t n_waves, uint32_t pool);
 size_t megakernel_gstack_bytes(uint32_t n_waves);
 size_t megakernel_lds_bytes(uint32_t pool, uint32_t stack_entries, uint32_t n_spheres, uint32_t n_meshes, uint32_t n_elem_tris);
@@ -179,8 +182,31 @@ struct rbrt_hip_scene {
         size_t tile_cull_words = 0, tile_lists_words = 0;
         hipEvent_t ev_traced = nullptr;
         bool in_use = false;  // ev_traced has been recorded at least once
+        // Elastic launches (below): the lane's helper words on the device ([0] helper waves holding work, [1] number of the
+        // last resolved launch), the number of its last launch, the stream and event of its helper launches, and what the
+        // watcher needs to issue one for the launch in flight.
+        uint32_t* d_helper_words = nullptr;
+        uint32_t seq = 0;
+        hipStream_t helper_stream = nullptr;
+        hipEvent_t ev_helper = nullptr;
+        bool helper_pending = false;  // a helper launch has been issued since the lane's last launch: the next one waits for it
+        hipEvent_t ev_ready = nullptr;  // recorded on the lane's stream in front of every launch: everything the launch waits for has happened
+        struct Open {                   // the lane's launch in flight, as the watcher needs it
+            bool valid = false;
+            TraceParams P;
+            uint32_t grid = 0, helper_waves = 0, rounds = 0;
+            bool share = false;
+        } open;
     };
     std::vector<Lane> lanes;
+    // Elastic launches: the watcher thread and what it shares with the caller's thread.
+    std::mutex mu;                 // the caller's thread holds it inside every render call, the watcher while it looks and issues
+    std::condition_variable cv;
+    std::thread watcher;
+    bool watcher_stop = false;
+    double last_call_s = 0.0;      // when the caller last issued a launch
+    uint32_t helpers_mode = 1;     // RBRT_HELPERS (lab): 0 never, 1 when the GPU has room and the caller has stopped issuing, 2 with every launch (tests)
+    uint32_t n_helper_launches = 0;  // since set_timing(1)
     hipStream_t prep_stream = nullptr;  // high priority: the tile passes of cameras the lanes have not seen
     uint64_t launch_no = 0;
     bool streaming_hint = false;  // the last trace launch was issued while another one was still running
@@ -517,6 +543,10 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
             B.d_work_counter = static_cast<unsigned long long*>(p);
             HIP_TRY(hipMemcpy(p, zeros, counter_bytes, hipMemcpyHostToDevice));
         }
+        HIP_TRY(hipMalloc(&p, 64));
+        s->allocs.push_back(p);
+        L.d_helper_words = static_cast<uint32_t*>(p);
+        HIP_TRY(hipMemcpy(p, zeros, 64, hipMemcpyHostToDevice));
         // the lane is recorded before its stream and events exist, so that a failure below leaves them to
         // rbrt_hip_scene_destroy instead of leaking them (a lane without a stream is never selected: the caller
         // gets the error)
@@ -529,11 +559,17 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: low >= high)
         if (const char* pe = lab_env("RBRT_LANE_PRIORITY")) prio_low = !std::strcmp(pe, "default") ? 0 : !std::strcmp(pe, "high") ? prio_high : prio_low;
         hipError_t e = hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, prio_low);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&R.helper_stream, hipStreamNonBlocking, prio_low);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_helper, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_traced, hipEventDisableTiming);
         for (auto& B : R.bufs)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&B.ev_resolved, hipEventDisableTiming);
         if (e != hipSuccess) {
             if (R.stream) (void)hipStreamDestroy(R.stream);
+            if (R.helper_stream) (void)hipStreamDestroy(R.helper_stream);
+            if (R.ev_helper) (void)hipEventDestroy(R.ev_helper);
+            if (R.ev_ready) (void)hipEventDestroy(R.ev_ready);
             if (R.ev_traced) (void)hipEventDestroy(R.ev_traced);
             for (auto& B : R.bufs)
                 if (B.ev_resolved) (void)hipEventDestroy(B.ev_resolved);
@@ -543,6 +579,82 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
     }
     (void)had;  // (the counters were zeroed by blocking copies: nothing of the new lanes is in flight)
     return RBRT_OK;
+}
+
+// ---- Elastic launches ------------------------------------------------------------------------------------------------
+// A launch's grid is fixed when it is issued -- a part of the wave slots while launches overlap (grid_for) -- but whether
+// the GPU stays full is decided later: when the caller stops issuing (the end of a stream of frames; an application that
+// keeps only two or three frames in flight) the launches still running keep their part of an emptying GPU: 3.5 ms of the
+// 70 ms that twenty frames between two fences take (profiles/r04_trace_frames.txt). The kernel hands its work out from
+// counters in memory, so a launch can be given more waves at any time: a HELPER launch of the same kernel with the same
+// parameters draws from the same counters into the same sample buffer. What has to be arranged is that nobody reads the
+// samples before a helper wave that holds some has written them, and that a helper wave arriving after the launch is over
+// takes nothing from counters that by then belong to the lane's next launch:
+//   * a helper wave adds itself to helper_words[0] BEFORE its first draw and leaves after its last store (release); the
+//     launch's resolve, which runs after the launch itself has ended -- nobody can draw any more --, waits for the count to
+//     return to zero (bounded; megakernel.inl, kernels.hip resolve_kernel);
+//   * the resolve then publishes the launch's number in helper_words[1] and only then resets the counters; a helper
+//     wave draws only while the published number is still the PREVIOUS launch's. One that looked just before the number
+//     changed may take one more chunk from the reset counters: it renders samples of its own launch once more -- the same
+//     bits -- into a buffer nobody else writes, because the lane's next launch waits for the helper LAUNCH to end
+//     (ev_helper) and zeroes the counters again before it starts.
+// Who issues them: a watcher thread (one per scene handle that has seen a stream of calls), which every 100 us retires
+// the launches that have ended and, once the caller has not issued anything for 200 us and the launches in flight leave a
+// wave per CU or more free, gives the free slots to them -- up to three rounds per launch as others end. The launch itself
+// is untouched (the helper is a build of its own), so a stream in full flow pays nothing. RBRT_HELPERS (lab): 0 off, 2 =
+// a helper with EVERY overlapped launch (tests: the protocol under every scene of the suite).
+int issue_helper(rbrt_hip_scene* s, rbrt_hip_scene::Lane& L, uint32_t waves) {
+    if (!L.open.valid || waves == 0u || L.open.grid + L.open.helper_waves + waves > s->scratch_waves) return RBRT_OK;
+    HIP_TRY(hipStreamWaitEvent(L.helper_stream, L.ev_ready, 0));  // (what the launch waited for: the resolve before it, its tables)
+    TraceParams P = L.open.P;
+    P.wave_base = L.open.grid + L.open.helper_waves;
+    HIP_TRY(launch_trace_helper(P, waves, s->pool, L.open.share, L.helper_stream));
+    HIP_TRY(hipEventRecord(L.ev_helper, L.helper_stream));
+    L.helper_pending = true;
+    L.open.helper_waves += waves, L.open.rounds += 1u;
+    s->n_helper_launches += 1u;
+    if (s->trace_launches) std::fprintf(stderr, "[rbrt_hip] helper launch: lane %u, %u waves behind %u\n", unsigned(&L - s->lanes.data()), waves, P.wave_base);
+    return RBRT_OK;
+}
+
+void watcher_main(rbrt_hip_scene* s) {
+    (void)hipSetDevice(s->device);
+    std::unique_lock<std::mutex> lk(s->mu);
+    while (!s->watcher_stop) {
+        bool any = false;
+        for (const auto& L : s->lanes) any = any || L.open.valid;
+        if (!any) {
+            s->cv.wait(lk);
+            continue;
+        }
+        lk.unlock();
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+        lk.lock();
+        if (s->watcher_stop) break;
+        uint32_t n_open = 0, resident = 0;
+        for (auto& L : s->lanes) {
+            if (!L.open.valid) continue;
+            const hipError_t q = hipEventQuery(L.ev_traced);
+            if (q == hipErrorNotReady) {
+                (void)hipGetLastError();
+                ++n_open, resident += L.open.grid + L.open.helper_waves;
+            } else {
+                L.open.valid = false;  // (ended, or an error the caller's next call will meet)
+            }
+        }
+        if (n_open == 0u || now_s() - s->last_call_s < 200e-6) continue;
+        const uint32_t free_waves = s->n_waves > resident ? s->n_waves - resident : 0u;
+        if (free_waves < s->n_cus) continue;
+        uint32_t per = (free_waves / n_open) / s->n_cus * s->n_cus;
+        if (per == 0u) per = s->n_cus;
+        uint32_t left = free_waves;
+        for (auto& L : s->lanes) {
+            if (!L.open.valid || L.open.rounds >= 3u || left < s->n_cus) continue;
+            const uint32_t w = per < left ? per : left / s->n_cus * s->n_cus;
+            if (issue_helper(s, L, w) != RBRT_OK) break;  // (the caller's next call reports what is wrong with the device)
+            left -= w;
+        }
+    }
 }
 
 // Switches the scene over to the background thread's trees once they are on the device (struct Refine). Launches issued
@@ -949,7 +1061,8 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
             lab_u32("RBRT_POISON_SAMPLES", 0, 1, poison, err) && lab_u32("RBRT_PRIMARY_CULL", 0, 1, s->primary_cull, err) &&
             lab_u32("RBRT_TILE_ORDER", 0, 2, s->tile_order, err) && lab_u32("RBRT_TILE_CLASSES", 0, 4, s->tile_classes, err) &&
             lab_u32("RBRT_OVERLAP_WAVES_PER_CU", 0, 16, s->overlap_waves_per_cu, err) &&
-            lab_u32("RBRT_TILE_ISOLATED_MODE", 0, 4, s->isolated_list_mode, err) && lab_u32("RBRT_TILE_TAIL_DIV", 1, 1024, s->tile_tail_div, err);
+            lab_u32("RBRT_TILE_ISOLATED_MODE", 0, 4, s->isolated_list_mode, err) && lab_u32("RBRT_TILE_TAIL_DIV", 1, 1024, s->tile_tail_div, err) &&
+            lab_u32("RBRT_HELPERS", 0, 2, s->helpers_mode, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
         s->tile_classes_set = lab_env("RBRT_TILE_CLASSES") != nullptr;
         s->trace_launches = lab_env("RBRT_TRACE_LAUNCHES") != nullptr;
@@ -968,7 +1081,9 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
         s->n_waves = uint32_t(cus * per_cu);
         s->n_cus = uint32_t(cus);
         s->hw_queues = g_hw_queues_at_load;
-        s->scratch_waves = s->n_waves;  // per-wave scratch is indexed by workgroup (= wave); no grid is larger than n_waves
+        // per-wave scratch is indexed by workgroup (= wave): no grid is larger than n_waves; two more waves per CU for helper
+        // launches behind a full grid (a blocking caller's launch under RBRT_HELPERS=2)
+        s->scratch_waves = s->n_waves + 2u * s->n_cus;
         // lanes up front: rbrt_hip_render_device then never allocates lanes (which synchronises the device); a one-shot
         // call makes the lanes its batches will use (rbrt_hip_render)
         const double t_lanes0 = now_s();
@@ -1011,6 +1126,14 @@ extern "C" {
 int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     if (!s) return RBRT_OK;
     (void)hipSetDevice(s->device);
+    if (s->watcher.joinable()) {  // (before anything it looks at goes away)
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            s->watcher_stop = true;
+        }
+        s->cv.notify_all();
+        s->watcher.join();
+    }
     if (Refine* r = s->refine.get()) {  // a background build nobody will use: cancelled, its allocations released
         r->cancel.store(true);
         if (r->th.joinable()) r->th.join();
@@ -1020,6 +1143,9 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     (void)hipDeviceSynchronize();  // lane streams included
     for (auto& L : s->lanes) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.helper_stream) (void)hipStreamDestroy(L.helper_stream);
+        if (L.ev_helper) (void)hipEventDestroy(L.ev_helper);
+        if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_traced) (void)hipEventDestroy(L.ev_traced);
         for (auto& B : L.bufs) {
             if (B.ev_resolved) (void)hipEventDestroy(B.ev_resolved);
@@ -1042,10 +1168,12 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
 
 int rbrt_hip_scene_set_timing(rbrt_hip_scene_t* s, int enable) {
     if (!s) return fail(RBRT_ERR_INVALID_ARG, "null scene");
+    std::lock_guard<std::mutex> watcher_lock(s->mu);
     s->timing = enable != 0;
     s->timing_overflow = false;
     s->events_used = 0;
     s->n_full_grid = s->n_half_grid = 0;
+    s->n_helper_launches = 0;
     return RBRT_OK;
 }
 
@@ -1055,6 +1183,14 @@ int rbrt_hip_scene_launch_mix(rbrt_hip_scene_t* s, uint32_t* n_full_grid, uint32
     if (!s) return fail(RBRT_ERR_INVALID_ARG, "null scene");
     if (n_full_grid) *n_full_grid = s->n_full_grid;
     if (n_half_grid) *n_half_grid = s->n_half_grid;
+    return RBRT_OK;
+}
+
+// Helper launches (api.cpp "Elastic launches") issued since set_timing(1).
+int rbrt_hip_scene_helper_launches(rbrt_hip_scene_t* s, uint32_t* n) {
+    if (!s || !n) return fail(RBRT_ERR_INVALID_ARG, "helper_launches: null argument");
+    std::lock_guard<std::mutex> watcher_lock(s->mu);
+    *n = s->n_helper_launches;
     return RBRT_OK;
 }
 
@@ -1096,6 +1232,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     const uint32_t world = o->tile_world ? o->tile_world : 1;
     if (o->tile_rank >= world) return fail(RBRT_ERR_INVALID_ARG, "tile_rank >= tile_world");
     HIP_TRY(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> watcher_lock(s->mu);  // (the watcher of elastic launches looks at the lanes between calls, not during one)
     adopt_refined(s);  // (the background thread's trees, once they are on the device: this call's launches use them)
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
 
@@ -1126,7 +1263,10 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     if (int rc = ensure_lanes(s, depth)) return rc;
     const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
         HIP_TRY(hipStreamSynchronize(stream));
-        for (auto& L : s->lanes) HIP_TRY(hipStreamSynchronize(L.stream));
+        for (auto& L : s->lanes) {
+            HIP_TRY(hipStreamSynchronize(L.stream));
+            if (L.helper_stream) HIP_TRY(hipStreamSynchronize(L.helper_stream));
+        }
         return RBRT_OK;
     };
     if (!acc && per_sample > s->acc_bytes) {
@@ -1323,6 +1463,16 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         } else if (depth > 1) {
             if (int rc = sync_lanes()) return rc;  // a counting launch: nothing else in flight
         }
+        L.open.valid = false;  // (the launch the watcher knew on this lane is being followed by another: no stream has ended)
+        if (L.helper_pending) {
+            // a helper launch joined the lane's last launch: its last waves may have drawn from the counters after that
+            // launch's resolve had reset them (api.cpp "Elastic launches") -- this launch starts behind the helper launch, on
+            // counters zeroed again
+            static const unsigned long long zeros[kWorkShards * kWorkCounterStride] = {};
+            HIP_TRY(hipStreamWaitEvent(ts, L.ev_helper, 0));
+            HIP_TRY(hipMemcpyAsync(B.d_work_counter, zeros, sizeof(zeros), hipMemcpyHostToDevice, ts));
+            L.helper_pending = false;
+        }
         P.sample_base = base;
         P.batch = nb;
         P.batch_magic = div_magic_of(nb);
@@ -1349,6 +1499,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         P.work_counter = B.d_work_counter;
         P.gseq = L.d_gseq;
         P.gstack = L.d_gstack;
+        P.helper_words = L.d_helper_words, P.helper_seq = ++L.seq, P.wave_base = 0u;
         // which of the lane's two sets of tile tables this launch reads: the one made for this camera and partition, else
         // the one used longer ago, filled now
         rbrt_hip_scene::Lane::TileSet* S = nullptr;
@@ -1395,7 +1546,14 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         if (S) HIP_TRY(hipStreamWaitEvent(ts, S->ev_lists, 0));  // (the set's tables: made on the prep stream, or at the first call on the caller's)
         const uint32_t grid = stats ? s->n_waves : grid_for(s, overlapped, depth, call_streams, company, P.n_items);
         (grid < s->n_waves ? s->n_half_grid : s->n_full_grid) += 1;
-        HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, s->share_idle != 0u && P.n_items < s->share_below, ts));
+        const bool share_build = s->share_idle != 0u && P.n_items < s->share_below;
+        if (piped) HIP_TRY(hipEventRecord(L.ev_ready, ts));  // (behind everything the launch waits for: a helper launch waits for this)
+        HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, share_build, ts));
+        if (piped && s->pool == 128u && s->helpers_mode != 0u) {
+            L.open.valid = true, L.open.P = P, L.open.grid = grid, L.open.helper_waves = 0u, L.open.rounds = 0u, L.open.share = share_build;
+            if (s->helpers_mode == 2u)
+                if (int rc = issue_helper(s, L, s->n_cus)) return rc;
+        }
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
         R.sample_buf = B.d_sample_buf;
         R.work_counter = B.d_work_counter;
@@ -1404,6 +1562,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         R.last_batch = base + nb == o->spp;
         R.tile_lists = P.tile_lists;
         R.counters = stats ? s->d_counters : nullptr;
+        R.helper_words = P.helper_words, R.helper_seq = P.helper_seq;
+        R.error_flag = &s->d_counters->diag[57];
         if (piped) {
             HIP_TRY(hipEventRecord(L.ev_traced, ts));
             L.in_use = true;
@@ -1428,6 +1588,17 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             s->events_used = ev0 + 3 * (b + 1);
         }
     }
+    // the watcher of elastic launches: started by the first call of a stream, woken when there is a launch to look after
+    s->last_call_s = now_s();
+    if (s->helpers_mode == 1u && depth > 1 && !stats) {
+        if (!s->watcher.joinable() && streams_now) {
+            try {
+                s->watcher = std::thread(watcher_main, s);
+            } catch (...) {  // (no thread to be had: launches stay the size they were issued with)
+            }
+        }
+        s->cv.notify_one();
+    }
     return RBRT_OK;
 }
 
@@ -1446,6 +1617,7 @@ int rbrt_hip_scene_set_pipeline(rbrt_hip_scene_t* s, uint32_t depth) {
     if (!s) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: null scene");
     if (depth > kMaxPipeline) return fail(RBRT_ERR_INVALID_ARG, "set_pipeline: depth must be 0 (automatic) or 1..8");
     HIP_TRY(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> watcher_lock(s->mu);
     HIP_TRY(hipDeviceSynchronize());
     s->pipeline = depth;
     s->next_lane = 0;

@@ -161,6 +161,13 @@ struct TraceParams {
     uint32_t tile_list_mode;  // order of the work list (tile_lists_kernel)
     uint32_t tile_tail_div;   // mode 4: the last n_work / this light tiles of the row-major order are handed out at the very end
     uint32_t tile_lists_wide;  // 1: tile_lists_kernel as four waves (a launch that has the GPU to itself); 0: as one wave
+    // Helper launches (api.cpp "Elastic launches"): a second launch of the kernel that joins THIS launch's work -- same work
+    // counters, same sample buffer -- when the GPU has room for more waves than the launch was issued with.
+    // helper_words[0] = helper waves that may be holding work of the lane's launch, [1] = sequence number of the lane's
+    // last launch that has been resolved (its counters are the next launch's by now); helper_seq = this launch's number.
+    uint32_t* helper_words;
+    uint32_t helper_seq;
+    uint32_t wave_base;  // helper launches: first per-wave scratch slot (gseq / gstack) of this launch's waves; 0 for the launch itself
 };
 
 struct ResolveParams {
@@ -176,6 +183,9 @@ struct ResolveParams {
     unsigned long long* work_counter;  // the finished launch's work counters, zeroed here for the lane's next launch
     const uint32_t* tile_lists;        // TraceParams::tile_lists (null: every local tile has samples in sample_buf)
     DevCounters* counters;             // sky_resolve_kernel in a counting launch: its samples and rays; else null
+    uint32_t* helper_words;            // TraceParams::helper_words of the launch this resolves (null: none)
+    uint32_t helper_seq;               // ... and its sequence number, published in helper_words[1]
+    unsigned long long* error_flag;    // DevCounters::diag[57]: raised if helper waves of the launch never finish (bounded wait)
 };
 
 }  // namespace rbrt

@@ -706,8 +706,34 @@ __global__ __launch_bounds__(kSmallBlock) void resolve_kernel(const ResolveParam
     const size_t i = size_t(blockIdx.x) * kSmallBlock + threadIdx.x;
     // the trace launch this resolves has ended: its work counters are reset for the lane's next launch (which
     // waits for this kernel), saving a memset launch that would have to queue behind the resident megakernels
-    if (blockIdx.x == 0)
+    // Helper launches (api.cpp "Elastic launches") may have joined the launch: a helper wave that took work registered in
+    // helper_words[0] before it drew from the counters, and leaves the count only when its samples are written. The launch
+    // itself has ended (stream order), so nobody can TAKE work any more; what is waited for here is the waves that hold
+    // some. Almost always the count is zero already. Bounded: a count that never returns raises the error flag instead of
+    // hanging the GPU (rbrt_hip_scene_check reports it).
+    if (R.helper_words) {
+        if (threadIdx.x == 0) {
+            uint32_t spins = 0;
+            while (__hip_atomic_load(R.helper_words, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1u << 23)) {
+                    atomicAdd(R.error_flag, 1ull);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        // (first the launch's number -- from here on a helper wave of it draws nothing more --, then the counters)
+        if (R.helper_words && threadIdx.x == 0) {
+            __hip_atomic_store(R.helper_words + 1, R.helper_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        __syncthreads();
         for (uint32_t w = threadIdx.x; w < kWorkShards * kWorkCounterStride; w += kSmallBlock) R.work_counter[w] = 0ull;
+    }
     if (i >= npix) return;
     const uint32_t p = uint32_t(i & 63u);
     const uint32_t tile_local = R.tile_lists ? R.tile_lists[kTileListHeader + (i >> 6)] : uint32_t(i >> 6);
@@ -1299,6 +1325,20 @@ int megakernel_occupancy_per_cu(uint32_t pool, size_t lds_bytes) {
 
 // n_waves single-wave workgroups; each loops until the global work counter (zeroed by the caller on
 // this stream) runs out, so any grid size is correct and no wave ever waits on another.
+// A helper launch (api.cpp "Elastic launches"): more waves for a launch that is already running -- the same parameters
+// (work counters, sample buffer, tables), scratch slots from P.wave_base on.
+hipError_t launch_trace_helper(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool share, hipStream_t stream) {
+    if (P.n_items == 0 || n_waves == 0 || !P.helper_words) return hipSuccess;
+    const size_t lds = megakernel_lds_bytes(pool, P.stack_entries, P.n_spheres, P.n_meshes, P.n_elem_tris);
+    if (pool == 128 && share)
+        hipLaunchKernelGGL((trace_megakernel<128, false, true, true>), dim3(n_waves), dim3(64), lds, stream, P);
+    else if (pool == 128)
+        hipLaunchKernelGGL((trace_megakernel<128, false, false, true>), dim3(n_waves), dim3(64), lds, stream, P);
+    else
+        return hipErrorInvalidValue;  // (the lab's 256-slot pool has no helper build)
+    return hipGetLastError();
+}
+
 hipError_t launch_trace_megakernel(const TraceParams& P, uint32_t n_waves, uint32_t pool, bool stats, bool share,
                                    hipStream_t stream) {
     if (P.n_items == 0 || n_waves == 0) return hipSuccess;

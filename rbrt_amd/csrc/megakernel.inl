@@ -164,16 +164,26 @@ struct WorkSource {
         if (k >= kWorkShards) return n_chunks * kWorkChunk;
         return uint32_t((uint64_t(n_chunks) * k) / kWorkShards) * kWorkChunk;
     }
+    // HELPER (a helper launch, api.cpp "Elastic launches"): the counters are this launch's only while the lane's last
+    // RESOLVED launch is the one before it -- once this launch's own resolve has published its number the counters have
+    // been handed to the next launch, and a helper wave that arrives late must not draw from them: it sees every shard dry.
+    template <bool HELPER>
     __device__ __forceinline__ void prefetch(const TraceParams& P, uint32_t lane) {
         if (pending) return;
-        if (lane == 0) pend_base = atomicAdd(P.work_counter + shard * kWorkCounterStride, (unsigned long long)kWorkChunk);
+        if (lane == 0) {
+            if (HELPER && __hip_atomic_load(P.helper_words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.helper_seq - 1u)
+                pend_base = ~0ull;
+            else
+                pend_base = atomicAdd(P.work_counter + shard * kWorkCounterStride, (unsigned long long)kWorkChunk);
+        }
         pend_shard = shard;
         pending = true;
     }
     // Blocks until a chunk is in hand: [lo, hi) global items. Returns false when every shard is exhausted.
+    template <bool HELPER>
     __device__ __forceinline__ bool next_chunk(const TraceParams& P, uint32_t lane, uint32_t& lo, uint32_t& hi) {
         for (;;) {
-            prefetch(P, lane);
+            prefetch<HELPER>(P, lane);
             // (lane 0's result, through SGPRs. next_chunk runs in wave-uniform control flow, so the first active lane IS lane 0.)
             const uint32_t l_lo = uni(uint32_t(pend_base)), l_hi = uni(uint32_t(pend_base >> 32));
             const uint32_t ps = uni(pend_shard);
@@ -212,7 +222,7 @@ struct WorkSource {
 // SHAREK: the build of the kernel that can share traversals between lanes in the drain (below). It is a separate
 // build because the second copy of the traversal loop costs the first one 3 % (register allocation at the
 // 128-VGPR limit): launches that are mostly bulk use the build without it.
-template <int POOLN, bool STATS, bool SHAREK>
+template <int POOLN, bool STATS, bool SHAREK, bool HELPER = false>
 __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(const TraceParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t kPoolPad = (uint32_t(POOLN) + 63u) & ~63u;  // census loops run in groups of 64 slots
@@ -252,7 +262,16 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         rt_cur = next;
     };
 #endif
-    uint32_t* const gseq = P.gseq + size_t(blockIdx.x) * uint32_t(POOLN) * kSeqWords;
+    // (a helper launch's waves take the scratch slots behind those of the launch they help)
+    const uint32_t wave_slot = HELPER ? blockIdx.x + P.wave_base : blockIdx.x;
+    uint32_t* const gseq = P.gseq + size_t(wave_slot) * uint32_t(POOLN) * kSeqWords;
+    if (HELPER) {
+        // registered BEFORE the first draw from the counters: a helper wave that holds work is counted in helper_words[0] by
+        // the time the launch's last work item is handed out, and the resolve waits for that count to return to zero
+        uint32_t before = 0u;
+        if (lane == 0) before = __hip_atomic_fetch_add(P.helper_words, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane(int(before)) == -1) return;  // (never: the value is waited for, that is all)
+    }
 #define POOL(f, s) pool[(f) * POOLN + (s)]
 
     for (uint32_t s = lane; s < kPoolPad; s += 64) status[s] = s < uint32_t(POOLN) ? ST_EMPTY : ST_BUSY;  // pad slots never match
@@ -344,7 +363,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
     int32_t t_pend = kNoChild;  // a leaf reached earlier whose triangles have not been tested yet
     int32_t t_pend2 = kNoChild;  // a second one (only ever set while t_pend is)
     // The first P.stack_entries stack slots of a lane live in LDS, deeper ones in this wave's global scratch.
-    uint32_t* const gstack = P.gstack + size_t(blockIdx.x) * kStackMax * 64u + lane;
+    uint32_t* const gstack = P.gstack + size_t(wave_slot) * kStackMax * 64u + lane;
     const uint32_t n_lds_stack = P.stack_entries;
     // (volatile LDS accesses: otherwise the two arms are merged into one access through a selected generic
     // pointer, i.e. a flat_store / flat_load plus a dozen address instructions on the hottest path of the kernel)
@@ -871,7 +890,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                 const uint32_t avail = work.res_end - work.res_next;
                 uint32_t new_lo = 0, new_hi = 0;
                 if (avail < n_want) {
-                    more_work = work.next_chunk(P, lane, new_lo, new_hi);
+                    more_work = work.template next_chunk<HELPER>(P, lane, new_lo, new_hi);
                     // drain_mode bit 3: a wave whose launch has run out of work items issues ahead of the bulk waves of
                     // other launches on its SIMD: the drain is a chain of dependent rounds, the bulk fills the gaps
                     if (!more_work && (P.drain_mode & 8u)) __builtin_amdgcn_s_setprio(2);
@@ -917,7 +936,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                     work.res_next = WorkSource::uni(work.res_next + n_want);
                 }
                 // reserve the next chunk now; its result is not needed before a later TERM pass
-                if (more_work && work.res_end - work.res_next < 64u) work.prefetch(P, lane);
+                if (more_work && work.res_end - work.res_next < 64u) work.template prefetch<HELPER>(P, lane);
             }
         }
         RBRT_MARK(scatter_load);
@@ -1093,6 +1112,10 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         if (STATS) dg_t_shade += __builtin_amdgcn_s_memtime() - dg_tk;
     }
 #undef POOL
+    if (HELPER) {  // this wave's samples are written and visible to the device before it stops counting as a holder of work
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_fetch_sub(P.helper_words, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #if RBRT_REGION_TIMERS
     rt_tick(R_init);
     if (lane < uint32_t(kNumRegions)) atomicAdd(&P.counters->diag[lane], (unsigned long long)rt_acc[lane]);

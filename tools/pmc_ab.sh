@@ -18,7 +18,7 @@ import csv, glob, sys, collections, re
 per = collections.defaultdict(float); nd = collections.defaultdict(set)
 for f in glob.glob(sys.argv[1] + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "trace_megakernel" in r["Kernel_Name"] and re.search(r"<\d+, false", r["Kernel_Name"]):
+        if "trace_megakernel" in r["Kernel_Name"] and re.search(r"<\d+, false, (true|false), false>", r["Kernel_Name"]):
             per[r["Counter_Name"]] += float(r["Counter_Value"]); nd[r["Counter_Name"]].add(r["Dispatch_Id"])
 for k in sorted(per): print(f"{k:32s} {per[k] / max(1, len(nd[k])):.4g}")
 if "SQ_ACTIVE_INST_VALU" in per: print("valu_lane_utilisation", per["SQ_THREAD_CYCLES_VALU"] / (64 * per["SQ_ACTIVE_INST_VALU"]))

@@ -18,7 +18,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ff
        *flags, "-S", "--cuda-device-only", "-o", "/tmp/static_cost.s", str(ROOT / "rbrt_amd/csrc/kernels.hip")]
 subprocess.run(cmd, check=True, capture_output=True, cwd="/tmp")
 text = Path("/tmp/static_cost.s").read_text().splitlines()
-start = next(i for i, l in enumerate(text) if l.startswith("_ZN4rbrt16trace_megakernelILi128ELb0ELb0EEEvNS_11TraceParamsE:"))
+start = next(i for i, l in enumerate(text) if l.startswith("_ZN4rbrt16trace_megakernelILi128ELb0ELb0ELb0EEEvNS_11TraceParamsE:"))
 end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
 # Issue cost of one wave64 instruction in SIMD cycles with four resident waves per SIMD (profiles/r03_valu_rate.txt):
 # full-rate VALU 2, the other VALU ~3.1, transcendental ~6.1, a scalar instruction ~2 (it takes an issue slot: v_fma +

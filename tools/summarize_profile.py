@@ -49,7 +49,7 @@ for f in glob.glob(str(SRC / "*" / "*" / "*counter_collection.csv")):
 for pass_name, f in newest.items():
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "trace_megakernel" not in k or not re.search(r"<\d+, false", k):  # (the build without counters)
+        if "trace_megakernel" not in k or not re.search(r"<\d+, false, (true|false), false>", k):  # (the build without counters)
             continue
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
         ndisp[(k, r["Counter_Name"])].add((pass_name, r["Dispatch_Id"]))  # (a counter collected in two passes: averaged over both)
