@@ -187,8 +187,9 @@ struct rbrt_hip_scene {
         // watcher needs to issue one for the launch in flight.
         uint32_t* d_helper_words = nullptr;
         uint32_t seq = 0;
-        hipStream_t helper_stream = nullptr;
-        hipEvent_t ev_helper = nullptr;
+        hipEvent_t ev_helper = nullptr;   // behind the last helper launch of THIS lane's launch (whatever stream carried it)
+        hipEvent_t ev_carried = nullptr;  // behind the last helper launch this lane's stream carried for another lane
+        bool helper_carried = false;
         bool helper_pending = false;  // a helper launch has been issued since the lane's last launch: the next one waits for it
         hipEvent_t ev_ready = nullptr;  // recorded on the lane's stream in front of every launch: everything the launch waits for has happened
         struct Open {                   // the lane's launch in flight, as the watcher needs it
@@ -208,6 +209,7 @@ struct rbrt_hip_scene {
     uint32_t helpers_mode = 1;     // RBRT_HELPERS (lab): 0 never, 1 when the GPU has room and the caller has stopped issuing, 2 with every launch (tests)
     uint32_t n_helper_launches = 0;  // since set_timing(1)
     hipStream_t prep_stream = nullptr;  // high priority: the tile passes of cameras the lanes have not seen
+    hipStream_t aux_stream = nullptr;   // RBRT_HELPERS=2 (tests): carries the helper launches
     uint64_t launch_no = 0;
     bool streaming_hint = false;  // the last trace launch was issued while another one was still running
     uint32_t pipeline = 0;   // RBRT_PIPELINE / rbrt_hip_scene_set_pipeline; 0 = automatic (depth_for)
@@ -559,16 +561,16 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: low >= high)
         if (const char* pe = lab_env("RBRT_LANE_PRIORITY")) prio_low = !std::strcmp(pe, "default") ? 0 : !std::strcmp(pe, "high") ? prio_high : prio_low;
         hipError_t e = hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, prio_low);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&R.helper_stream, hipStreamNonBlocking, prio_low);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_helper, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_carried, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_traced, hipEventDisableTiming);
         for (auto& B : R.bufs)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&B.ev_resolved, hipEventDisableTiming);
         if (e != hipSuccess) {
             if (R.stream) (void)hipStreamDestroy(R.stream);
-            if (R.helper_stream) (void)hipStreamDestroy(R.helper_stream);
             if (R.ev_helper) (void)hipEventDestroy(R.ev_helper);
+            if (R.ev_carried) (void)hipEventDestroy(R.ev_carried);
             if (R.ev_ready) (void)hipEventDestroy(R.ev_ready);
             if (R.ev_traced) (void)hipEventDestroy(R.ev_traced);
             for (auto& B : R.bufs)
@@ -600,16 +602,21 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
 //     (ev_helper) and zeroes the counters again before it starts.
 // Who issues them: a watcher thread (one per scene handle that has seen a stream of calls), which every 100 us retires
 // the launches that have ended and, once the caller has not issued anything for 200 us and the launches in flight leave a
-// wave per CU or more free, gives the free slots to them -- up to three rounds per launch as others end. The launch itself
+// wave per CU or more free, gives the free slots to them -- up to four rounds per launch as others end --, each helper
+// launch carried by the stream of a lane that has nothing in flight (issue_helper). The launch itself
 // is untouched (the helper is a build of its own), so a stream in full flow pays nothing. RBRT_HELPERS (lab): 0 off, 2 =
 // a helper with EVERY overlapped launch (tests: the protocol under every scene of the suite).
-int issue_helper(rbrt_hip_scene* s, rbrt_hip_scene::Lane& L, uint32_t waves) {
+// `carrier`: the stream the helper launch is issued on. The runtime maps streams onto a few hardware queues and a queue
+// takes its packets in order, so a helper launch on a stream of its own would sit in some lane's queue, behind that lane's
+// launch or in front of its next one; the streams of lanes that have nothing in flight are the queues that are free, and
+// at the end of a stream of frames there are more of them with every launch that ends.
+int issue_helper(rbrt_hip_scene* s, rbrt_hip_scene::Lane& L, uint32_t waves, hipStream_t carrier) {
     if (!L.open.valid || waves == 0u || L.open.grid + L.open.helper_waves + waves > s->scratch_waves) return RBRT_OK;
-    HIP_TRY(hipStreamWaitEvent(L.helper_stream, L.ev_ready, 0));  // (what the launch waited for: the resolve before it, its tables)
+    HIP_TRY(hipStreamWaitEvent(carrier, L.ev_ready, 0));  // (what the launch waited for: the resolve before it, its tables)
     TraceParams P = L.open.P;
     P.wave_base = L.open.grid + L.open.helper_waves;
-    HIP_TRY(launch_trace_helper(P, waves, s->pool, L.open.share, L.helper_stream));
-    HIP_TRY(hipEventRecord(L.ev_helper, L.helper_stream));
+    HIP_TRY(launch_trace_helper(P, waves, s->pool, L.open.share, carrier));
+    HIP_TRY(hipEventRecord(L.ev_helper, carrier));
     L.helper_pending = true;
     L.open.helper_waves += waves, L.open.rounds += 1u;
     s->n_helper_launches += 1u;
@@ -632,26 +639,34 @@ void watcher_main(rbrt_hip_scene* s) {
         lk.lock();
         if (s->watcher_stop) break;
         uint32_t n_open = 0, resident = 0;
+        std::vector<rbrt_hip_scene::Lane*> carriers;
         for (auto& L : s->lanes) {
-            if (!L.open.valid) continue;
-            const hipError_t q = hipEventQuery(L.ev_traced);
-            if (q == hipErrorNotReady) {
-                (void)hipGetLastError();
-                ++n_open, resident += L.open.grid + L.open.helper_waves;
-            } else {
+            if (L.open.valid) {
+                const hipError_t q = hipEventQuery(L.ev_traced);
+                if (q == hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    ++n_open, resident += L.open.grid + L.open.helper_waves;
+                    continue;
+                }
                 L.open.valid = false;  // (ended, or an error the caller's next call will meet)
             }
+            // a lane with nothing in flight: its stream can carry a helper launch (unless it still carries one)
+            if (L.stream && (!L.helper_carried || hipEventQuery(L.ev_carried) == hipSuccess)) carriers.push_back(&L);
+            (void)hipGetLastError();
         }
-        if (n_open == 0u || now_s() - s->last_call_s < 200e-6) continue;
+        if (n_open == 0u || carriers.empty() || now_s() - s->last_call_s < 200e-6) continue;
         const uint32_t free_waves = s->n_waves > resident ? s->n_waves - resident : 0u;
         if (free_waves < s->n_cus) continue;
-        uint32_t per = (free_waves / n_open) / s->n_cus * s->n_cus;
-        if (per == 0u) per = s->n_cus;
+        const uint32_t per = std::max(64u, (free_waves / n_open) / 64u * 64u);
         uint32_t left = free_waves;
         for (auto& L : s->lanes) {
-            if (!L.open.valid || L.open.rounds >= 3u || left < s->n_cus) continue;
-            const uint32_t w = per < left ? per : left / s->n_cus * s->n_cus;
-            if (issue_helper(s, L, w) != RBRT_OK) break;  // (the caller's next call reports what is wrong with the device)
+            if (!L.open.valid || L.open.rounds >= 4u || left < 64u || carriers.empty()) continue;
+            const uint32_t w = per < left ? per : left / 64u * 64u;
+            rbrt_hip_scene::Lane* C = carriers.back();
+            carriers.pop_back();
+            if (issue_helper(s, L, w, C->stream) != RBRT_OK) break;  // (the caller's next call reports what is wrong with the device)
+            if (hipEventRecord(C->ev_carried, C->stream) != hipSuccess) break;
+            C->helper_carried = true;
             left -= w;
         }
     }
@@ -1143,8 +1158,8 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     (void)hipDeviceSynchronize();  // lane streams included
     for (auto& L : s->lanes) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
-        if (L.helper_stream) (void)hipStreamDestroy(L.helper_stream);
         if (L.ev_helper) (void)hipEventDestroy(L.ev_helper);
+        if (L.ev_carried) (void)hipEventDestroy(L.ev_carried);
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_traced) (void)hipEventDestroy(L.ev_traced);
         for (auto& B : L.bufs) {
@@ -1159,6 +1174,7 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
         }
     }
     if (s->prep_stream) (void)hipStreamDestroy(s->prep_stream);
+    if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->d_acc) (void)hipFree(s->d_acc);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
@@ -1263,10 +1279,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     if (int rc = ensure_lanes(s, depth)) return rc;
     const auto sync_lanes = [&]() -> int {  // everything in flight on the caller's stream and on the lanes
         HIP_TRY(hipStreamSynchronize(stream));
-        for (auto& L : s->lanes) {
-            HIP_TRY(hipStreamSynchronize(L.stream));
-            if (L.helper_stream) HIP_TRY(hipStreamSynchronize(L.helper_stream));
-        }
+        for (auto& L : s->lanes) HIP_TRY(hipStreamSynchronize(L.stream));  // (helper launches are carried by lane streams)
+        if (s->aux_stream) HIP_TRY(hipStreamSynchronize(s->aux_stream));
         return RBRT_OK;
     };
     if (!acc && per_sample > s->acc_bytes) {
@@ -1551,8 +1565,10 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, share_build, ts));
         if (piped && s->pool == 128u && s->helpers_mode != 0u) {
             L.open.valid = true, L.open.P = P, L.open.grid = grid, L.open.helper_waves = 0u, L.open.rounds = 0u, L.open.share = share_build;
-            if (s->helpers_mode == 2u)
-                if (int rc = issue_helper(s, L, s->n_cus)) return rc;
+            if (s->helpers_mode == 2u) {  // (tests: a helper with every overlapped launch, on a stream of its own)
+                if (!s->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
+                if (int rc = issue_helper(s, L, s->n_cus, s->aux_stream)) return rc;
+            }
         }
         if (timing) HIP_TRY(hipEventRecord(s->events[ev0 + 3 * b + 1], ts));
         R.sample_buf = B.d_sample_buf;
