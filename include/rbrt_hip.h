@@ -24,10 +24,17 @@
  *       rgb8    : uint8[H][W][3]  — (sqrt(c)*256) saturating cast (lib.rs:116-122)
  *   - there is NO CPU fallback: without a usable HIP device every render entry
  *     point fails with RBRT_ERR_NO_DEVICE.
- *   - environment: the library reads three variables, all optional --
+ *   - environment: the library reads four variables, all optional --
  *       RBRT_HIP_WORKSPACE_MB   cap of one pipeline lane's sample workspace in MiB (default 1024)
- *       RBRT_BVH_BUILDER        host | device: force one BVH builder (default: by mesh size)
+ *       RBRT_BVH_BUILDER        host | device: force one BVH builder (default: a mesh's first tree by whichever builder
+ *                               costs the call less, the host builder's tree following from a background thread)
+ *       RBRT_BVH_REFINE         0: no background build, a handle keeps the tree it started with
  *       RBRT_BVH_THREADS        threads of the host BVH builder (default: the machine's, at most 16)
+ *     and takes note of GPU_MAX_HW_QUEUES as the process had it when the library was loaded (the HIP runtime's own
+ *     variable: the frame pipeline is planned for the hardware queues the runtime really has).
+ *   - threads: besides the caller's, a scene handle may own a background BVH builder and, once it has seen a stream of
+ *     calls, a watcher that gives launches still running the wave slots that have become free (rbrt_hip_scene_destroy
+ *     ends both). A handle is still used by ONE calling thread at a time.
  *     Everything else that tunes the kernels' scheduling is a lab knob: ignored unless RBRT_HIP_LAB=1 is set, and
  *     documented with the test / diagnostic entry points in rbrt_hip_debug.h, not here. No knob changes the image.
  */

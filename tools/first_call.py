@@ -1,7 +1,7 @@
 """First render call of a scene against the later ones (GPU box): what a one-shot caller such as the rbrt CLI pays."""
 import os, sys, time, tempfile
 from pathlib import Path
-ROOT = Path("/root/repo"); sys.path.insert(0, str(ROOT))
+ROOT = Path(__file__).resolve().parent.parent; sys.path.insert(0, str(ROOT))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import rbrt_amd
 from rbrt_amd import abi, standin
