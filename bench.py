@@ -398,16 +398,17 @@ def main():
     cam_no = [0]
     import numpy as np
 
+    cam_x = [np.float32(cam.position[0])]
+
     def fresh_camera():
         """A camera the library has not seen: the position's first component moves one unit in the last place per call
         (every rank makes the same sequence). The image and the work are the frame's to within rounding; the library's
-        per-camera tile pass has to run again."""
+        per-camera tile pass has to run again. (Constant time per call: an earlier form walked from the first camera to the
+        k-th on every call, and after a thousand frames the HOST took longer per step than an eighth of a frame does.)"""
         cam_no[0] += 1
         c = type(cam).from_buffer_copy(cam)
-        x = np.float32(cam.position[0])
-        for _ in range(cam_no[0]):
-            x = np.nextafter(x, np.float32(np.inf), dtype=np.float32)
-        c.position[0] = float(x)
+        cam_x[0] = np.nextafter(cam_x[0], np.float32(np.inf), dtype=np.float32)
+        c.position[0] = float(cam_x[0])
         return c
 
     if args.pipeline > 0:  # 0: leave the library's choice (automatic, or $RBRT_PIPELINE)
@@ -555,11 +556,14 @@ def main():
         table = {}
         whole = None
         for wd in [1] + [w_ for w_ in worlds if w_ > 1]:
-            per_rank = []
-            for r in range(wd):
-                opts.tile_rank, opts.tile_world = r, wd
-                el = timed_leg(args.warmup, args.steps, True)[0]
-                per_rank.append(round(el / args.steps * 1e3, 4))
+            # (two sweeps over the ranks, first to last and last to first, averaged: a GPU under a minute of steady load drifts by
+            # several per cent, which a single sweep would book to the ranks measured last)
+            acc = [0.0] * wd
+            for order in (range(wd), reversed(range(wd))):
+                for r in order:
+                    opts.tile_rank, opts.tile_world = r, wd
+                    acc[r] += timed_leg(args.warmup, args.steps, True)[0] / args.steps * 1e3
+            per_rank = [round(a / 2.0, 4) for a in acc]
             if wd == 1:
                 whole = per_rank[0]
                 continue

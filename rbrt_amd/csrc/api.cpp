@@ -210,6 +210,7 @@ struct rbrt_hip_scene {
     uint32_t n_helper_launches = 0;  // since set_timing(1)
     hipStream_t prep_stream = nullptr;  // high priority: the tile passes of cameras the lanes have not seen
     hipStream_t aux_stream = nullptr;   // RBRT_HELPERS=2 (tests): carries the helper launches
+    void* h_zeros = nullptr;            // pinned: what a lane's work counters are set to again behind a helper launch
     uint64_t launch_no = 0;
     bool streaming_hint = false;  // the last trace launch was issued while another one was still running
     uint32_t pipeline = 0;   // RBRT_PIPELINE / rbrt_hip_scene_set_pipeline; 0 = automatic (depth_for)
@@ -660,7 +661,10 @@ void watcher_main(rbrt_hip_scene* s) {
         const uint32_t per = std::max(64u, (free_waves / n_open) / 64u * 64u);
         uint32_t left = free_waves;
         for (auto& L : s->lanes) {
-            if (!L.open.valid || L.open.rounds >= 4u || left < 64u || carriers.empty()) continue;
+            // (a short launch is over before a helper launch has arrived: an eighth of the headline frame, 0.5 ms, came out 2 %
+            // SLOWER with helpers -- the watcher looks every 100 us --; the launches of 8 M work items or more that take 4 slots
+            // per CU in a stream, grid_for, are the ones that are helped)
+            if (!L.open.valid || L.open.rounds >= 4u || left < 64u || carriers.empty() || L.open.P.n_items < (8ull << 20)) continue;
             const uint32_t w = per < left ? per : left / 64u * 64u;
             rbrt_hip_scene::Lane* C = carriers.back();
             carriers.pop_back();
@@ -1175,6 +1179,7 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     }
     if (s->prep_stream) (void)hipStreamDestroy(s->prep_stream);
     if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
+    if (s->h_zeros) (void)hipHostFree(s->h_zeros);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->d_acc) (void)hipFree(s->d_acc);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
@@ -1482,9 +1487,14 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             // a helper launch joined the lane's last launch: its last waves may have drawn from the counters after that
             // launch's resolve had reset them (api.cpp "Elastic launches") -- this launch starts behind the helper launch, on
             // counters zeroed again
-            static const unsigned long long zeros[kWorkShards * kWorkCounterStride] = {};
+            // (from pinned memory: an asynchronous copy out of pageable memory makes the issuing thread wait for the stream)
+            constexpr size_t counter_bytes = sizeof(unsigned long long) * kWorkShards * kWorkCounterStride;
+            if (!s->h_zeros) {
+                HIP_TRY(hipHostMalloc(&s->h_zeros, counter_bytes, hipHostMallocDefault));
+                std::memset(s->h_zeros, 0, counter_bytes);
+            }
             HIP_TRY(hipStreamWaitEvent(ts, L.ev_helper, 0));
-            HIP_TRY(hipMemcpyAsync(B.d_work_counter, zeros, sizeof(zeros), hipMemcpyHostToDevice, ts));
+            HIP_TRY(hipMemcpyAsync(B.d_work_counter, s->h_zeros, counter_bytes, hipMemcpyHostToDevice, ts));
             L.helper_pending = false;
         }
         P.sample_base = base;
