@@ -611,11 +611,16 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
 // takes its packets in order, so a helper launch on a stream of its own would sit in some lane's queue, behind that lane's
 // launch or in front of its next one; the streams of lanes that have nothing in flight are the queues that are free, and
 // at the end of a stream of frames there are more of them with every launch that ends.
+// A wave processes ~1,700 work items per millisecond in the bulk of the headline frame: below ~1,500 items per wave left, the
+// launch's own waves are within a millisecond of running out and a helper wave's own drain costs more than it brings.
+constexpr uint32_t kHelperMinItemsPerWave = 1536;
+
 int issue_helper(rbrt_hip_scene* s, rbrt_hip_scene::Lane& L, uint32_t waves, hipStream_t carrier) {
     if (!L.open.valid || waves == 0u || L.open.grid + L.open.helper_waves + waves > s->scratch_waves) return RBRT_OK;
     HIP_TRY(hipStreamWaitEvent(carrier, L.ev_ready, 0));  // (what the launch waited for: the resolve before it, its tables)
     TraceParams P = L.open.P;
     P.wave_base = L.open.grid + L.open.helper_waves;
+    P.helper_min_items = s->helpers_mode == 2u ? 0u : kHelperMinItemsPerWave;  // (tests: every helper wave joins)
     HIP_TRY(launch_trace_helper(P, waves, s->pool, L.open.share, carrier));
     HIP_TRY(hipEventRecord(L.ev_helper, carrier));
     L.helper_pending = true;

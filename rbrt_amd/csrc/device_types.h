@@ -168,6 +168,7 @@ struct TraceParams {
     uint32_t* helper_words;
     uint32_t helper_seq;
     uint32_t wave_base;  // helper launches: first per-wave scratch slot (gseq / gstack) of this launch's waves; 0 for the launch itself
+    uint32_t helper_min_items;  // helper launches: a helper wave joins only while at least this many work items per wave (the launch's and all its helpers') are left
 };
 
 struct ResolveParams {
