@@ -208,6 +208,12 @@ struct rbrt_hip_scene {
     double last_call_s = 0.0;      // when the caller last issued a launch
     uint32_t helpers_mode = 1;     // RBRT_HELPERS (lab): 0 never, 1 when the GPU has room and the caller has stopped issuing, 2 with every launch (tests)
     uint32_t n_helper_launches = 0;  // since set_timing(1)
+    // RBRT_HELPER_MIN_ITEMS (lab): a helper wave joins a launch only while this many work items per wave are left. A wave
+    // does ~1,700 items per millisecond in the bulk of the headline frame; twenty frames between fences, ten rounds in one
+    // process (profiles/r05_helpers_threshold_sweep.txt), median / worst ms per step: no helpers 3.582 / 3.631; 1536: 3.506 /
+    // 3.813 (three rounds of ten WORSE than without: late joiners turn bulk into drain); 4096: 3.513 / 3.544; 8192: 3.536 / 3.578
+    uint32_t helper_min_items = 4096;
+    uint32_t helper_rounds = 4;        // RBRT_HELPER_ROUNDS (lab)
     hipStream_t prep_stream = nullptr;  // high priority: the tile passes of cameras the lanes have not seen
     hipStream_t aux_stream = nullptr;   // RBRT_HELPERS=2 (tests): carries the helper launches
     void* h_zeros = nullptr;            // pinned: what a lane's work counters are set to again behind a helper launch
@@ -611,16 +617,12 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
 // takes its packets in order, so a helper launch on a stream of its own would sit in some lane's queue, behind that lane's
 // launch or in front of its next one; the streams of lanes that have nothing in flight are the queues that are free, and
 // at the end of a stream of frames there are more of them with every launch that ends.
-// A wave processes ~1,700 work items per millisecond in the bulk of the headline frame: below ~1,500 items per wave left, the
-// launch's own waves are within a millisecond of running out and a helper wave's own drain costs more than it brings.
-constexpr uint32_t kHelperMinItemsPerWave = 1536;
-
 int issue_helper(rbrt_hip_scene* s, rbrt_hip_scene::Lane& L, uint32_t waves, hipStream_t carrier) {
     if (!L.open.valid || waves == 0u || L.open.grid + L.open.helper_waves + waves > s->scratch_waves) return RBRT_OK;
     HIP_TRY(hipStreamWaitEvent(carrier, L.ev_ready, 0));  // (what the launch waited for: the resolve before it, its tables)
     TraceParams P = L.open.P;
     P.wave_base = L.open.grid + L.open.helper_waves;
-    P.helper_min_items = s->helpers_mode == 2u ? 0u : kHelperMinItemsPerWave;  // (tests: every helper wave joins)
+    P.helper_min_items = s->helpers_mode == 2u ? 0u : s->helper_min_items;  // (tests: every helper wave joins)
     HIP_TRY(launch_trace_helper(P, waves, s->pool, L.open.share, carrier));
     HIP_TRY(hipEventRecord(L.ev_helper, carrier));
     L.helper_pending = true;
@@ -669,7 +671,7 @@ void watcher_main(rbrt_hip_scene* s) {
             // (a short launch is over before a helper launch has arrived: an eighth of the headline frame, 0.5 ms, came out 2 %
             // SLOWER with helpers -- the watcher looks every 100 us --; the launches of 8 M work items or more that take 4 slots
             // per CU in a stream, grid_for, are the ones that are helped)
-            if (!L.open.valid || L.open.rounds >= 4u || left < 64u || carriers.empty() || L.open.P.n_items < (8ull << 20)) continue;
+            if (!L.open.valid || L.open.rounds >= s->helper_rounds || left < 64u || carriers.empty() || L.open.P.n_items < (8ull << 20)) continue;
             const uint32_t w = per < left ? per : left / 64u * 64u;
             rbrt_hip_scene::Lane* C = carriers.back();
             carriers.pop_back();
@@ -1086,7 +1088,8 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
             lab_u32("RBRT_TILE_ORDER", 0, 2, s->tile_order, err) && lab_u32("RBRT_TILE_CLASSES", 0, 4, s->tile_classes, err) &&
             lab_u32("RBRT_OVERLAP_WAVES_PER_CU", 0, 16, s->overlap_waves_per_cu, err) &&
             lab_u32("RBRT_TILE_ISOLATED_MODE", 0, 4, s->isolated_list_mode, err) && lab_u32("RBRT_TILE_TAIL_DIV", 1, 1024, s->tile_tail_div, err) &&
-            lab_u32("RBRT_HELPERS", 0, 2, s->helpers_mode, err);
+            lab_u32("RBRT_HELPERS", 0, 2, s->helpers_mode, err) && lab_u32("RBRT_HELPER_MIN_ITEMS", 1, 1 << 24, s->helper_min_items, err) &&
+            lab_u32("RBRT_HELPER_ROUNDS", 1, 16, s->helper_rounds, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
         s->tile_classes_set = lab_env("RBRT_TILE_CLASSES") != nullptr;
         s->trace_launches = lab_env("RBRT_TRACE_LAUNCHES") != nullptr;

@@ -274,8 +274,7 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
         // Is there enough left to be worth joining? A wave that joins fills a pool of its own and, when the work runs out,
         // runs it empty alone -- half a millisecond and more at a tenth of the lane utilisation. With plenty of work left per
         // wave that is repaid many times over; joined late it only turns work the launch's own waves would have done in full
-        // passes into one more drain, and the launch ends LATER (twenty frames between fences came out anything from 4 %
-        // faster to 7 % slower before this test). What is left = the items no shard counter has handed out yet.
+        // passes into one more drain, and the launch ends LATER (api.cpp helper_min_items has the measurements). What is left = the items no shard counter has handed out yet.
         if (P.helper_min_items != 0u) {
             unsigned long long drawn = 0ull;
             const unsigned long long per_shard = (unsigned long long)(n_items / kWorkShards) + kWorkChunk;
