@@ -461,9 +461,17 @@ def test_cli_end_to_end_png(hip, oracle, tmp_path):
     (tmp_path / "scene.yaml").write_text(text)
     out = tmp_path / "out.png"
     r = subprocess.run([str(root / "rbrt_amd" / "bin" / "rbrt"), "-c", str(tmp_path / "scene.yaml"), "-t", str(out),
-                        "--height", "96", "-w", "128", "-s", "6", "--seed", "9"], capture_output=True, text=True, timeout=300)
+                        "--height", "96", "-w", "128", "-s", "6", "--seed", "9", "--report", str(tmp_path / "rep.json")],
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Starting rendering" in r.stdout and "100% complete" in r.stdout  # lib.rs:80,112
+    # --report: every part of the run named, and on one GPU the parts add up to the total
+    import json
+    j = json.loads((tmp_path / "rep.json").read_text())
+    parts = ("parse_s", "obj_load_s", "prep_s", "hip_init_s", "upload_s", "bvh_build_s", "lanes_s", "buffers_s", "render_s", "gather_s",
+             "release_s", "encode_s", "other_s")
+    assert all(j[k] >= 0 for k in parts) and abs(sum(j[k] for k in parts) - j["total_s"]) <= 0.02 * j["total_s"] + 1e-4
+    assert j["other_s"] <= 0.05 * j["total_s"] + 0.005 and j["bvh_builder"] == "host"  # (1203 entries: the host builder is the cheaper first tree)
     got = np.array(Image.open(out))
     cam = scenes.camera(oracle, 128, 96)
     sc = scenes.example_scene(oracle, n_tris)
