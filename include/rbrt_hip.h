@@ -173,6 +173,14 @@ typedef struct rbrt_render_opts {
 #define RBRT_FLAG_COLLECT_STATS 1u /* run the counting variant of the kernel (slower); see rbrt_hip_stats_t */
 
 #define RBRT_TILE 8u /* tile edge in pixels used for sharding and work ordering */
+/* How tiles are dealt to ranks. Tile NUMBER t (0 <= t < tiles_x * tiles_y) belongs to rank t % tile_world, and a rank's packed
+ * buffers hold its tiles in ascending number. Number t is the image tile in tile row ty = t / tiles_x at tile column
+ * tx = (t % tiles_x + RBRT_TILE_SKEW * ty) % tiles_x: every tile row is rotated by RBRT_TILE_SKEW more than the one above, so
+ * that a rank's tiles lie on skew lines through the image and not in fixed tile columns (with 8 ranks and a width of 128 or
+ * 240 tiles a rank owned every 8th COLUMN, and the columns over the mesh made two ranks 5 % slower than the mean at
+ * 1920 x 1080). rbrt_hip_unpack_tiles undoes it; rbrt_hip_tile_xy / rbrt_hip_tile_number (below) are the two directions for a
+ * host that does its own gather. The image does not depend on the dealing. */
+#define RBRT_TILE_SKEW 3u
 
 /* Per-render work counters from the counting kernel variant: the inputs of the
  * algorithmic-bytes figure ("Measurement"). */
@@ -206,6 +214,10 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* scene);
 /* Number of pixels this rank owns for a W x H image under (tile_rank, tile_world), counting
  * the padded pixels of partial edge tiles (each tile contributes RBRT_TILE*RBRT_TILE slots). */
 size_t rbrt_hip_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_world);
+
+/* Tile number -> tile row / column and back ("How tiles are dealt to ranks", above); tiles_x = ceil(width / RBRT_TILE). */
+void rbrt_hip_tile_xy(uint32_t tile, uint32_t tiles_x, uint32_t* tile_row, uint32_t* tile_col);
+uint32_t rbrt_hip_tile_number(uint32_t tile_row, uint32_t tile_col, uint32_t tiles_x);
 
 /* Renders into DEVICE memory on `stream` (a hipStream_t, may be NULL = default stream) and
  * returns without synchronising.

@@ -142,6 +142,8 @@ HIP_SYMBOLS = {
     "rbrt_hip_scene_create": (C.c_int, [C.POINTER(Scene), C.c_int, C.POINTER(C.c_void_p)]),
     "rbrt_hip_scene_destroy": (C.c_int, [C.c_void_p]),
     "rbrt_hip_packed_pixels": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rbrt_hip_tile_xy": (None, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rbrt_hip_tile_number": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "rbrt_hip_render_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     "rbrt_hip_render_pass": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_uint32, C.c_uint32,

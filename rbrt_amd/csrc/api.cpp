@@ -739,7 +739,8 @@ bool empty_end_is_first(const rbrt_hip_scene* s, const rbrt_camera_t& cam, uint3
                         uint32_t n_local) {
     const auto tile_hits = [&](uint32_t tl) {
         const uint32_t tile = tl * world + rank;
-        const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
+        uint32_t ty, tx;
+        tile_xy(tile, tiles_x, ty, tx);
         const double col = tx * RBRT_TILE + 0.5 * RBRT_TILE, row = ty * RBRT_TILE + 0.5 * RBRT_TILE;
         const double col_mm = (col - double(cam.img_width_pix / 2)) * cam.mm_per_pix_hor;
         const double row_mm = (row - double(cam.img_height_pix / 2)) * cam.mm_per_pix_vert;
@@ -828,6 +829,16 @@ size_t rbrt_hip_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_ran
     const uint32_t tx = (width + RBRT_TILE - 1) / RBRT_TILE, ty = (height + RBRT_TILE - 1) / RBRT_TILE;
     const uint32_t world = tile_world ? tile_world : 1;
     return size_t(local_tiles_of(tx * ty, tile_rank, world)) * 64u;
+}
+
+void rbrt_hip_tile_xy(uint32_t tile, uint32_t tiles_x, uint32_t* tile_row, uint32_t* tile_col) {
+    uint32_t ty = 0, tx = 0;
+    if (tiles_x) tile_xy(tile, tiles_x, ty, tx);
+    if (tile_row) *tile_row = ty;
+    if (tile_col) *tile_col = tx;
+}
+uint32_t rbrt_hip_tile_number(uint32_t tile_row, uint32_t tile_col, uint32_t tiles_x) {
+    return tiles_x ? tile_number(tile_row, tile_col, tiles_x) : 0u;
 }
 
 int rbrt_hip_scene_create(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** out) {
@@ -1840,7 +1851,8 @@ int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const r
         const size_t n_local = n_out / 64;
         for (size_t tl = 0; tl < n_local; ++tl) {
             const uint32_t tile = uint32_t(tl) * world + opts->tile_rank;
-            const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
+            uint32_t ty, tx;
+            tile_xy(tile, tiles_x, ty, tx);
             for (uint32_t p = 0; p < 64; ++p) {
                 const uint32_t row = ty * RBRT_TILE + p / 8, col = tx * RBRT_TILE + p % 8;
                 if (row >= H || col >= W) continue;
@@ -2065,9 +2077,13 @@ int rbrt_hip_debug_primary_cull(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, u
     P.tile_cull = static_cast<uint32_t*>(d);
     hipError_t e = launch_primary_cull(P, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(out_words, d, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    std::vector<uint32_t> by_number(n_words);
+    if (e == hipSuccess) e = hipMemcpy(by_number.data(), d, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RBRT_ERR_HIP, std::string("debug_primary_cull: ") + hipGetErrorString(e));
+    // (the table is indexed by tile NUMBER, rbrt_hip.h "How tiles are dealt to ranks"; the hook hands it over in image order)
+    for (uint32_t ty = 0; ty < tiles_y; ++ty)
+        for (uint32_t tx = 0; tx < tiles_x; ++tx) out_words[size_t(ty) * tiles_x + tx] = by_number[tile_number(ty, tx, tiles_x)];
     return RBRT_OK;
 }
 

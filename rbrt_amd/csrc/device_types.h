@@ -7,6 +7,15 @@
 namespace rbrt {
 
 // Compile-time limits.
+// Tile number -> tile coordinates and back (rbrt_hip.h "How tiles are dealt to ranks": row ty is rotated by RBRT_TILE_SKEW * ty).
+__host__ __device__ inline void tile_xy(uint32_t tile, uint32_t tiles_x, uint32_t& ty, uint32_t& tx) {
+    ty = tile / tiles_x;
+    tx = uint32_t((uint64_t(tile - ty * tiles_x) + uint64_t(RBRT_TILE_SKEW) * ty) % tiles_x);
+}
+__host__ __device__ inline uint32_t tile_number(uint32_t ty, uint32_t tx, uint32_t tiles_x) {
+    const uint32_t rot = uint32_t((uint64_t(RBRT_TILE_SKEW) * ty) % tiles_x);
+    return ty * tiles_x + (tx + tiles_x - rot) % tiles_x;
+}
 constexpr uint32_t kTileListHeader = 4;  // words ahead of the lists in TraceParams::tile_lists
 constexpr int kBlock = 256;          // threads per workgroup of the test hooks' kernels
 // Threads per workgroup of the short kernels that run BESIDE resident trace launches (resolve, sky_resolve, unpack, the tile

@@ -743,7 +743,8 @@ __global__ __launch_bounds__(kSmallBlock) void resolve_kernel(const ResolveParam
     const uint32_t tile_local = R.tile_lists ? R.tile_lists[kTileListHeader + (i >> 6)] : uint32_t(i >> 6);
     const size_t j = size_t(tile_local) * 64u + p;  // the pixel's place in the rank's packed tiles (acc, packed outputs)
     const uint32_t tile = tile_local * R.tile_world + R.tile_rank;
-    const uint32_t ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
+    uint32_t ty, tx;
+    tile_xy(tile, R.tiles_x, ty, tx);
     const uint32_t row = ty * RBRT_TILE + (p >> 3), col = tx * RBRT_TILE + (p & 7u);
     const bool valid = row < R.height && col < R.width;
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
@@ -774,7 +775,8 @@ __global__ __launch_bounds__(kSmallBlock) void sky_resolve_kernel(const TracePar
     const uint32_t tile_local = R.tile_lists[kTileListHeader + R.n_local_tiles + (i >> 6)];
     const size_t j = size_t(tile_local) * 64u + p;
     const uint32_t tile = tile_local * R.tile_world + R.tile_rank;
-    const uint32_t ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
+    uint32_t ty, tx;
+    tile_xy(tile, R.tiles_x, ty, tx);
     const uint32_t row = ty * RBRT_TILE + (p >> 3), col = tx * RBRT_TILE + (p & 7u);
     const bool valid = row < R.height && col < R.width;
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
@@ -918,7 +920,8 @@ __global__ __launch_bounds__(kCullBlock, 4) void primary_cull_kernel(const Trace
     const uint32_t tile = tile_local * cull_world + (cull_world > 1u ? P.tile_rank : 0u);
     const uint32_t quad_lane = threadIdx.x % kCullLanes, quad_shift = threadIdx.x & ~(kCullLanes - 1u);
     if (tile >= P.n_tiles) return;  // (whole quads: the votes below count active lanes only)
-    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    uint32_t ty, tx;
+    tile_xy(tile, P.tiles_x, ty, tx);
     const rbrt_camera_t& c = P.cam;
     const uint32_t W = c.img_width_pix, H = c.img_height_pix;
     const D3 pos = d3(c.position), right = d3(c.right), up = d3(c.up), ctr = d3(c.img_center_point);
@@ -1189,7 +1192,7 @@ __global__ __launch_bounds__(kSmallBlock) void unpack_kernel(const float* __rest
     const size_t i = size_t(blockIdx.x) * kSmallBlock + threadIdx.x;
     if (i >= size_t(width) * height) return;
     const uint32_t row = uint32_t(i / width), col = uint32_t(i - size_t(row) * width);
-    const uint32_t tile = (row / RBRT_TILE) * tiles_x + col / RBRT_TILE;
+    const uint32_t tile = tile_number(row / RBRT_TILE, col / RBRT_TILE, tiles_x);
     const uint32_t rank = tile % world, tile_local = tile / world;
     size_t base = 0;
     if (rank_stride_pixels != 0) {  // equal-size slots per rank (what a gather of equal-size tensors produces)

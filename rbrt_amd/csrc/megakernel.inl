@@ -931,7 +931,9 @@ __global__ __launch_bounds__(64, RBRT_MK_WAVES_PER_SIMD) void trace_megakernel(c
                         const uint32_t tile_local = P.tile_lists ? P.tile_lists[kTileListHeader + widx] : widx;
                         const uint32_t tile = tile_local * gp[G_TILE_WORLD] + gp[G_TILE_RANK];
                         const uint32_t tiles_x = gp[G_TILES_X];
-                        const uint32_t ty = div_magic(tile, tiles_x, gp[G_TILES_X_MAGIC]), tx = tile - ty * tiles_x;
+                        const uint32_t ty = div_magic(tile, tiles_x, gp[G_TILES_X_MAGIC]);
+                        uint32_t tx = tile - ty * tiles_x + RBRT_TILE_SKEW * ty;  // (rbrt_hip.h "How tiles are dealt to ranks")
+                        tx -= div_magic(tx, tiles_x, gp[G_TILES_X_MAGIC]) * tiles_x;
                         const uint32_t row = ty * RBRT_TILE + (pp >> 3), col = tx * RBRT_TILE + (pp & 7u);
                         const uint32_t img_w = gp[G_W], img_h = gp[G_H];
                         if (row < img_h && col < img_w) {

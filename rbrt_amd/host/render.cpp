@@ -374,7 +374,8 @@ ImageBuffer render_scene(const Camera& cam, uint32_t num_samples, const Scene& s
                 const uint32_t tiles_x = (img.width + RBRT_TILE - 1) / RBRT_TILE;
                 for (size_t tl = 0; tl < npix / 64; ++tl) {  // (ranks write disjoint pixels of the shared image)
                     const uint32_t tile = uint32_t(tl) * uint32_t(world) + uint32_t(rank);
-                    const uint32_t ty = tile / tiles_x, tx = tile % tiles_x;
+                    uint32_t ty, tx;
+                    rbrt_hip_tile_xy(tile, tiles_x, &ty, &tx);
                     for (uint32_t p = 0; p < 64; ++p) {
                         const uint32_t row = ty * RBRT_TILE + p / 8, col = tx * RBRT_TILE + p % 8;
                         if (row >= img.height || col >= img.width) continue;

@@ -1,7 +1,9 @@
 """Pixel-tile sharding index math (host side, numpy) — the same layout the kernels use.
 
-An image is cut into 8x8 tiles in row-major tile order; tile t belongs to rank t % world; a rank's
-packed buffer holds its tiles in ascending tile order, 64 pixel slots per tile (slot p = (y%8)*8 +
+An image is cut into 8x8 tiles; tile NUMBER t belongs to rank t % world, where number t is the tile in tile row
+ty = t // tiles_x at tile column (t % tiles_x + SKEW * ty) % tiles_x (include/rbrt_hip.h "How tiles are dealt to
+ranks": every tile row is rotated a little more than the one above, so that a rank's tiles are not fixed columns); a rank's
+packed buffer holds its tiles in ascending number, 64 pixel slots per tile (slot p = (y%8)*8 +
 x%8; slots outside a ragged image edge are padding). bench.py gathers the packed buffers with one
 RCCL gather and rank 0 de-interleaves them (rbrt_hip_unpack_tiles on the GPU; `unpack` here is the
 numpy restatement used by the CPU tests).
@@ -11,6 +13,7 @@ from __future__ import annotations
 import numpy as np
 
 TILE = 8
+SKEW = 3  # RBRT_TILE_SKEW
 
 
 def n_tiles(width: int, height: int) -> int:
@@ -30,7 +33,8 @@ def _index_maps(width: int, height: int, world: int):
     """For every image pixel: (owner rank, slot index inside the owner's packed buffer)."""
     tiles_x = (width + TILE - 1) // TILE
     ys, xs = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
-    tile = (ys // TILE) * tiles_x + xs // TILE
+    ty, tx = ys // TILE, xs // TILE
+    tile = ty * tiles_x + (tx + tiles_x - (SKEW * ty) % tiles_x) % tiles_x  # rbrt_tile_number
     return tile % world, (tile // world) * TILE * TILE + (ys % TILE) * TILE + xs % TILE
 
 

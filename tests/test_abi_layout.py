@@ -117,3 +117,32 @@ def test_argument_errors_come_back_as_codes_without_a_gpu():
     assert lib.rbrt_hip_render_device(None, None, C.byref(opts), None, None, None) == -1
     assert lib.rbrt_hip_scene_set_pipeline(None, 2) == -1
     assert lib.rbrt_hip_scene_destroy(None) == 0  # destroying nothing is fine
+
+
+def test_the_dealing_of_tiles_is_one_bijection_in_the_library_and_in_python():
+    """rbrt_hip.h "How tiles are dealt to ranks": tile number <-> (tile row, tile column), rows rotated by RBRT_TILE_SKEW per
+    row. The library's two directions are inverse to each other for every tiles_x (smaller than, equal to, not coprime with
+    the skew), cover every tile exactly once, and agree with rbrt_amd/tiles.py, which the CPU multi-rank tests pack with."""
+    import ctypes as C
+
+    import numpy as np
+    from rbrt_amd import tiles
+    lib = abi.load_hip()
+    for tiles_x, tiles_y in ((1, 5), (2, 7), (3, 4), (13, 8), (128, 96), (240, 135)):
+        seen = set()
+        for t in range(tiles_x * tiles_y):
+            ty, tx = C.c_uint32(), C.c_uint32()
+            lib.rbrt_hip_tile_xy(t, tiles_x, C.byref(ty), C.byref(tx))
+            assert ty.value == t // tiles_x and tx.value == (t % tiles_x + tiles.SKEW * ty.value) % tiles_x
+            assert lib.rbrt_hip_tile_number(ty.value, tx.value, tiles_x) == t
+            seen.add((ty.value, tx.value))
+        assert len(seen) == tiles_x * tiles_y
+    w, h, world = 100, 60, 3
+    owner, slot = tiles._index_maps(w, h, world)
+    tx_n = (w + 7) // 8
+    for (y, x) in ((0, 0), (59, 99), (17, 42), (8, 8), (40, 96)):
+        t = lib.rbrt_hip_tile_number(y // 8, x // 8, tx_n)
+        assert owner[y, x] == t % world and slot[y, x] == (t // world) * 64 + (y % 8) * 8 + x % 8
+    # with 8 ranks and a width that is a multiple of 8 tiles, a rank's tiles are no longer whole columns
+    owner, _ = tiles._index_maps(1024, 768, 8)
+    assert all(len(np.unique(owner[::8, c * 8])) == 8 for c in (0, 5, 127))

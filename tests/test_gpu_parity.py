@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import scenes
-from rbrt_amd import abi, standin
+from rbrt_amd import abi, standin, tiles
 
 pytestmark = pytest.mark.gpu
 
@@ -172,7 +172,8 @@ def test_tile_sharding_is_partition_invariant(hip, oracle):
         for r in range(world):
             part, part8 = hip.render_scene(cam, 4, sc, seed=7, tile_rank=r, tile_world=world)
             ty, tx = np.meshgrid(np.arange(60) // 8, np.arange(100) // 8, indexing="ij")
-            mine = ((ty * 13 + tx) % world) == r
+            # (13 tiles per row; tile number of the tile at (ty, tx): rbrt_hip.h "How tiles are dealt to ranks")
+            mine = ((ty * 13 + (tx + 13 - (tiles.SKEW * ty) % 13) % 13) % world) == r
             merged[mine] = part[mine]
             merged8[mine] = part8[mine]
         assert_same_image(merged, full, f"world {world}")
