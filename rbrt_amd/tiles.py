@@ -16,6 +16,11 @@ TILE = 8
 SKEW = 3  # RBRT_TILE_SKEW
 
 
+def tile_number(ty, tx, tiles_x: int):
+    """Number of the tile in tile row ty at tile column tx (ints or numpy arrays): rbrt_hip_tile_number."""
+    return ty * tiles_x + (tx + tiles_x - (SKEW * ty) % tiles_x) % tiles_x
+
+
 def n_tiles(width: int, height: int) -> int:
     return ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE)
 
@@ -34,7 +39,7 @@ def _index_maps(width: int, height: int, world: int):
     tiles_x = (width + TILE - 1) // TILE
     ys, xs = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
     ty, tx = ys // TILE, xs // TILE
-    tile = ty * tiles_x + (tx + tiles_x - (SKEW * ty) % tiles_x) % tiles_x  # rbrt_tile_number
+    tile = tile_number(ty, tx, tiles_x)
     return tile % world, (tile // world) * TILE * TILE + (ys % TILE) * TILE + xs % TILE
 
 

@@ -172,8 +172,7 @@ def test_tile_sharding_is_partition_invariant(hip, oracle):
         for r in range(world):
             part, part8 = hip.render_scene(cam, 4, sc, seed=7, tile_rank=r, tile_world=world)
             ty, tx = np.meshgrid(np.arange(60) // 8, np.arange(100) // 8, indexing="ij")
-            # (13 tiles per row; tile number of the tile at (ty, tx): rbrt_hip.h "How tiles are dealt to ranks")
-            mine = ((ty * 13 + (tx + 13 - (tiles.SKEW * ty) % 13) % 13) % world) == r
+            mine = (tiles.tile_number(ty, tx, 13) % world) == r
             merged[mine] = part[mine]
             merged8[mine] = part8[mine]
         assert_same_image(merged, full, f"world {world}")
@@ -371,7 +370,7 @@ def test_dragon_sized_mesh_cfg4(hip, oracle):
     part0, _ = hip.render_scene(cam, 2, sc, seed=1, tile_rank=0, tile_world=2)
     part1, _ = hip.render_scene(cam, 2, sc, seed=1, tile_rank=1, tile_world=2)
     ty, tx = np.meshgrid(np.arange(768) // 8, np.arange(1024) // 8, indexing="ij")
-    mine = ((ty * 128 + tx) % 2) == 0
+    mine = (tiles.tile_number(ty, tx, 128) % 2) == 0
     assert np.array_equal(np.where(mine[..., None], part0, part1), full)
     # and a sub-window of it against the brute-force oracle (108,927 AVX iterations per mesh ray)
     exp, _, _ = oracle.render(cam, sc, abi.default_opts(spp=2, seed=1), window=(500, 532, 300, 316))
