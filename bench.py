@@ -549,9 +549,8 @@ def main():
         fence()
     guarded(prime_pipeline)
     if world == 1 and args.emulate_all:
-        # Every rank's share, not rank 0's: the step of an N-GPU run is the MAX over its ranks, and with tiles dealt round-robin
-        # over the row-major tile index a rank's tiles are fixed columns of the image, over which the mesh and the glass sphere
-        # are not spread evenly (the reference balances by work stealing, lib.rs:84-88).
+        # Every rank's share, not rank 0's: the step of an N-GPU run is the MAX over its ranks (the reference balances by work
+        # stealing, lib.rs:84-88; here a rank's tiles lie on skew lines through the image, rbrt_hip.h "How tiles are dealt to ranks").
         worlds = [int(x) for x in args.emulate_all.split(",") if x.strip()]
         table = {}
         whole = None
@@ -858,7 +857,7 @@ def main():
                                f"{'' if args.mesh_scale is None else f' at scale {args.mesh_scale:g} (translation {args.mesh_translation})'}, "
                                f"{W}x{H}, {spp} spp, seed {args.seed}",
                    "baseline_config": args.config,
-                   "parallelism": f"pixel tiles 8x8 round-robin over {world} GPU(s)" + (f", {gather_mode[0]} gather to rank 0" if world > 1 else ""),
+                   "parallelism": f"pixel tiles 8x8 dealt round-robin along skew lines over {world} GPU(s)" + (f", {gather_mode[0]} gather to rank 0" if world > 1 else ""),
                    "pipeline": pipeline_note(args.pipeline),
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                    "launch_mix_timed_region": {"full_grid": mix_full, "half_grid": mix_half},

@@ -160,8 +160,8 @@ typedef struct rbrt_render_opts {
     float max_dist;     /* 2000.0 */
     float bg[3];        /* (0.05, 0.05, 0.8) */
     uint64_t seed;
-    /* pixel-tile sharding for multi-GPU: 8x8 tiles in row-major tile order are
-     * dealt round-robin, this call renders tiles t with t % tile_world == tile_rank.
+    /* pixel-tile sharding for multi-GPU: 8x8 tiles are dealt round-robin by tile NUMBER ("How tiles are
+     * dealt to ranks", below), this call renders the tiles numbered t with t % tile_world == tile_rank.
      * tile_world <= 1 renders the whole image. */
     uint32_t tile_rank;
     uint32_t tile_world;
