@@ -8,11 +8,16 @@ namespace rbrt {
 
 // Compile-time limits.
 // Tile number -> tile coordinates and back (rbrt_hip.h "How tiles are dealt to ranks": row ty is rotated by RBRT_TILE_SKEW * ty).
-__host__ __device__ inline void tile_xy(uint32_t tile, uint32_t tiles_x, uint32_t& ty, uint32_t& tx) {
+#if defined(__HIPCC__)
+#define RBRT_HOST_DEVICE __host__ __device__
+#else
+#define RBRT_HOST_DEVICE  // (bvh.cpp alone under a host compiler: tests/cpp)
+#endif
+RBRT_HOST_DEVICE inline void tile_xy(uint32_t tile, uint32_t tiles_x, uint32_t& ty, uint32_t& tx) {
     ty = tile / tiles_x;
     tx = uint32_t((uint64_t(tile - ty * tiles_x) + uint64_t(RBRT_TILE_SKEW) * ty) % tiles_x);
 }
-__host__ __device__ inline uint32_t tile_number(uint32_t ty, uint32_t tx, uint32_t tiles_x) {
+RBRT_HOST_DEVICE inline uint32_t tile_number(uint32_t ty, uint32_t tx, uint32_t tiles_x) {
     const uint32_t rot = uint32_t((uint64_t(RBRT_TILE_SKEW) * ty) % tiles_x);
     return ty * tiles_x + (tx + tiles_x - rot) % tiles_x;
 }
