@@ -668,10 +668,10 @@ void watcher_main(rbrt_hip_scene* s) {
         const uint32_t per = std::max(64u, (free_waves / n_open) / 64u * 64u);
         uint32_t left = free_waves;
         for (auto& L : s->lanes) {
-            // (a short launch is over before a helper launch has arrived: an eighth of the headline frame, 0.5 ms, came out 2 %
-            // SLOWER with helpers -- the watcher looks every 100 us --; the launches of 8 M work items or more that take 4 slots
-            // per CU in a stream, grid_for, are the ones that are helped)
-            if (!L.open.valid || L.open.rounds >= s->helper_rounds || left < 64u || carriers.empty() || L.open.P.n_items < (8ull << 20)) continue;
+            // (a short launch is over before a helper launch has arrived -- the watcher looks every 100 us --: with helpers an
+            // eighth of the headline frame, 0.5 ms, came out 2 % SLOWER, a quarter 1 % slower, a half equal, the frame 2 %
+            // faster: launches of 16 M work items or more are the ones that are helped)
+            if (!L.open.valid || L.open.rounds >= s->helper_rounds || left < 64u || carriers.empty() || L.open.P.n_items < (16ull << 20)) continue;
             const uint32_t w = per < left ? per : left / 64u * 64u;
             rbrt_hip_scene::Lane* C = carriers.back();
             carriers.pop_back();

@@ -77,9 +77,9 @@ def test_the_watcher_gives_the_end_of_a_stream_more_waves(hip, oracle, monkeypat
     free (helper launches > 0), and every frame is what it is without them."""
     import torch
     sc = scenes.example_scene(oracle, 20000)
-    w, h, n = 1024, 768, 16  # (launches of 8 M work items or more are the ones the watcher helps: 1024 x 768 x 12)
+    w, h, n = 1024, 768, 16  # (launches of 16 M work items or more are the ones the watcher helps: 1024 x 768 x 24)
     cams = [scenes.camera(oracle, w, h) for _ in range(n)]
-    opts = [abi.default_opts(spp=12, seed=20 + k) for k in range(n)]
+    opts = [abi.default_opts(spp=24, seed=20 + k) for k in range(n)]
     monkeypatch.setenv("RBRT_HIP_LAB", "1")
     monkeypatch.setenv("RBRT_POISON_SAMPLES", "1")
     monkeypatch.setenv("RBRT_HELPERS", "0")
