@@ -48,7 +48,8 @@
 extern "C" {
 #endif
 
-#define RBRT_ABI_VERSION 2 /* 2: rbrt_scene_t grew n_triangles / triangles / element_order (appended: the v1 prefix is unchanged) */
+#define RBRT_ABI_VERSION 2 /* 2: rbrt_scene_t grew n_triangles / triangles / element_order (appended: the v1 prefix is unchanged);
+                              entry points added since (rbrt_hip_tile_xy / _tile_number) change no struct and no existing call */
 
 typedef enum rbrt_status {
     RBRT_OK = 0,

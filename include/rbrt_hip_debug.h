@@ -27,6 +27,7 @@
  *                                4 instead of 3 for a launch of 8 M work items or more)
  *   RBRT_TRACE_LAUNCHES=1        one stderr line per trace launch, tile pass and helper launch (which lane, grid, table set)
  *   RBRT_HELPERS=0|1|2           helper launches (elastic launches): never, by the watcher (1), one with every overlapped launch (tests)
+ *   RBRT_HELPER_MIN_ITEMS=<n>    a helper wave joins only while n work items per wave are left (4096); RBRT_HELPER_ROUNDS=1..16 (4)
  *   RBRT_BVH_SPATIAL=0..0.3      the host builder's budget of duplicated references (spatial splits), as a share of the triangles
  *   RBRT_TRACE_CREATE=1          one stderr line per rbrt_hip_scene_create: where its time went
  */

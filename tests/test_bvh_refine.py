@@ -153,3 +153,41 @@ def test_the_one_shot_call_uses_the_cheaper_builder_and_accounts_for_its_time(hi
     assert t["meshes_device_built"] == 1
     parts = t["create_s"] + t["render_s"] + t["copy_s"] + t["destroy_s"]
     assert 0.0 < parts <= t["total_s"] * 1.0001 and parts >= 0.95 * t["total_s"]
+
+
+@pytest.mark.gpu
+def test_three_meshes_two_of_them_refined_one_small(hip, oracle, monkeypatch):
+    """Several meshes in one scene: their records share ONE array (leaf links are absolute positions in it), so the
+    background thread relocates every rebuilt tree to its mesh's place; a small mesh between two large ones keeps the host
+    builder's first tree and is carried over as it is. Images and single rays before and after the switch."""
+    import torch
+    monkeypatch.delenv("RBRT_BVH_BUILDER", raising=False)
+    monkeypatch.delenv("RBRT_BVH_REFINE", raising=False)
+    a = scenes.standin_mesh(oracle, 9000, 45.0, (5.0, -1.8, -12.5), (0, 0, 0), abi.material(abi.MAT_LAMBERTIAN, (0.8, 0.2, 0.2)))
+    b = scenes.standin_mesh(oracle, 603, 20.0, (2.5, -1.2, -9.0), (0.1, 0.4, 0.2), abi.material(abi.MAT_DIELECTRIC, (1, 1, 1), 1.5))
+    c = scenes.standin_mesh(oracle, 12004, 30.0, (2.0, -1.0, -10.0), (0.3, 0.2, 0.1), abi.material(abi.MAT_METAL, (0.9, 0.9, 0.9), 0.1), kind="rough")
+    sc = abi.SceneData(spheres=scenes.EXAMPLE_SPHERES, meshes=[a, b, c])
+    cam = scenes.camera(oracle, 160, 120)
+    opts = abi.default_opts(spp=4, seed=8)
+    exp, _, _ = oracle.render(cam, sc, opts)
+    rng = np.random.default_rng(5)
+    o = np.float32([3.5, 1.0, -11.0]) + rng.normal(size=(30000, 3)).astype(np.float32) * 6.0
+    d = (np.float32([3.5, -1.0, -11.0]) + rng.uniform(-3, 3, (30000, 3)).astype(np.float32)) - o
+    rays = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], 1).astype(np.float32)
+    et, eo, ei, _ = oracle.trace_rays(sc, rays)
+    img = torch.empty((120, 160, 3), dtype=torch.float32, device="cuda")
+    with hip.HipScene(sc) as hs:
+        t = hs.create_times()
+        assert t["meshes_device_built"] == 2 and t["meshes_host_built"] == 1
+        for phase in ("first trees", "after the switch"):
+            img.zero_()
+            hs.render_device(cam, opts, img.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(img.cpu().numpy().view(np.uint32), exp.view(np.uint32)), phase
+            gt, go, gi, _ = hs.trace_rays(rays)
+            assert np.array_equal(eo, go) and np.array_equal(ei, gi) and np.array_equal(et.view(np.uint32), gt.view(np.uint32)), phase
+            if phase == "first trees":
+                assert hs.refine_wait(60.0)[0] == 1 and hs.info()["n_meshes_device_built"] == 0
+        hs.check()
+    n_el = len(scenes.EXAMPLE_SPHERES)
+    assert all((go == n_el + k).sum() > 50 for k in range(3))
