@@ -1145,7 +1145,16 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
         r->max_threads = std::max(1u, hc / 2u);  // (the caller's thread goes on issuing launches)
         Refine* rp = r.get();
         try {
-            r->th = std::thread([rp]() { rp->run(); });
+            r->th = std::thread([rp]() {
+                try {
+                    rp->run();
+                } catch (...) {  // (no memory for the copy of the records or for the tree: the device's trees stay)
+                    for (void* p : rp->allocs) (void)hipFree(p);
+                    rp->allocs.clear();
+                    rp->error = "out of host memory";
+                    rp->state.store(2, std::memory_order_release);
+                }
+            });
             s->refine = std::move(r);
         } catch (...) {  // (no thread to be had: the device's tree stays)
         }
@@ -1638,7 +1647,12 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     if (s->helpers_mode == 1u && depth > 1 && !stats) {
         if (!s->watcher.joinable() && streams_now) {
             try {
-                s->watcher = std::thread(watcher_main, s);
+                s->watcher = std::thread([s]() {
+                    try {
+                        watcher_main(s);
+                    } catch (...) {  // (nothing the watcher does is needed: launches then stay the size they were issued with)
+                    }
+                });
             } catch (...) {  // (no thread to be had: launches stay the size they were issued with)
             }
         }
