@@ -191,3 +191,42 @@ def test_three_meshes_two_of_them_refined_one_small(hip, oracle, monkeypatch):
         hs.check()
     n_el = len(scenes.EXAMPLE_SPHERES)
     assert all((go == n_el + k).sum() > 50 for k in range(3))
+
+
+@pytest.mark.gpu
+def test_handles_made_and_dropped_again_leave_no_device_memory_behind(hip, oracle, monkeypatch):
+    """Sixty handles, each with a background build (some adopted, some cancelled by the destroy) and a short stream of frames
+    (watcher thread, helper launches in the forced mode on every second handle): free device memory ends where it began."""
+    import torch
+    monkeypatch.delenv("RBRT_BVH_BUILDER", raising=False)
+    sc = scenes.example_scene(oracle, 30000)
+    cam = scenes.camera(oracle, 128, 96)
+    opts = abi.default_opts(spp=2, seed=1)
+    img = torch.empty((96, 128, 3), dtype=torch.float32, device="cuda")
+    ref = None
+
+    def once(k):
+        nonlocal ref
+        monkeypatch.setenv("RBRT_HIP_LAB", "1")
+        monkeypatch.setenv("RBRT_HELPERS", "2" if k % 2 else "1")
+        with hip.HipScene(sc) as hs:
+            if k % 3 == 0:
+                hs.refine_wait(30.0)
+            for _ in range(4):
+                hs.render_device(cam, opts, img.data_ptr())
+            torch.cuda.synchronize()
+            hs.check()
+        got = img.cpu().numpy()
+        if ref is None:
+            ref = got.copy()
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
+
+    for k in range(6):  # (the runtime's own pools settle)
+        once(k)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(60):
+        once(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), (free0, free1)
