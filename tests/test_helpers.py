@@ -86,10 +86,12 @@ def test_the_watcher_gives_the_end_of_a_stream_more_waves(hip, oracle, monkeypat
     ref, _ = _stream(hip, torch, sc, cams, opts, [(w, h)] * n)
     monkeypatch.delenv("RBRT_HELPERS")
     total = 0
-    for _ in range(3):  # (three streams, each with its own end)
+    for _ in range(6):  # (up to six streams, each with its own end: whether the watcher gets to help one depends on the box's load)
         got, n_helpers = _stream(hip, torch, sc, cams, opts, [(w, h)] * n)
         total += n_helpers
         for k in range(n):
             assert np.isfinite(got[k]).all() and np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
         time.sleep(0.01)
+        if total > 0 and _ >= 2:
+            break
     assert total > 0
