@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <atomic>
+#include <functional>
 #include <limits>
 #include <thread>
 
@@ -599,14 +601,140 @@ struct Builder {
             return;
         }
         out.nodes.reserve(nodes2.size() / 2 + 2);
+        plan_openings();
         collapse(0, 0);
         out.stack_need = 3u * (out.max_depth + 1u) + 1u;
         nodes2.clear();
         nodes2.shrink_to_fit();
     }
 
-    // Binary -> 4-wide: a node adopts its grandchildren, always opening the inner child with the
-    // largest surface first, until it has four children or only leaves are left.
+    // The openings that minimise the 4-wide tree's SAH cost for THIS binary tree (dynamic programme over slots, after
+    // Ylitie et al. 2017 section 3.1): E[n][k] = cheapest way to stand for binary subtree n with at most k slots of one
+    // wide node; C[n] = n as a wide node of its own (one visit of its surface + its four slots' best use).
+    // The triangles of a leaf with their boxes (each cut to the leaf's box: a reference cut by a spatial split lies in it).
+    struct LeafTris {
+        uint32_t first, count;
+        BvhTri t[kLeafMax];
+        Box tb[kLeafMax];
+        float te12[kLeafMax];
+    };
+    void leaf_tris(int32_t ref, const Box& leaf_box, LeafTris& L) const {
+        const uint32_t code = uint32_t(~ref);
+        L.first = code >> kLeafBits, L.count = (code & uint32_t(kLeafMax - 1)) + 1u;
+        const float fmax = std::numeric_limits<float>::max();
+        for (uint32_t i = 0; i < L.count; ++i) {
+            const BvhTri& t = L.t[i] = out.tris[L.first + i];
+            const float v0[3] = {t.v0[0], t.v0[1], t.v0[2]};
+            const float e1[3] = {t.e1x, t.e1yz[0], t.e1yz[1]}, e2[3] = {t.e2xy[0], t.e2xy[1], t.e2z};
+            float v1[3], v2[3];
+            for (int k = 0; k < 3; ++k) {
+                v1[k] = std::min(std::max(v0[k] + e1[k], -fmax), fmax);
+                v2[k] = std::min(std::max(v0[k] + e2[k], -fmax), fmax);
+            }
+            Box& b = L.tb[i];
+            b.reset();
+            b.grow(v0), b.grow(v1), b.grow(v2);
+            for (int k = 0; k < 3; ++k) b.lo[k] = std::max(b.lo[k], leaf_box.lo[k]), b.hi[k] = std::min(b.hi[k], leaf_box.hi[k]);
+            L.te12[i] = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) *
+                        std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        }
+    }
+    // The cheapest way to stand for a leaf with at most k leaves (sum of surface x count over the groups of a partition of
+    // its triangles): label[i] = group of triangle i, groups numbered in order of their first triangle. Returns the cost
+    // in units of surface x triangles and the number of groups.
+    static float best_partition(const LeafTris& L, int k, uint8_t label[kLeafMax], int& groups) {
+        float best = std::numeric_limits<float>::infinity();
+        uint8_t cur[kLeafMax] = {0, 0, 0, 0};
+        std::function<void(uint32_t, int)> rec = [&](uint32_t i, int used) {
+            if (i == L.count) {
+                float cost = 0.0f;
+                for (int g = 0; g < used; ++g) {
+                    Box b;
+                    b.reset();
+                    uint32_t n = 0;
+                    for (uint32_t j = 0; j < L.count; ++j)
+                        if (cur[j] == g) b.grow(L.tb[j]), ++n;
+                    cost += b.half_area() * float(n);
+                }
+                if (cost < best) {
+                    best = cost, groups = used;
+                    for (uint32_t j = 0; j < L.count; ++j) label[j] = cur[j];
+                }
+                return;
+            }
+            for (int g = 0; g <= used && g < k; ++g) cur[i] = uint8_t(g), rec(i + 1, std::max(used, g + 1));
+        };
+        rec(0, 0);
+        return best;
+    }
+
+    std::vector<std::array<uint8_t, 5>> dp_open;  // [binary node][k] = slots given to child 0 (0: the node stays closed)
+    std::vector<uint8_t> dp_open_root;            // [binary node] = slots given to child 0 when the node IS a wide node
+    void plan_openings() {
+        const size_t nn = nodes2.size();
+        // (one wide visit = 1; a triangle of a leaf 0.2: measured on the GPU, 0.03-0.2 are equal, 0.35 costs the rough
+        // stand-in 1 %, 1.0 costs it 6 %: profiles/r05_collapse_ab.txt)
+        const float c_node = 1.0f, c_tri = 0.2f;
+        std::vector<std::array<float, 5>> E(nn);
+        dp_open.assign(nn, std::array<uint8_t, 5>{});
+        dp_open_root.assign(nn, 1);
+        std::vector<float> area(nn, 0.0f);
+        {
+            Box rb;
+            rb.reset();
+            const Node2& r = nodes2[0];
+            for (int k = 0; k < 3; ++k)
+                rb.lo[k] = std::min(r.lo0[k], r.lo1[k]), rb.hi[k] = std::max(r.hi0[k], r.hi1[k]);
+            area[0] = rb.half_area();
+        }
+        for (size_t i = 0; i < nn; ++i) {  // (children come after their parents)
+            const Node2& n = nodes2[i];
+            Box a, b;
+            for (int k = 0; k < 3; ++k) a.lo[k] = n.lo0[k], a.hi[k] = n.hi0[k], b.lo[k] = n.lo1[k], b.hi[k] = n.hi1[k];
+            if (n.child0 >= 0) area[size_t(n.child0)] = a.half_area();
+            if (n.child1 >= 0) area[size_t(n.child1)] = b.half_area();
+        }
+        auto leaf_table = [&](int32_t ref, const Box& box, float e[5]) {
+            LeafTris L;
+            leaf_tris(ref, box, L);
+            e[1] = box.half_area() * c_tri * float(L.count);
+            uint8_t label[kLeafMax];
+            int groups;
+            for (int k = 2; k <= 4; ++k) e[k] = L.count > 1 ? std::min(e[k - 1], c_tri * best_partition(L, k, label, groups)) : e[1];
+        };
+        for (size_t ii = nn; ii-- > 0;) {
+            const Node2& n = nodes2[ii];
+            float el[5], er[5];
+            {
+                Box a, b;
+                for (int k = 0; k < 3; ++k) a.lo[k] = n.lo0[k], a.hi[k] = n.hi0[k], b.lo[k] = n.lo1[k], b.hi[k] = n.hi1[k];
+                if (n.child0 < 0) leaf_table(n.child0, a, el);
+                if (n.child1 < 0) leaf_table(n.child1, b, er);
+                for (int k = 1; k <= 4; ++k) {
+                    if (n.child0 >= 0) el[k] = E[size_t(n.child0)][k];
+                    if (n.child1 >= 0) er[k] = E[size_t(n.child1)][k];
+                }
+            }
+            float D[5];
+            uint8_t Dl[5];
+            for (int k = 2; k <= 4; ++k) {
+                D[k] = std::numeric_limits<float>::infinity(), Dl[k] = 1;
+                for (int l = 1; l < k; ++l)
+                    if (el[l] + er[k - l] < D[k]) D[k] = el[l] + er[k - l], Dl[k] = uint8_t(l);
+            }
+            const float C = area[ii] * c_node + D[4];
+            dp_open_root[ii] = Dl[4];
+            E[ii][1] = C;
+            for (int k = 2; k <= 4; ++k) {
+                if (D[k] < C)
+                    E[ii][k] = D[k], dp_open[ii][k] = Dl[k];
+                else
+                    E[ii][k] = C, dp_open[ii][k] = 0;
+            }
+        }
+    }
+
+    // Binary -> 4-wide by the table of plan_openings().
     uint32_t collapse(int32_t n2, uint32_t depth) {
         struct Cand {
             int32_t ref;
@@ -622,81 +750,47 @@ struct Builder {
                 b.box.lo[k] = n.lo1[k], b.box.hi[k] = n.hi1[k];
             }
         };
-        // Slots still free when only leaves are left go to the two halves of the largest leaf of two or more
-        // triangles (the best of its two-way partitions by surface x count): two tighter boxes for the same node.
-        // The leaf's records are regrouped in place; each half keeps the ascending order of reference indices.
-        auto split_leaf = [&](const Cand& leaf, Cand& a, Cand& b) {
-            const uint32_t code = uint32_t(~leaf.ref), first = code >> kLeafBits, count = (code & uint32_t(kLeafMax - 1)) + 1u;
-            BvhTri t[kLeafMax];
-            Box tb[kLeafMax];
-            float te12[kLeafMax];
-            const float fmax = std::numeric_limits<float>::max();
-            for (uint32_t i = 0; i < count; ++i) {
-                t[i] = out.tris[first + i];
-                const float v0[3] = {t[i].v0[0], t[i].v0[1], t[i].v0[2]};
-                const float e1[3] = {t[i].e1x, t[i].e1yz[0], t[i].e1yz[1]}, e2[3] = {t[i].e2xy[0], t[i].e2xy[1], t[i].e2z};
-                float v1[3], v2[3];
-                for (int k = 0; k < 3; ++k) {
-                    v1[k] = std::min(std::max(v0[k] + e1[k], -fmax), fmax);
-                    v2[k] = std::min(std::max(v0[k] + e2[k], -fmax), fmax);
-                }
-                tb[i].reset();
-                tb[i].grow(v0), tb[i].grow(v1), tb[i].grow(v2);
-                te12[i] = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) *
-                          std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
-            }
-            uint32_t best_mask = 1;
-            float best_cost = std::numeric_limits<float>::infinity();
-            for (uint32_t mask = 1; mask < (1u << count) - 1u; mask += 2) {  // triangle 0 always in the first half
-                Box ba, bb;
-                ba.reset(), bb.reset();
-                uint32_t na = 0;
-                for (uint32_t i = 0; i < count; ++i) (mask >> i & 1u) ? (ba.grow(tb[i]), ++na) : (bb.grow(tb[i]), 0u);
-                const float cost = ba.half_area() * float(na) + bb.half_area() * float(count - na);
-                if (cost < best_cost) best_cost = cost, best_mask = mask;
-            }
-            uint32_t pos = first, na = 0;
-            a.box.reset(), b.box.reset();
-            a.e12 = b.e12 = 0.0f;
-            for (int half = 1; half >= 0; --half)
-                for (uint32_t i = 0; i < count; ++i)
-                    if (int(best_mask >> i & 1u) == half) {
-                        out.tris[pos++] = t[i];
-                        Cand& dst = half ? a : b;
-                        dst.box.grow(tb[i]);
-                        dst.e12 = std::max(dst.e12, te12[i]);
-                        na += uint32_t(half);
-                    }
-            // (a reference cut by a spatial split: its part lies in the leaf's box, which is smaller than the triangle's)
-            for (int k = 0; k < 3; ++k) {
-                a.box.lo[k] = std::max(a.box.lo[k], leaf.box.lo[k]), a.box.hi[k] = std::min(a.box.hi[k], leaf.box.hi[k]);
-                b.box.lo[k] = std::max(b.box.lo[k], leaf.box.lo[k]), b.box.hi[k] = std::min(b.box.hi[k], leaf.box.hi[k]);
-            }
-            a.ref = ~int32_t((first << kLeafBits) | (na - 1u));
-            b.ref = ~int32_t(((first + na) << kLeafBits) | (count - na - 1u));
-            ++out.n_leaves;
-        };
         Cand c[4];
-        int n = 2;
-        children_of(n2, c[0], c[1]);
-        for (int pass = 0; pass < 2; ++pass)
-            while (n < 4) {
-                int pick = -1;
-                float best = -1.0f;
-                for (int i = 0; i < n; ++i) {
-                    const bool ok = pass == 0 ? c[i].ref >= 0
-                                              : c[i].ref < 0 && (uint32_t(~c[i].ref) & uint32_t(kLeafMax - 1)) != 0u;
-                    if (ok && c[i].box.half_area() > best) best = c[i].box.half_area(), pick = i;
+        int n = 0;
+        // The openings the table chose for this node's four slots: a closed binary node becomes a wide node of its own, a
+        // leaf given several slots is regrouped in place into that many leaves (each keeps the ascending order of
+        // reference indices).
+        std::function<void(const Cand&, int)> gather = [&](const Cand& x, int k) {
+            if (x.ref < 0 && k >= 2 && (uint32_t(~x.ref) & uint32_t(kLeafMax - 1)) != 0u) {
+                LeafTris L;
+                leaf_tris(x.ref, x.box, L);
+                uint8_t label[kLeafMax];
+                int groups = 1;
+                const float cost = best_partition(L, k, label, groups);
+                if (groups > 1 && cost < x.box.half_area() * float(L.count)) {
+                    uint32_t pos = L.first;
+                    for (int g = 0; g < groups; ++g) {
+                        Cand& d = c[n++];
+                        d.box.reset(), d.e12 = 0.0f;
+                        const uint32_t start = pos;
+                        for (uint32_t j = 0; j < L.count; ++j)
+                            if (label[j] == g) out.tris[pos++] = L.t[j], d.box.grow(L.tb[j]), d.e12 = std::max(d.e12, L.te12[j]);
+                        d.ref = ~int32_t((start << kLeafBits) | (pos - start - 1u));
+                    }
+                    out.n_leaves += uint32_t(groups - 1);
+                    return;
                 }
-                if (pick < 0) break;
-                Cand a, b;
-                if (pass == 0)
-                    children_of(c[pick].ref, a, b);
-                else
-                    split_leaf(c[pick], a, b);
-                c[pick] = a;
-                c[n++] = b;
             }
+            const int left = x.ref >= 0 && k >= 2 ? dp_open[size_t(x.ref)][size_t(k)] : 0;
+            if (left == 0) {
+                c[n++] = x;
+                return;
+            }
+            Cand a, b;
+            children_of(x.ref, a, b);
+            gather(a, left), gather(b, k - left);
+        };
+        {
+            Cand a, b;
+            children_of(n2, a, b);
+            const int left = dp_open_root[size_t(n2)];
+            gather(a, left), gather(b, 4 - left);
+        }
         const uint32_t me = uint32_t(out.nodes.size());
         out.nodes.emplace_back();
         out.max_depth = std::max(out.max_depth, depth);
