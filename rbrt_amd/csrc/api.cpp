@@ -125,6 +125,8 @@ struct rbrt_hip_scene {
     int device = 0;
     uint32_t n_spheres = 0, n_meshes = 0, n_elem_tris = 0;
     std::vector<void*> allocs;  // everything hipMalloc'ed for the scene itself
+    char* slab_cur = nullptr;   // dev_alloc: the scene's arrays below kSlabMaxPiece are cut from slabs (a hipMalloc / hipFree
+    size_t slab_left = 0;       // pair costs 0.1-0.15 ms whatever its size: eleven of them were a tenth of a one-shot call)
     DevSphere* d_spheres = nullptr;
     DevTriangle* d_elem_tris = nullptr;  // BasicTriangle elements (triangle.rs:9-34)
     uint32_t* d_elems = nullptr;         // Scene::elements order (null: no triangles, element e = sphere e)
@@ -215,6 +217,7 @@ struct rbrt_hip_scene {
     uint32_t helper_min_items = 4096;
     uint32_t helper_rounds = 4;        // RBRT_HELPER_ROUNDS (lab)
     hipStream_t prep_stream = nullptr;  // high priority: the tile passes of cameras the lanes have not seen
+    bool one_shot = false;              // made by rbrt_hip_render for one render (CreateHint::one_shot)
     hipStream_t aux_stream = nullptr;   // RBRT_HELPERS=2 (tests): carries the helper launches
     void* h_zeros = nullptr;            // pinned: what a lane's work counters are set to again behind a helper launch
     uint64_t launch_no = 0;
@@ -391,12 +394,34 @@ int ensure_device(int device) {
     return RBRT_OK;
 }
 
+// Device memory that lives as long as the scene (released by rbrt_hip_scene_destroy, never one by one). Called from the
+// thread that holds the scene (scene_create, or a render call under s->mu); the background builder has allocations of its own.
+constexpr size_t kSlabBytes = 32u << 20, kSlabMaxPiece = 8u << 20, kSlabAlign = 512;
+hipError_t dev_alloc(rbrt_hip_scene* s, size_t bytes, void** out) {
+    bytes = (std::max<size_t>(bytes, 1) + kSlabAlign - 1) & ~(kSlabAlign - 1);
+    *out = nullptr;
+    if (bytes > kSlabMaxPiece) {
+        const hipError_t e = hipMalloc(out, bytes);
+        if (e == hipSuccess) s->allocs.push_back(*out);
+        return e;
+    }
+    if (bytes > s->slab_left) {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, kSlabBytes);
+        if (e != hipSuccess) return e;
+        s->allocs.push_back(p);
+        s->slab_cur = static_cast<char*>(p), s->slab_left = kSlabBytes;
+    }
+    *out = s->slab_cur;
+    s->slab_cur += bytes, s->slab_left -= bytes;
+    return hipSuccess;
+}
+
 template <class T>
 int upload(rbrt_hip_scene* s, const std::vector<T>& host, T** out) {
     void* d = nullptr;
     size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
-    HIP_TRY(hipMalloc(&d, bytes));
-    s->allocs.push_back(d);
+    HIP_TRY(dev_alloc(s, bytes, &d));
     if (!host.empty()) HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<T*>(d);
     return RBRT_OK;
@@ -547,13 +572,11 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         // one render; the per-wave scratch -- 50 MB per lane -- is made when the lane first gets a launch, size_lane)
         static const unsigned long long zeros[kWorkShards * kWorkCounterStride] = {};
         for (auto& B : L.bufs) {
-            HIP_TRY(hipMalloc(&p, counter_bytes));
-            s->allocs.push_back(p);
+            HIP_TRY(dev_alloc(s, counter_bytes, &p));
             B.d_work_counter = static_cast<unsigned long long*>(p);
             HIP_TRY(hipMemcpy(p, zeros, counter_bytes, hipMemcpyHostToDevice));
         }
-        HIP_TRY(hipMalloc(&p, 64));
-        s->allocs.push_back(p);
+        HIP_TRY(dev_alloc(s, 64, &p));
         L.d_helper_words = static_cast<uint32_t*>(p);
         HIP_TRY(hipMemcpy(p, zeros, 64, hipMemcpyHostToDevice));
         // the lane is recorded before its stream and events exist, so that a failure below leaves them to
@@ -777,15 +800,15 @@ struct CreateHint {
 // (2.5-3.5 % measured). A handle starts with the cheaper build and, where that was the device's, gets the host's tree
 // in the background (struct Refine); a one-shot call adds what the slower frames of ITS render would cost.
 //   entries        500   2000   8000   32000   69451   262144   871414
-//   host, ms      0.22   0.68   2.68   11.3     8.2     39.5    143.5    (build + upload; threaded from 32768 entries, 16 threads)
-//   device, ms    1.18   1.56   1.91    2.55    3.16     4.60     6.57   (upload + build: a dozen dependent stages, then ~25 rounds)
-constexpr double kHostBuildSecPerTri = 0.33e-6, kHostThreadedFrom = 32768.0, kDeviceBuildSec0 = 1.0e-3, kDeviceBuildSecPerDoubling = 0.28e-3,
+//   host, ms      3.0   10.5   41.0   119.7    42.4    149.2    493.3    (build; spatial splits; threaded from 32768 entries, 16 threads)
+//   device, ms    0.90   1.07   1.31    1.92    2.44     3.67     5.46   (upload + build: a dozen dependent stages, ~25 rounds in 4 batches)
+constexpr double kHostBuildSecPerTri = 4.5e-6, kHostThreadedFrom = 32768.0, kDeviceBuildSec0 = 0.9e-3, kDeviceBuildSecPerDoubling = 0.18e-3,
                  kDeviceBuildSecPerTri = 3.0e-9, kDeviceTreeSlowdown = 0.04;
 bool device_builder_is_cheaper(uint32_t n_total, const CreateHint& hint) {
     const double n = double(n_total);
     const double threads = double(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
-    // (the top of the host's tree is built by one thread: 16 threads halve the time, they do not divide it by 16)
-    const double host_s = kHostBuildSecPerTri * n * (n < kHostThreadedFrom ? 1.0 : 0.35 + 1.3 / threads);
+    // (the top of the host's tree is built by one thread)
+    const double host_s = kHostBuildSecPerTri * n * (n < kHostThreadedFrom ? 1.0 : 0.05 + 1.2 / threads);
     const double device_s = kDeviceBuildSec0 + kDeviceBuildSecPerDoubling * std::log2(std::max(n, 500.0) / 500.0) + kDeviceBuildSecPerTri * n +
                             (hint.one_shot ? kDeviceTreeSlowdown * hint.render_s_est : 0.0);
     return n_total >= 8u && device_s < host_s;
@@ -968,8 +991,7 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
     {
         void* p = nullptr;
         const size_t bytes = std::max<size_t>(size_t(tri_total) * sizeof(BvhTri), 64);
-        HIP_TRY_BAIL(hipMalloc(&p, bytes));
-        s->allocs.push_back(p);
+        HIP_TRY_BAIL(dev_alloc(s, bytes, &p));
         s->d_tris = static_cast<BvhTri*>(p);  // (records no leaf points at are never read: left as they are)
     }
     // Builder of each mesh's first tree: whichever costs this call less (device_builder_is_cheaper), the host's tree
@@ -979,6 +1001,7 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
     int builder_mode = 0;  // 0 by cost, 1 host, 2 device
     if (const char* e = std::getenv("RBRT_BVH_BUILDER")) builder_mode = !std::strcmp(e, "host") ? 1 : !std::strcmp(e, "device") ? 2 : 0;
     bool refine_allowed = builder_mode == 0 && !hint.one_shot;
+    s->one_shot = hint.one_shot;
     if (const char* e = std::getenv("RBRT_BVH_REFINE")) refine_allowed = refine_allowed && e[0] != '0';
     uint32_t device_min_tris = 0;  // (lab: a threshold on the entry count instead of the cost rule)
     bool device_min_set = false;
@@ -997,8 +1020,7 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
         Normal4* d_normals = nullptr;
         {
             void* p = nullptr;
-            HIP_TRY_BAIL(hipMalloc(&p, std::max<size_t>(size_t(m.n_total) * sizeof(Normal4), 16)));
-            s->allocs.push_back(p);
+            HIP_TRY_BAIL(dev_alloc(s, std::max<size_t>(size_t(m.n_total) * sizeof(Normal4), 16), &p));
             d_normals = static_cast<Normal4*>(p);
         }
         bool built = false;
@@ -1187,7 +1209,11 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
         for (void* p : r->allocs) (void)hipFree(p);
         r->allocs.clear();
     }
+    const bool trace_destroy = lab_env("RBRT_TRACE_CREATE");
+    const double td0 = now_s();
     (void)hipDeviceSynchronize();  // lane streams included
+    const double td1 = now_s();
+    double t_big = 0.0;
     for (auto& L : s->lanes) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
         if (L.ev_helper) (void)hipEventDestroy(L.ev_helper);
@@ -1196,21 +1222,29 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
         if (L.ev_traced) (void)hipEventDestroy(L.ev_traced);
         for (auto& B : L.bufs) {
             if (B.ev_resolved) (void)hipEventDestroy(B.ev_resolved);
+            const double tb = now_s();
             if (B.d_sample_buf) (void)hipFree(B.d_sample_buf);
+            t_big += now_s() - tb;
         }
         for (auto& T : L.tiles) {
-            if (T.d_cull) (void)hipFree(T.d_cull);
-            if (T.d_lists) (void)hipFree(T.d_lists);
             if (T.ev_lists) (void)hipEventDestroy(T.ev_lists);
             if (T.ev_free) (void)hipEventDestroy(T.ev_free);
         }
     }
+    const double td2 = now_s();
     if (s->prep_stream) (void)hipStreamDestroy(s->prep_stream);
     if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
+    const double td3 = now_s();
     if (s->h_zeros) (void)hipHostFree(s->h_zeros);
+    const double td4 = now_s();
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->d_acc) (void)hipFree(s->d_acc);
+    const double td5 = now_s();
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    if (trace_destroy)
+        std::fprintf(stderr, "[rbrt_hip] scene_destroy: sync %.3f ms, lanes %.3f (sample buffers %.3f), streams %.3f, pinned %.3f, %zu allocations %.3f, %zu events %.3f\n",
+                     (td1 - td0) * 1e3, (td2 - td1) * 1e3, t_big * 1e3, (td3 - td2) * 1e3, (td4 - td3) * 1e3, s->allocs.size(), (td5 - td4) * 1e3,
+                     s->events.size(), (now_s() - td5) * 1e3);
     delete s;
     return RBRT_OK;
 }
@@ -1316,7 +1350,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         if (s->aux_stream) HIP_TRY(hipStreamSynchronize(s->aux_stream));
         return RBRT_OK;
     };
-    if (!acc && per_sample > s->acc_bytes) {
+    // (running sums between the batches of one call: a call of one batch has none)
+    if (!acc && batch < s_end - s_begin && per_sample > s->acc_bytes) {
         if (s->d_acc) {
             if (int rc = sync_lanes()) return rc;
             HIP_TRY(hipFree(s->d_acc));
@@ -1388,12 +1423,10 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         if (!L.d_gseq) {  // the lane's per-wave scratch: scatter records beyond the four in LDS (written before they are read: no
                           // initial value), the overflow of the LDS stacks
             void* p = nullptr;
-            HIP_TRY(hipMalloc(&p, megakernel_gseq_bytes(s->scratch_waves, s->pool)));
-            s->allocs.push_back(p);
+            const size_t gseq_bytes = (megakernel_gseq_bytes(s->scratch_waves, s->pool) + kSlabAlign - 1) & ~(kSlabAlign - 1);
+            HIP_TRY(dev_alloc(s, gseq_bytes + megakernel_gstack_bytes(s->scratch_waves), &p));
             L.d_gseq = static_cast<uint32_t*>(p);
-            HIP_TRY(hipMalloc(&p, megakernel_gstack_bytes(s->scratch_waves)));
-            s->allocs.push_back(p);
-            L.d_gstack = static_cast<uint32_t*>(p);
+            L.d_gstack = reinterpret_cast<uint32_t*>(static_cast<char*>(p) + gseq_bytes);
         }
         for (auto& B : L.bufs) {
             if (need <= B.sample_buf_bytes) continue;
@@ -1412,14 +1445,13 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
                 if (s->prep_stream) HIP_TRY(hipStreamSynchronize(s->prep_stream));
             }
             for (auto& T : L.tiles) {
-                if (T.d_cull) HIP_TRY(hipFree(T.d_cull));
-                if (T.d_lists) HIP_TRY(hipFree(T.d_lists));
+                // (a set that has grown leaves its old arrays in the slab: a few hundred KB per frame size, until destroy)
                 T.d_cull = T.d_lists = nullptr;
                 T.key_valid = false, T.free_recorded = false;
                 void* p = nullptr;
-                HIP_TRY(hipMalloc(&p, size_t(n_tiles) * sizeof(uint32_t)));
+                HIP_TRY(dev_alloc(s, size_t(n_tiles) * sizeof(uint32_t), &p));
                 T.d_cull = static_cast<uint32_t*>(p);
-                HIP_TRY(hipMalloc(&p, lists_need * sizeof(uint32_t)));
+                HIP_TRY(dev_alloc(s, lists_need * sizeof(uint32_t), &p));
                 T.d_lists = static_cast<uint32_t*>(p);
                 if (!T.ev_lists) HIP_TRY(hipEventCreateWithFlags(&T.ev_lists, hipEventDisableTiming));
                 if (!T.ev_free) HIP_TRY(hipEventCreateWithFlags(&T.ev_free, hipEventDisableTiming));
@@ -1431,11 +1463,17 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
     if (streams_now)
         for (uint32_t li = 0; li < depth; ++li)
             if (int rc = size_lane(li)) return rc;
-    if (tile_pass && !s->prep_stream) {
+    const auto ensure_prep_stream = [&]() -> int {
+        if (s->prep_stream) return RBRT_OK;
         int prio_low = 0, prio_high = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: low >= high)
         HIP_TRY(hipStreamCreateWithPriority(&s->prep_stream, hipStreamNonBlocking, prio_high));
-    }
+        return RBRT_OK;
+    };
+    // (a one-shot scene's launch has the GPU to itself and runs its tile pass on its own stream: it makes the prep stream
+    // only if a second batch ever overlaps the first -- creating and destroying one costs the call 0.3 ms)
+    if (tile_pass && !s->one_shot)
+        if (int rc = ensure_prep_stream()) return rc;
     // The tile pass of a lane that has never had one runs now, for this camera, on the caller's stream (the lanes' buffers
     // were made just above; in the middle of a stream of frames a first pass would have to find room beside resident waves).
     if (tile_pass && streams_now) {
@@ -1568,6 +1606,8 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
                 // prep stream: beside the launches in flight, ahead of this one
                 // (a launch that has the GPU to itself has nothing to run beside: its pass goes on its own stream, one
                 // cross-stream hop less in front of a blocking frame)
+                if (overlapped)
+                    if (int rc = ensure_prep_stream()) return rc;
                 hipStream_t cs = overlapped ? s->prep_stream : ts;
                 if (S->free_recorded) HIP_TRY(hipStreamWaitEvent(cs, S->ev_free, 0));
                 if (S->key_valid) HIP_TRY(hipStreamWaitEvent(cs, S->ev_lists, 0));
@@ -1826,11 +1866,7 @@ int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const r
     float* d_rad = nullptr;
     uint8_t* d_rgb = nullptr;
     int rc = RBRT_OK;
-    auto cleanup = [&]() {
-        if (d_rad) (void)hipFree(d_rad);
-        if (d_rgb) (void)hipFree(d_rgb);
-        rbrt_hip_scene_destroy(s);
-    };
+    auto cleanup = [&]() { rbrt_hip_scene_destroy(s); };  // (the images are the scene's memory: dev_alloc)
 #define TRY_OR_CLEAN(expr)                                                                  \
     do {                                                                                    \
         hipError_t _e = (expr);                                                             \
@@ -1844,8 +1880,13 @@ int rbrt_hip_render(const rbrt_camera_t* cam, const rbrt_scene_t* scene, const r
         cleanup();
         return RBRT_OK;
     }
-    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_rad), n_out * 3 * sizeof(float)));
-    if (out_rgb8) TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_rgb), n_out * 3));
+    {
+        void* p = nullptr;
+        const size_t rad_bytes = (n_out * 3 * sizeof(float) + kSlabAlign - 1) & ~(kSlabAlign - 1);
+        TRY_OR_CLEAN(dev_alloc(s, rad_bytes + (out_rgb8 ? n_out * 3 : 0), &p));
+        d_rad = static_cast<float*>(p);
+        if (out_rgb8) d_rgb = static_cast<uint8_t*>(p) + rad_bytes;
+    }
     rc = rbrt_hip_render_device(s, cam, opts, nullptr, d_rad, d_rgb);
     if (rc) {
         cleanup();

@@ -28,6 +28,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -55,7 +56,8 @@ struct Work {  // build state shared by the kernels
     uint32_t n_nodes;           // 4-wide nodes allocated so far
     uint32_t overflow;          // bit 0: node array full; bit 1: depth budget exceeded
     uint32_t max_depth;
-    uint32_t q_count[2];        // collapse queues
+    uint32_t q_count[3];        // collapse queues: level d reads [d % 3], fills [(d + 1) % 3], zeroes [(d + 2) % 3]
+    uint32_t ploc_m[2];         // PLOC: clusters before / after the round (in turn)
     float max_e12;
     uint32_t n_internal;        // PLOC: internal nodes created so far
     uint32_t root;              // id of the root
@@ -237,10 +239,17 @@ __global__ __launch_bounds__(kTpb) void fit(const Work* w, Tree t, uint32_t* __r
 // splits are the Morton grid's, this looks at surfaces, and gives trees close to a top-down SAH build's.
 constexpr int kPlocRadius = 16;  // default search radius (RBRT_PLOC_RADIUS overrides: experiments)
 
-__global__ __launch_bounds__(kTpb) void ploc_nearest(const uint32_t* __restrict__ cl, uint32_t m, const float* __restrict__ nbox,
-                                                    uint32_t* __restrict__ nn, uint32_t radius) {
+// The rounds of one batch are launched without the host in between: a round's cluster count is read from device memory
+// (`m_ptr`), the launches are sized by the count the host last saw (an upper bound: counts only fall).
+__global__ __launch_bounds__(kTpb) void ploc_nearest(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ m_ptr,
+                                                    const float* __restrict__ nbox, uint32_t* __restrict__ nn, uint32_t radius) {
     const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    const uint32_t m = *m_ptr;
     if (i >= m) return;
+    if (m < 2u) {  // (a round after the last merge: nothing to pair with)
+        nn[i] = i;
+        return;
+    }
     const float4 a0 = reinterpret_cast<const float4*>(nbox + size_t(cl[i]) * 8u)[0];
     const float4 a1 = reinterpret_cast<const float4*>(nbox + size_t(cl[i]) * 8u)[1];
     const uint32_t j0 = i > radius ? i - radius : 0u;
@@ -260,13 +269,18 @@ __global__ __launch_bounds__(kTpb) void ploc_nearest(const uint32_t* __restrict_
     nn[i] = bj;
 }
 
-__global__ __launch_bounds__(kTpb) void ploc_merge(Work* w, const uint32_t* __restrict__ cl, uint32_t m, const uint32_t* __restrict__ nn,
-                                                  Tree t, uint32_t n_leaves, uint32_t* __restrict__ cl_out, uint32_t* __restrict__ valid) {
+__global__ __launch_bounds__(kTpb) void ploc_merge(Work* w, const uint32_t* __restrict__ cl, const uint32_t* __restrict__ m_ptr,
+                                                  uint32_t m_bound, const uint32_t* __restrict__ nn, Tree t, uint32_t n_leaves,
+                                                  uint32_t* __restrict__ cl_out, uint32_t* __restrict__ valid) {
     const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
-    if (i >= m) return;
+    const uint32_t m = *m_ptr;
+    if (i >= m) {
+        if (i < m_bound) valid[i] = 0u;  // (the scan runs over the bound)
+        return;
+    }
     const uint32_t j = nn[i];
     uint32_t id = cl[i], keep = 1u;
-    if (nn[j] == i) {  // a mutual pair: the lower position carries the merged cluster, the higher one disappears
+    if (j != i && nn[j] == i) {  // a mutual pair: the lower position carries the merged cluster, the higher one disappears
         if (i < j) {
             const uint32_t a = cl[i], b = cl[j];
             id = n_leaves + atomicAdd(&w->n_internal, 1u);
@@ -289,15 +303,17 @@ __global__ __launch_bounds__(kTpb) void ploc_merge(Work* w, const uint32_t* __re
 }
 
 __global__ __launch_bounds__(kTpb) void ploc_compact(const uint32_t* __restrict__ cl_in, const uint32_t* __restrict__ valid,
-                                                    const uint32_t* __restrict__ pos, uint32_t m, uint32_t* __restrict__ cl_next,
-                                                    uint32_t* m_next) {
+                                                    const uint32_t* __restrict__ pos, const uint32_t* __restrict__ m_ptr,
+                                                    uint32_t* __restrict__ cl_next, uint32_t* m_next) {
     const uint32_t i = blockIdx.x * kTpb + threadIdx.x;
+    const uint32_t m = *m_ptr;
     if (i >= m) return;
     if (valid[i]) cl_next[pos[i]] = cl_in[i];
     if (i == m - 1u) *m_next = pos[i] + valid[i];
 }
 
 __global__ void ploc_root(Work* w, const uint32_t* cl) { w->root = cl[0]; }
+__global__ void ploc_seed(Work* w, uint32_t n) { w->ploc_m[0] = n; }
 __global__ void radix_root(Work* w) { w->root = w->n_valid; }  // internal node 0
 
 struct QItem {
@@ -309,13 +325,16 @@ struct QItem {
 // One level of the collapse. A candidate is a node of the binary tree; one with <= kLeafMax triangles below it becomes
 // a leaf, a larger one may be opened into its two children (the left child's triangles come first in the output).
 __global__ __launch_bounds__(kTpb) void collapse_level(Work* w, Tree t, uint32_t n_leaves, const uint32_t* __restrict__ sorted,
-                                                       uint32_t* __restrict__ order, const QItem* __restrict__ q_in, uint32_t n_in,
-                                                       QItem* __restrict__ q_out, uint32_t* q_out_count, uint32_t* q_in_count,
-                                                       BvhNode4* __restrict__ nodes, uint32_t node_cap, uint32_t tri_base, uint32_t depth) {
+                                                       uint32_t* __restrict__ order, const QItem* __restrict__ q_in,
+                                                       const uint32_t* __restrict__ q_in_count, QItem* __restrict__ q_out,
+                                                       uint32_t* q_out_count, uint32_t* q_spare_count, BvhNode4* __restrict__ nodes,
+                                                       uint32_t node_cap, uint32_t tri_base, uint32_t depth) {
     const uint32_t tid = blockIdx.x * kTpb + threadIdx.x;
-    // (this level's input count came in by value: its word is the NEXT level's output count, zeroed here instead of by a
-    // hipMemsetAsync per level -- whose first use in a process loads the runtime's fill kernels)
-    if (tid == 0) *q_in_count = 0u;
+    // (the levels of one batch are launched without the host in between: this level's count is read here, the launch is
+    // sized by a bound; the third count word -- the level after next's output -- is zeroed here instead of by a
+    // hipMemsetAsync per level, whose first use in a process loads the runtime's fill kernels)
+    if (tid == 0) *q_spare_count = 0u;
+    const uint32_t n_in = min(*q_in_count, node_cap);  // (overflow is flagged in w)
     if (tid >= n_in) return;
     const QItem it = q_in[tid];
     uint32_t c[4] = {uint32_t(t.left[it.bnode]), uint32_t(t.right[it.bnode]), 0u, 0u};
@@ -419,12 +438,18 @@ __global__ void init_work(Work* w) {
     w->n_nodes = 1;  // the root
     w->overflow = 0;
     w->max_depth = 0;
-    w->q_count[0] = w->q_count[1] = 0;
+    w->q_count[0] = w->q_count[1] = w->q_count[2] = 0;
+    w->ploc_m[0] = w->ploc_m[1] = 0;
     w->max_e12 = 0.0f;
     w->n_internal = 0;
     w->root = 0;
 }
-__global__ void root_info(Work* w, const float* nbox) { w->max_e12 = nbox[size_t(w->root) * 8u + 3u]; }
+// The tree's root: its pad for the mesh table, and the collapse's first candidate.
+__global__ void root_info(Work* w, const float* nbox, QItem* q0) {
+    w->max_e12 = nbox[size_t(w->root) * 8u + 3u];
+    q0[0] = QItem{w->root, 0u, 0u};
+    w->q_count[0] = 1u, w->q_count[1] = 0u, w->q_count[2] = 0u;
+}
 
 #define DEV_TRY(expr)                 \
     do {                              \
@@ -458,7 +483,7 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
     float* boxes = nullptr;
     uint64_t *keys = nullptr, *keys2 = nullptr;
     uint32_t *vals = nullptr, *sorted = nullptr, *order = nullptr, *arrived = nullptr;
-    uint32_t *cl[2] = {nullptr, nullptr}, *cl_tmp = nullptr, *nn = nullptr, *valid = nullptr, *pos = nullptr, *d_m = nullptr;
+    uint32_t *cl[2] = {nullptr, nullptr}, *cl_tmp = nullptr, *nn = nullptr, *valid = nullptr, *pos = nullptr;
     Tree t = {nullptr, nullptr, nullptr, nullptr, nullptr};
     QItem* queue[2] = {nullptr, nullptr};
     void *tmp = nullptr, *scan_tmp = nullptr;
@@ -536,13 +561,14 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
         DEV_TRY(alloc(&nn, n));
         DEV_TRY(alloc(&valid, n));
         DEV_TRY(alloc(&pos, n));
-        DEV_TRY(alloc(&d_m, 1));
         {
             char* tp = nullptr;
             DEV_TRY(alloc(&tp, scan_bytes + 16u));
             scan_tmp = tp;
         }
         hipLaunchKernelGGL(iota_kernel, dim3(blocks(n)), dim3(kTpb), 0, stream, cl[0], n);
+        hipLaunchKernelGGL(ploc_seed, dim3(1), dim3(1), 0, stream, w, n);
+        uint32_t* d_pm = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(w) + offsetof(Work, ploc_m));
         uint32_t mcur = n, radius = uint32_t(kPlocRadius);
         const char* lab = std::getenv("RBRT_HIP_LAB");  // (a lab knob: include/rbrt_hip_debug.h)
         if (const char* e = (lab && lab[0] == '1') ? std::getenv("RBRT_PLOC_RADIUS") : nullptr) radius = uint32_t(std::min(256, std::max(1, std::atoi(e))));
@@ -551,17 +577,26 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
         // (a round typically merges ~45 % of the clusters; with many ties in merged surface -- coincident or duplicate
         // triangles, non-finite areas -- the lowest-position tie-break leaves one mutual pair per round: a round that
         // merges under 1 % of the clusters hands the build to the radix tree below instead of running hundreds more)
+        // The host looks at the count once per BATCH of rounds (a look is a 40-us round trip, a round's four launches take
+        // less): half the rounds the count is expected to need at 45 % per round, three at least; a batch's launches are
+        // sized by the count at its start.
         while (mcur > 1u && rounds < 400 && !stalled) {
-            hipLaunchKernelGGL(ploc_nearest, dim3(blocks(mcur)), dim3(kTpb), 0, stream, cl[cur], mcur, t.nbox, nn, radius);
-            hipLaunchKernelGGL(ploc_merge, dim3(blocks(mcur)), dim3(kTpb), 0, stream, w, cl[cur], mcur, nn, t, n, cl_tmp, valid);
-            DEV_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, valid, pos, 0u, mcur, rocprim::plus<uint32_t>(), stream));
-            hipLaunchKernelGGL(ploc_compact, dim3(blocks(mcur)), dim3(kTpb), 0, stream, cl_tmp, valid, pos, mcur, cl[cur ^ 1], d_m);
+            const int batch = std::min(400 - rounds, std::max(3, int(std::ceil(std::log(double(mcur)) / 0.6 * 0.5))));
             const uint32_t before = mcur;
-            DEV_TRY(hipMemcpyAsync(&mcur, d_m, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            for (int r = 0; r < batch; ++r) {
+                const uint32_t* m_in = d_pm + (rounds & 1);
+                uint32_t* m_out = d_pm + ((rounds & 1) ^ 1);
+                hipLaunchKernelGGL(ploc_nearest, dim3(blocks(before)), dim3(kTpb), 0, stream, cl[cur], m_in, t.nbox, nn, radius);
+                hipLaunchKernelGGL(ploc_merge, dim3(blocks(before)), dim3(kTpb), 0, stream, w, cl[cur], m_in, before, nn, t, n, cl_tmp, valid);
+                DEV_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, valid, pos, 0u, before, rocprim::plus<uint32_t>(), stream));
+                hipLaunchKernelGGL(ploc_compact, dim3(blocks(before)), dim3(kTpb), 0, stream, cl_tmp, valid, pos, m_in, cl[cur ^ 1], m_out);
+                cur ^= 1;
+                ++rounds;
+            }
+            DEV_TRY(hipMemcpyAsync(&mcur, d_pm + (rounds & 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             DEV_TRY(hipStreamSynchronize(stream));
-            cur ^= 1;
-            ++rounds;
-            stalled = before > 256u && uint64_t(before - mcur) * 100u < before;
+            // (under 1 % per round, compounded over the batch)
+            stalled = before > 256u && double(mcur) > double(before) * std::pow(0.99, double(batch));
         }
         if (mcur == 1u) {
             hipLaunchKernelGGL(ploc_root, dim3(1), dim3(1), 0, stream, w, cl[cur]);
@@ -576,22 +611,22 @@ hipError_t build_bvh_device(const DeviceMeshSoa& soa, uint32_t n_total, BvhTri* 
         hipLaunchKernelGGL(fit, dim3(blocks(n)), dim3(kTpb), 0, stream, w, t, arrived);
         hipLaunchKernelGGL(radix_root, dim3(1), dim3(1), 0, stream, w);
     }
-    hipLaunchKernelGGL(root_info, dim3(1), dim3(1), 0, stream, w, t.nbox);
-    DEV_TRY(hipMemcpyAsync(&hw, w, sizeof(hw), hipMemcpyDeviceToHost, stream));
-    DEV_TRY(hipStreamSynchronize(stream));
-    // collapse, level by level: the queue sizes come back to the host once per level (a 4-byte read each)
-    const QItem root = {hw.root, 0u, 0u};
-    DEV_TRY(hipMemcpyAsync(queue[0], &root, sizeof(root), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(root_info, dim3(1), dim3(1), 0, stream, w, t.nbox, queue[0]);
+    // collapse, level by level: the queue size comes back to the host once per four levels (a level has at most four times
+    // the candidates of the one before: that sizes the launches in between)
     uint32_t n_in = 1, depth = 0;
     uint32_t* d_q_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(w) + offsetof(Work, q_count));
     while (n_in != 0 && depth <= uint32_t(kMaxBvhDepth)) {
-        const int curq = int(depth & 1u);
-        hipLaunchKernelGGL(collapse_level, dim3(blocks(n_in)), dim3(kTpb), 0, stream, w, t, n, sorted, order, queue[curq], n_in,
-                           queue[curq ^ 1], d_q_count + (curq ^ 1), d_q_count + curq, nodes, node_cap, tri_base, depth);
-        DEV_TRY(hipMemcpyAsync(&n_in, d_q_count + (curq ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        uint64_t bound = n_in;
+        for (int k = 0; k < 4 && depth <= uint32_t(kMaxBvhDepth); ++k, ++depth, bound *= 4u) {
+            const uint32_t qi = depth % 3u, qo = (depth + 1u) % 3u, qs = (depth + 2u) % 3u;
+            hipLaunchKernelGGL(collapse_level, dim3(blocks(uint32_t(std::min<uint64_t>(bound, node_cap)))), dim3(kTpb), 0, stream, w, t, n, sorted,
+                               order, queue[depth & 1u], d_q_count + qi, queue[(depth & 1u) ^ 1u], d_q_count + qo, d_q_count + qs, nodes,
+                               node_cap, tri_base, depth);
+        }
+        DEV_TRY(hipMemcpyAsync(&n_in, d_q_count + depth % 3u, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         DEV_TRY(hipStreamSynchronize(stream));
         if (n_in > node_cap) n_in = node_cap;  // (overflow is flagged in w)
-        ++depth;
     }
     hipLaunchKernelGGL(emit_tris, dim3(blocks(n)), dim3(kTpb), 0, stream, m, w, order, d_tris_out);
     DEV_TRY(hipMemcpyAsync(&hw, w, sizeof(hw), hipMemcpyDeviceToHost, stream));

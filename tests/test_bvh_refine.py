@@ -136,7 +136,7 @@ def test_refinement_can_be_turned_off_forced_builders_start_none_and_destroy_can
         t0 = time.perf_counter()
         hs.close()
         assert time.perf_counter() - t0 < 1.0  # (the 200k-triangle host build alone takes 0.03-0.3 s; a cancelled one ends within a node)
-    small = scenes.example_scene(oracle, 203)  # a small mesh: the host builder is the cheaper first tree, nothing follows
+    small = scenes.example_scene(oracle, 83)  # a small mesh: the host builder is the cheaper first tree, nothing follows
     with hip.HipScene(small) as hs:
         assert hs.create_times()["meshes_host_built"] == 1 and hs.refine_wait(0.0)[0] == 0
 
@@ -164,7 +164,7 @@ def test_three_meshes_two_of_them_refined_one_small(hip, oracle, monkeypatch):
     monkeypatch.delenv("RBRT_BVH_BUILDER", raising=False)
     monkeypatch.delenv("RBRT_BVH_REFINE", raising=False)
     a = scenes.standin_mesh(oracle, 9000, 45.0, (5.0, -1.8, -12.5), (0, 0, 0), abi.material(abi.MAT_LAMBERTIAN, (0.8, 0.2, 0.2)))
-    b = scenes.standin_mesh(oracle, 603, 20.0, (2.5, -1.2, -9.0), (0.1, 0.4, 0.2), abi.material(abi.MAT_DIELECTRIC, (1, 1, 1), 1.5))
+    b = scenes.standin_mesh(oracle, 91, 20.0, (2.5, -1.2, -9.0), (0.1, 0.4, 0.2), abi.material(abi.MAT_DIELECTRIC, (1, 1, 1), 1.5))
     c = scenes.standin_mesh(oracle, 12004, 30.0, (2.0, -1.0, -10.0), (0.3, 0.2, 0.1), abi.material(abi.MAT_METAL, (0.9, 0.9, 0.9), 0.1), kind="rough")
     sc = abi.SceneData(spheres=scenes.EXAMPLE_SPHERES, meshes=[a, b, c])
     cam = scenes.camera(oracle, 160, 120)

@@ -473,7 +473,7 @@ def test_cli_end_to_end_png(hip, oracle, tmp_path):
     assert all(j[k] >= 0 for k in parts) and abs(sum(j[k] for k in parts) - j["total_s"]) <= 0.02 * j["total_s"] + 1e-4
     assert j["other_s"] <= 0.05 * j["total_s"] + 0.005
     if not __import__("os").environ.get("RBRT_BVH_BUILDER"):
-        assert j["bvh_builder"] == "host"  # (1203 entries: the host builder is the cheaper first tree)
+        assert j["bvh_builder"] == "device"  # (1203 entries: the device builder is the cheaper first tree from ~200)
     got = np.array(Image.open(out))
     cam = scenes.camera(oracle, 128, 96)
     sc = scenes.example_scene(oracle, n_tris)
