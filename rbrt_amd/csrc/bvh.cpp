@@ -189,6 +189,10 @@ struct Builder {
     void split_ref(const Prim& p, int axis, float plane, Box& lb, Box& rb) const {
         float v[3][3];
         corners(p.src, v);
+        split_tri(v, p.box, axis, plane, lb, rb);
+    }
+    // (the same with the triangle's corners in hand: a reference chopped into many bins fetches them once)
+    static void split_tri(const float v[3][3], const Box& pbox, int axis, float plane, Box& lb, Box& rb) {
         lb.reset(), rb.reset();
         for (int i = 0; i < 3; ++i) {
             const float* a = v[i];
@@ -210,8 +214,8 @@ struct Builder {
         }
         lb.hi[axis] = std::min(lb.hi[axis], plane), rb.lo[axis] = std::max(rb.lo[axis], plane);
         for (int k = 0; k < 3; ++k) {  // inside the reference's own box
-            lb.lo[k] = std::max(lb.lo[k], p.box.lo[k]), lb.hi[k] = std::min(lb.hi[k], p.box.hi[k]);
-            rb.lo[k] = std::max(rb.lo[k], p.box.lo[k]), rb.hi[k] = std::min(rb.hi[k], p.box.hi[k]);
+            lb.lo[k] = std::max(lb.lo[k], pbox.lo[k]), lb.hi[k] = std::min(lb.hi[k], pbox.hi[k]);
+            rb.lo[k] = std::max(rb.lo[k], pbox.lo[k]), rb.hi[k] = std::min(rb.hi[k], pbox.hi[k]);
         }
     }
     static bool box_ok(const Box& b) { return b.lo[0] <= b.hi[0] && b.lo[1] <= b.hi[1] && b.lo[2] <= b.hi[2]; }
@@ -315,13 +319,15 @@ struct Builder {
                         if (b0 == b1) {
                             bin_box[b0].grow(p.box);
                         } else {  // chopped into the bins it crosses
-                            Prim cur = p;
+                            float v[3][3];
+                            corners(p.src, v);
+                            Box cur = p.box;
                             for (int bb = b0; bb < b1; ++bb) {
                                 Box l, r;
-                                split_ref(cur, axis, planes[bb + 1], l, r);
+                                split_tri(v, cur, axis, planes[bb + 1], l, r);
                                 if (box_ok(l)) bin_box[bb].grow(l);
                                 if (!box_ok(r)) break;
-                                cur.box = r;
+                                cur = r;
                                 if (bb + 1 == b1) bin_box[b1].grow(r);
                             }
                         }
