@@ -198,6 +198,7 @@ struct rbrt_hip_scene {
             bool valid = false;
             TraceParams P;
             uint32_t grid = 0, helper_waves = 0, rounds = 0;
+            uint64_t seq = 0;           // issue number: a later launch has more of its work left
             bool share = false;
         } open;
     };
@@ -208,6 +209,7 @@ struct rbrt_hip_scene {
     std::thread watcher;
     bool watcher_stop = false;
     double last_call_s = 0.0;      // when the caller last issued a launch
+    uint64_t open_seq = 0;         // Lane::Open::seq of the launch issued last
     uint32_t helpers_mode = 1;     // RBRT_HELPERS (lab): 0 never, 1 when the GPU has room and the caller has stopped issuing, 2 with every launch (tests)
     uint32_t n_helper_launches = 0;  // since set_timing(1)
     // RBRT_HELPER_MIN_ITEMS (lab): a helper wave joins a launch only while this many work items per wave are left. A wave
@@ -651,7 +653,8 @@ int issue_helper(rbrt_hip_scene* s, rbrt_hip_scene::Lane& L, uint32_t waves, hip
     L.helper_pending = true;
     L.open.helper_waves += waves, L.open.rounds += 1u;
     s->n_helper_launches += 1u;
-    if (s->trace_launches) std::fprintf(stderr, "[rbrt_hip] helper launch: lane %u, %u waves behind %u\n", unsigned(&L - s->lanes.data()), waves, P.wave_base);
+    if (s->trace_launches)
+        std::fprintf(stderr, "[rbrt_hip] t %.3f ms helper launch: lane %u, %u waves behind %u\n", now_s() * 1e3, unsigned(&L - s->lanes.data()), waves, P.wave_base);
     return RBRT_OK;
 }
 
@@ -680,6 +683,7 @@ void watcher_main(rbrt_hip_scene* s) {
                     continue;
                 }
                 L.open.valid = false;  // (ended, or an error the caller's next call will meet)
+                if (s->trace_launches) std::fprintf(stderr, "[rbrt_hip] t %.3f ms lane %u: its launch has ended\n", now_s() * 1e3, unsigned(&L - s->lanes.data()));
             }
             // a lane with nothing in flight: its stream can carry a helper launch (unless it still carries one)
             if (L.stream && (!L.helper_carried || hipEventQuery(L.ev_carried) == hipSuccess)) carriers.push_back(&L);
@@ -688,14 +692,23 @@ void watcher_main(rbrt_hip_scene* s) {
         if (n_open == 0u || carriers.empty() || now_s() - s->last_call_s < 200e-6) continue;
         const uint32_t free_waves = s->n_waves > resident ? s->n_waves - resident : 0u;
         if (free_waves < s->n_cus) continue;
-        const uint32_t per = std::max(64u, (free_waves / n_open) / 64u * 64u);
+        // The free slots go to the launch issued LAST first (it has the most work left: of the launches of a stream's end the
+        // last one otherwise ends alone, a frame's time after the others), up to what its scratch holds, then to the one before.
+        std::vector<rbrt_hip_scene::Lane*> open_lanes;
+        for (auto& L : s->lanes)
+            if (L.open.valid) open_lanes.push_back(&L);
+        std::sort(open_lanes.begin(), open_lanes.end(), [](const rbrt_hip_scene::Lane* a, const rbrt_hip_scene::Lane* b) { return a->open.seq > b->open.seq; });
         uint32_t left = free_waves;
-        for (auto& L : s->lanes) {
+        for (rbrt_hip_scene::Lane* LP : open_lanes) {
+            rbrt_hip_scene::Lane& L = *LP;
             // (a short launch is over before a helper launch has arrived -- the watcher looks every 100 us --: with helpers an
             // eighth of the headline frame, 0.5 ms, came out 2 % SLOWER, a quarter 1 % slower, a half equal, the frame 2 %
             // faster: launches of 16 M work items or more are the ones that are helped)
-            if (!L.open.valid || L.open.rounds >= s->helper_rounds || left < 64u || carriers.empty() || L.open.P.n_items < (16ull << 20)) continue;
-            const uint32_t w = per < left ? per : left / 64u * 64u;
+            if (L.open.rounds >= s->helper_rounds || left < 64u || carriers.empty() || L.open.P.n_items < (16ull << 20)) continue;
+            const uint32_t has = L.open.grid + L.open.helper_waves;
+            const uint32_t room = s->scratch_waves > has ? (s->scratch_waves - has) / 64u * 64u : 0u;
+            const uint32_t w = std::min(left / 64u * 64u, room);
+            if (w < 64u) continue;
             rbrt_hip_scene::Lane* C = carriers.back();
             carriers.pop_back();
             if (issue_helper(s, L, w, C->stream) != RBRT_OK) break;  // (the caller's next call reports what is wrong with the device)
@@ -1623,7 +1636,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
             }
             S->last_used = ++s->launch_no;
             if (s->trace_launches)
-                std::fprintf(stderr, "[rbrt_hip] launch %llu lane %u %s grid list_mode %u set %d\n", (unsigned long long)s->launch_no,
+                std::fprintf(stderr, "[rbrt_hip] t %.3f ms launch %llu lane %u %s grid list_mode %u set %d\n", now_s() * 1e3, (unsigned long long)s->launch_no,
                              unsigned(&L - s->lanes.data()), overlapped ? "half" : "full", S->key.list_mode, int(S - L.tiles));
         }
         P.tile_cull = S ? S->d_cull : nullptr;
@@ -1643,6 +1656,7 @@ static int render_samples(rbrt_hip_scene_t* s, const rbrt_camera_t* cam, const r
         HIP_TRY(launch_trace_megakernel(P, grid, s->pool, stats, share_build, ts));
         if (piped && s->pool == 128u && s->helpers_mode != 0u) {
             L.open.valid = true, L.open.P = P, L.open.grid = grid, L.open.helper_waves = 0u, L.open.rounds = 0u, L.open.share = share_build;
+            L.open.seq = ++s->open_seq;
             if (s->helpers_mode == 2u) {  // (tests: a helper with every overlapped launch, on a stream of its own)
                 if (!s->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
                 if (int rc = issue_helper(s, L, s->n_cus, s->aux_stream)) return rc;
