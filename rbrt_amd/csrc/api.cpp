@@ -217,6 +217,7 @@ struct rbrt_hip_scene {
     // process (profiles/r05_helpers_threshold_sweep.txt), median / worst ms per step: no helpers 3.582 / 3.631; 1536: 3.506 /
     // 3.813 (three rounds of ten WORSE than without: late joiners turn bulk into drain); 4096: 3.513 / 3.544; 8192: 3.536 / 3.578
     uint32_t helper_min_items = 4096;
+    uint32_t helper_min_launch_mi = 16;  // RBRT_HELPER_MIN_LAUNCH_MI (lab): launches of this many Mi work items or more are helped
     uint32_t helper_rounds = 4;        // RBRT_HELPER_ROUNDS (lab)
     hipStream_t prep_stream = nullptr;  // high priority: the tile passes of cameras the lanes have not seen
     bool one_shot = false;              // made by rbrt_hip_render for one render (CreateHint::one_shot)
@@ -704,7 +705,7 @@ void watcher_main(rbrt_hip_scene* s) {
             // (a short launch is over before a helper launch has arrived -- the watcher looks every 100 us --: with helpers an
             // eighth of the headline frame, 0.5 ms, came out 2 % SLOWER, a quarter 1 % slower, a half equal, the frame 2 %
             // faster: launches of 16 M work items or more are the ones that are helped)
-            if (L.open.rounds >= s->helper_rounds || left < 64u || carriers.empty() || L.open.P.n_items < (16ull << 20)) continue;
+            if (L.open.rounds >= s->helper_rounds || left < 64u || carriers.empty() || L.open.P.n_items < (uint64_t(s->helper_min_launch_mi) << 20)) continue;
             const uint32_t has = L.open.grid + L.open.helper_waves;
             const uint32_t room = s->scratch_waves > has ? (s->scratch_waves - has) / 64u * 64u : 0u;
             const uint32_t w = std::min(left / 64u * 64u, room);
@@ -1135,6 +1136,7 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
             lab_u32("RBRT_OVERLAP_WAVES_PER_CU", 0, 16, s->overlap_waves_per_cu, err) &&
             lab_u32("RBRT_TILE_ISOLATED_MODE", 0, 4, s->isolated_list_mode, err) && lab_u32("RBRT_TILE_TAIL_DIV", 1, 1024, s->tile_tail_div, err) &&
             lab_u32("RBRT_HELPERS", 0, 2, s->helpers_mode, err) && lab_u32("RBRT_HELPER_MIN_ITEMS", 1, 1 << 24, s->helper_min_items, err) &&
+            lab_u32("RBRT_HELPER_MIN_LAUNCH_MI", 0, 4096, s->helper_min_launch_mi, err) &&
             lab_u32("RBRT_HELPER_ROUNDS", 1, 16, s->helper_rounds, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
         s->tile_classes_set = lab_env("RBRT_TILE_CLASSES") != nullptr;
