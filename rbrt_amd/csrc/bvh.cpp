@@ -219,6 +219,55 @@ struct Builder {
         }
     }
     static bool box_ok(const Box& b) { return b.lo[0] <= b.hi[0] && b.lo[1] <= b.hi[1] && b.lo[2] <= b.hi[2]; }
+    // A reference that spans bins b0 < b1 of `axis` (planes[j] = lower end of bin j): the box of the triangle's part in
+    // each of them -- bin b0 stands for everything below planes[b0 + 1], bin b1 for everything above planes[b1] --, inside
+    // the reference's own box, grown into bin_box. One walk over the corners and over the planes every edge crosses
+    // (a crossing point as in split_tri: on the plane exactly, widened by a few units in the last place elsewhere), where
+    // cutting the triangle plane by plane touched all three edges per plane.
+    static void chop_tri(const float v[3][3], const Box& pbox, int axis, const float* planes, int b0, int b1, Box* bin_box) {
+        Box part[kSpatialBins];
+        for (int b = b0; b <= b1; ++b) part[b].reset();
+        for (int i = 0; i < 3; ++i) {
+            const float x = v[i][axis];
+            int b = b0;
+            while (b < b1 && x > planes[b + 1]) ++b;  // planes[b] <= x <= planes[b + 1] (open-ended at b0 and b1)
+            part[b].grow(v[i]);
+            if (b < b1 && x == planes[b + 1]) part[b + 1].grow(v[i]);  // (a corner ON a plane belongs to both sides)
+        }
+        for (int i = 0; i < 3; ++i) {
+            const float* a = v[i];
+            const float* c = v[(i + 1) % 3];
+            const float xa = a[axis], xc = c[axis];
+            if (xa == xc) continue;
+            const float xlo = std::min(xa, xc), xhi = std::max(xa, xc);
+            const float inv = 1.0f / (xc - xa);
+            float slack[3], mn[3], mx[3];
+            for (int k = 0; k < 3; ++k) {
+                slack[k] = 4.0f * 1.1920929e-7f * (std::fabs(a[k]) + std::fabs(c[k])) + 1e-30f;
+                mn[k] = std::min(a[k], c[k]), mx[k] = std::max(a[k], c[k]);
+            }
+            for (int j = b0 + 1; j <= b1; ++j) {
+                const float plane = planes[j];
+                if (!(xlo < plane && plane < xhi)) continue;
+                const float t = (plane - xa) * inv;
+                float lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) {
+                    const float x = a[k] + (c[k] - a[k]) * t;
+                    lo[k] = std::min(std::max(x - slack[k], mn[k]), mx[k]);
+                    hi[k] = std::max(std::min(x + slack[k], mx[k]), mn[k]);
+                }
+                lo[axis] = hi[axis] = plane;
+                part[j - 1].grow(lo), part[j - 1].grow(hi), part[j].grow(lo), part[j].grow(hi);
+            }
+        }
+        for (int b = b0; b <= b1; ++b) {
+            Box& q = part[b];
+            if (b > b0) q.lo[axis] = std::max(q.lo[axis], planes[b]);
+            if (b < b1) q.hi[axis] = std::min(q.hi[axis], planes[b + 1]);
+            for (int k = 0; k < 3; ++k) q.lo[k] = std::max(q.lo[k], pbox.lo[k]), q.hi[k] = std::min(q.hi[k], pbox.hi[k]);
+            if (box_ok(q)) bin_box[b].grow(q);
+        }
+    }
     static void set_centroid(Prim& p) {
         for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * p.box.lo[k] + 0.5f * p.box.hi[k];
     }
@@ -321,15 +370,7 @@ struct Builder {
                         } else {  // chopped into the bins it crosses
                             float v[3][3];
                             corners(p.src, v);
-                            Box cur = p.box;
-                            for (int bb = b0; bb < b1; ++bb) {
-                                Box l, r;
-                                split_tri(v, cur, axis, planes[bb + 1], l, r);
-                                if (box_ok(l)) bin_box[bb].grow(l);
-                                if (!box_ok(r)) break;
-                                cur = r;
-                                if (bb + 1 == b1) bin_box[b1].grow(r);
-                            }
+                            chop_tri(v, p.box, axis, planes, b0, b1, bin_box);
                         }
                     }
                     Box right_box[kSpatialBins];
