@@ -101,6 +101,7 @@ inline bool is_task_ref(int32_t r) { return r != kNoChild && r < -(int32_t(1) <<
 // traversal's pad) in at least one part, and the walk reaches that part's leaf (bvh.h). Duplicated references are capped
 // at kSpatialBudget of the mesh's triangles, dealt down the tree in proportion to the subtrees' sizes, so that the tree is
 // a function of the SET of triangles (any thread count, any order of the input).
+constexpr size_t kThreadedFrom = 4096;  // entries from which the subtrees are built by worker threads
 constexpr int kSpatialBins = 32;
 constexpr float kSpatialAlpha = 1e-4f;  // try a spatial split when the object split's children overlap by more than this share of the root's surface
 float spatial_budget_frac() {
@@ -541,7 +542,7 @@ struct Builder {
             for (const Prim& p : prims) all.grow(p.box);
             root_area = all.half_area();
         }
-        if (n_threads <= 1 || n_prims < 32768) {
+        if (n_threads <= 1 || n_prims < kThreadedFrom) {
             Sink sk;
             sk.nodes2.reserve(n_prims / 2 + 2);
             sk.tris.reserve(n_prims + size_t(budget) + 2);
@@ -551,7 +552,9 @@ struct Builder {
             out.n_leaves = sk.n_leaves;
             return root;
         }
-        task_grain = std::max<size_t>(4096, n_prims / (8u * n_threads));
+        // (the top of the tree, down to lists of task_grain references, is built by this thread alone: about sixteen tasks for a
+        // small mesh, lists of 4096 or an eighth of a thread's share for a large one)
+        task_grain = std::max<size_t>(std::min<size_t>(std::max<size_t>(n_prims / 16u, 512), 4096), n_prims / (8u * n_threads));
         Sink top;
         const ChildInfo top_root = build_node(top, std::move(prims), 0, true, budget);
         std::atomic<size_t> next{0};
