@@ -692,29 +692,52 @@ struct Builder {
     // The cheapest way to stand for a leaf with at most k leaves (sum of surface x count over the groups of a partition of
     // its triangles): label[i] = group of triangle i, groups numbered in order of their first triangle. Returns the cost
     // in units of surface x triangles and the number of groups.
-    static float best_partition(const LeafTris& L, int k, uint8_t label[kLeafMax], int& groups) {
-        float best = std::numeric_limits<float>::infinity();
-        uint8_t cur[kLeafMax] = {0, 0, 0, 0};
-        std::function<void(uint32_t, int)> rec = [&](uint32_t i, int used) {
-            if (i == L.count) {
-                float cost = 0.0f;
-                for (int g = 0; g < used; ++g) {
-                    Box b;
-                    b.reset();
-                    uint32_t n = 0;
-                    for (uint32_t j = 0; j < L.count; ++j)
-                        if (cur[j] == g) b.grow(L.tb[j]), ++n;
-                    cost += b.half_area() * float(n);
-                }
-                if (cost < best) {
-                    best = cost, groups = used;
-                    for (uint32_t j = 0; j < L.count; ++j) label[j] = cur[j];
-                }
-                return;
+    // (every partition of `count` triangles into at most four groups, in the order of their label strings; a group is a
+    // bit mask of triangles)
+    struct Partition {
+        uint8_t label[kLeafMax], groups, mask[4];
+    };
+    static const std::vector<Partition>& partitions_of(uint32_t count) {
+        static const std::array<std::vector<Partition>, kLeafMax + 1> all = [] {
+            std::array<std::vector<Partition>, kLeafMax + 1> t;
+            for (uint32_t c = 1; c <= uint32_t(kLeafMax); ++c) {
+                Partition cur{};
+                std::function<void(uint32_t, int)> rec = [&](uint32_t i, int used) {
+                    if (i == c) {
+                        cur.groups = uint8_t(used);
+                        for (int g = 0; g < 4; ++g) cur.mask[g] = 0;
+                        for (uint32_t j = 0; j < c; ++j) cur.mask[cur.label[j]] |= uint8_t(1u << j);
+                        t[c].push_back(cur);
+                        return;
+                    }
+                    for (int g = 0; g <= used && g < 4; ++g) cur.label[i] = uint8_t(g), rec(i + 1, std::max(used, g + 1));
+                };
+                rec(0, 0);
             }
-            for (int g = 0; g <= used && g < k; ++g) cur[i] = uint8_t(g), rec(i + 1, std::max(used, g + 1));
-        };
-        rec(0, 0);
+            return t;
+        }();
+        return all[count];
+    }
+    static float best_partition(const LeafTris& L, int k, uint8_t label[kLeafMax], int& groups) {
+        float sub[1u << kLeafMax];  // surface x count of every subset of the leaf's triangles
+        for (uint32_t m = 1; m < (1u << L.count); ++m) {
+            Box b;
+            b.reset();
+            uint32_t n = 0;
+            for (uint32_t j = 0; j < L.count; ++j)
+                if (m >> j & 1u) b.grow(L.tb[j]), ++n;
+            sub[m] = b.half_area() * float(n);
+        }
+        float best = std::numeric_limits<float>::infinity();
+        const Partition* pick = nullptr;
+        for (const Partition& q : partitions_of(L.count)) {
+            if (int(q.groups) > k) continue;
+            float cost = 0.0f;
+            for (int g = 0; g < int(q.groups); ++g) cost += sub[q.mask[g]];
+            if (cost < best) best = cost, pick = &q;
+        }
+        groups = pick ? int(pick->groups) : 1;  // (no finite cost: one group)
+        for (uint32_t j = 0; j < L.count; ++j) label[j] = pick ? pick->label[j] : uint8_t(0);
         return best;
     }
 
