@@ -814,7 +814,7 @@ struct CreateHint {
 // (2.5-3.5 % measured). A handle starts with the cheaper build and, where that was the device's, gets the host's tree
 // in the background (struct Refine); a one-shot call adds what the slower frames of ITS render would cost.
 //   entries        500   2000   8000   32000   69451   262144   871414
-//   host, ms      1.9    8.0    8.8    24.1    41.7    155.0    509.5    (build; spatial splits; threaded from 4096 entries, 16 threads)
+//   host, ms      1.9    8.0    8.8    24.0    37.2    130.7    392.1    (build; spatial splits; threaded from 4096 entries, 16 threads)
 //   device, ms    0.90   1.07   1.31    1.92    2.44     3.67     5.46   (upload + build: a dozen dependent stages, ~25 rounds in 4 batches)
 constexpr double kHostBuildSecPerTri = 4.0e-6, kHostThreadedFrom = 4096.0, kDeviceBuildSec0 = 0.9e-3, kDeviceBuildSecPerDoubling = 0.18e-3,
                  kDeviceBuildSecPerTri = 3.0e-9, kDeviceTreeSlowdown = 0.04;

@@ -102,6 +102,7 @@ inline bool is_task_ref(int32_t r) { return r != kNoChild && r < -(int32_t(1) <<
 // at kSpatialBudget of the mesh's triangles, dealt down the tree in proportion to the subtrees' sizes, so that the tree is
 // a function of the SET of triangles (any thread count, any order of the input).
 constexpr size_t kThreadedFrom = 4096;  // entries from which the subtrees are built by worker threads
+constexpr size_t kSlicedFrom = 32768;   // references from which a node of the TOP of the tree is binned in slices by helper threads
 constexpr int kSpatialBins = 32;
 constexpr float kSpatialAlpha = 1e-4f;  // try a spatial split when the object split's children overlap by more than this share of the root's surface
 float spatial_budget_frac() {
@@ -273,6 +274,45 @@ struct Builder {
         for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * p.box.lo[k] + 0.5f * p.box.hi[k];
     }
 
+    // fn(slice, begin, end) over [0, n) in `slices` contiguous slices, slice 0 on this thread, the others on threads of their own.
+    unsigned slice_threads = 1;
+    template <class F>
+    static void in_slices(size_t n, unsigned slices, F fn) {
+        if (slices <= 1u) {
+            fn(0u, size_t(0), n);
+            return;
+        }
+        const size_t per = (n + slices - 1) / slices;
+        std::vector<std::thread> th;
+        for (unsigned sl = 1; sl < slices; ++sl) th.emplace_back([&fn, sl, per, n] { fn(sl, std::min(n, sl * per), std::min(n, (sl + 1) * per)); });
+        fn(0u, size_t(0), std::min(n, per));
+        for (auto& t : th) t.join();
+    }
+
+    // Every reference of `refs` placed by `place(p, left, right)` (which appends to one list or to both), the lists in the
+    // order of the references: in slices by helper threads, the slices' lists joined in their order.
+    template <class F>
+    static void two_lists(const std::vector<Prim>& refs, unsigned slices, size_t n_left, size_t n_right, F place, std::vector<Prim>& left,
+                          std::vector<Prim>& right) {
+        if (slices <= 1u) {
+            left.reserve(n_left), right.reserve(n_right);
+            for (const Prim& p : refs) place(p, left, right);
+            return;
+        }
+        std::vector<std::vector<Prim>> ls(slices), rs(slices);
+        in_slices(refs.size(), slices, [&](unsigned sl, size_t i0, size_t i1) {
+            ls[sl].reserve((i1 - i0) / 2 + 16), rs[sl].reserve((i1 - i0) / 2 + 16);
+            for (size_t i = i0; i < i1; ++i) place(refs[i], ls[sl], rs[sl]);
+        });
+        size_t nl = 0, nr = 0;
+        for (unsigned sl = 0; sl < slices; ++sl) nl += ls[sl].size(), nr += rs[sl].size();
+        left.reserve(nl), right.reserve(nr);
+        for (unsigned sl = 0; sl < slices; ++sl) {
+            left.insert(left.end(), ls[sl].begin(), ls[sl].end()), right.insert(right.end(), rs[sl].begin(), rs[sl].end());
+            std::vector<Prim>().swap(ls[sl]), std::vector<Prim>().swap(rs[sl]);
+        }
+    }
+
     // `top`: this call belongs to the single-threaded top of the tree; lists of at most task_grain references are not
     // built here but queued as tasks (a placeholder ref is returned). `budget`: references this subtree may still add.
     ChildInfo build_node(Sink& sk, std::vector<Prim> refs, int depth, bool top, int64_t budget) {
@@ -298,46 +338,73 @@ struct Builder {
         if (cancelled()) return make_leaf(sk, refs, 1, box, max_e12);  // (memory-safe nonsense: the result is thrown away)
 
         // ---- object split: binned SAH over the three axes (centroids of the references' boxes) ----
+        // (both binnings are sums over the references of boxes grown and counts: at the top of a large tree, where one
+        // thread works alone, they are done in slices by helper threads and added up -- the same bins whatever the slicing)
+        const unsigned slices = top && count >= kSlicedFrom ? std::min<unsigned>(slice_threads, unsigned(count / 4096)) : 1u;
         const float parent_area = box.half_area();
         float best_cost = std::numeric_limits<float>::infinity();
         int best_axis = -1, best_split = -1;
         Box best_lbox, best_rbox;
         best_lbox.reset(), best_rbox.reset();
-        for (int axis = 0; axis < 3; ++axis) {
-            const float cmin = cbox.lo[axis], cext = cbox.hi[axis] - cbox.lo[axis];
-            if (!(cext > 0.0f)) continue;
-            const float scale = float(kBins) / cext;
-            Box bin_box[kBins];
-            uint32_t bin_cnt[kBins] = {0};
-            for (auto& bb : bin_box) bb.reset();
-            for (const Prim& p : refs) {
-                int bi = std::min(kBins - 1, std::max(0, int((p.c[axis] - cmin) * scale)));
-                bin_box[bi].grow(p.box);
-                ++bin_cnt[bi];
+        {
+            struct ObjBins {
+                Box box[3][kBins];
+                uint32_t cnt[3][kBins];
+            };
+            float cmin[3], scale[3];
+            bool axis_ok[3];
+            for (int axis = 0; axis < 3; ++axis) {
+                const float cext = cbox.hi[axis] - cbox.lo[axis];
+                axis_ok[axis] = cext > 0.0f;
+                cmin[axis] = cbox.lo[axis], scale[axis] = axis_ok[axis] ? float(kBins) / cext : 0.0f;
             }
-            Box right_box[kBins];
-            uint32_t right_cnt[kBins];
-            Box acc;
-            acc.reset();
-            uint32_t n = 0;
-            for (int i = kBins - 1; i > 0; --i) {
-                acc.grow(bin_box[i]);
-                n += bin_cnt[i];
-                right_box[i] = acc;
-                right_cnt[i] = n;
-            }
-            acc.reset();
-            n = 0;
-            for (int i = 1; i < kBins; ++i) {  // split = first bin of the right side
-                acc.grow(bin_box[i - 1]);
-                n += bin_cnt[i - 1];
-                if (n == 0 || right_cnt[i] == 0) continue;
-                float cost = acc.half_area() * float(n) + right_box[i].half_area() * float(right_cnt[i]);
-                if (cost < best_cost) {
-                    best_cost = cost;
-                    best_axis = axis;
-                    best_split = i;
-                    best_lbox = acc, best_rbox = right_box[i];
+            std::vector<ObjBins> part(slices);
+            in_slices(count, slices, [&](unsigned sl, size_t i0, size_t i1) {
+                ObjBins& B = part[sl];
+                for (int axis = 0; axis < 3; ++axis)
+                    for (int i = 0; i < kBins; ++i) B.box[axis][i].reset(), B.cnt[axis][i] = 0;
+                for (size_t i = i0; i < i1; ++i) {
+                    const Prim& p = refs[i];
+                    for (int axis = 0; axis < 3; ++axis) {
+                        if (!axis_ok[axis]) continue;
+                        const int bi = std::min(kBins - 1, std::max(0, int((p.c[axis] - cmin[axis]) * scale[axis])));
+                        B.box[axis][bi].grow(p.box);
+                        ++B.cnt[axis][bi];
+                    }
+                }
+            });
+            ObjBins& B = part[0];
+            for (unsigned sl = 1; sl < slices; ++sl)
+                for (int axis = 0; axis < 3; ++axis)
+                    for (int i = 0; i < kBins; ++i) B.box[axis][i].grow(part[sl].box[axis][i]), B.cnt[axis][i] += part[sl].cnt[axis][i];
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!axis_ok[axis]) continue;
+                const Box* bin_box = B.box[axis];
+                const uint32_t* bin_cnt = B.cnt[axis];
+                Box right_box[kBins];
+                uint32_t right_cnt[kBins];
+                Box acc;
+                acc.reset();
+                uint32_t n = 0;
+                for (int i = kBins - 1; i > 0; --i) {
+                    acc.grow(bin_box[i]);
+                    n += bin_cnt[i];
+                    right_box[i] = acc;
+                    right_cnt[i] = n;
+                }
+                acc.reset();
+                n = 0;
+                for (int i = 1; i < kBins; ++i) {  // split = first bin of the right side
+                    acc.grow(bin_box[i - 1]);
+                    n += bin_cnt[i - 1];
+                    if (n == 0 || right_cnt[i] == 0) continue;
+                    float cost = acc.half_area() * float(n) + right_box[i].half_area() * float(right_cnt[i]);
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = axis;
+                        best_split = i;
+                        best_lbox = acc, best_rbox = right_box[i];
+                    }
                 }
             }
         }
@@ -351,29 +418,56 @@ struct Builder {
             Box ov;
             for (int k = 0; k < 3; ++k) ov.lo[k] = std::max(best_lbox.lo[k], best_rbox.lo[k]), ov.hi[k] = std::min(best_lbox.hi[k], best_rbox.hi[k]);
             if (box_ok(ov) && ov.half_area() > kSpatialAlpha * root_area) {
+                struct SpBins {
+                    Box box[3][kSpatialBins];
+                    uint32_t enter[3][kSpatialBins], leave[3][kSpatialBins];
+                };
+                float lo3[3], scale[3], planes[3][kSpatialBins + 1];
+                bool axis_ok[3];
                 for (int axis = 0; axis < 3; ++axis) {
                     const float lo = box.lo[axis], ext = box.hi[axis] - box.lo[axis];
-                    if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
-                    const float scale = float(kSpatialBins) / ext;
-                    float planes[kSpatialBins + 1];
-                    for (int j = 0; j <= kSpatialBins; ++j) planes[j] = j == kSpatialBins ? box.hi[axis] : lo + ext * (float(j) / float(kSpatialBins));
-                    Box bin_box[kSpatialBins];
-                    uint32_t enter[kSpatialBins] = {0}, leave[kSpatialBins] = {0};
-                    for (auto& bb : bin_box) bb.reset();
-                    for (const Prim& p : refs) {
-                        int b0 = std::min(kSpatialBins - 1, std::max(0, int((p.box.lo[axis] - lo) * scale)));
-                        int b1 = std::min(kSpatialBins - 1, std::max(b0, int((p.box.hi[axis] - lo) * scale)));
-                        while (b1 > b0 && p.box.hi[axis] <= planes[b1]) --b1;      // (a box that ends ON a plane is not beyond it)
-                        while (b0 < b1 && p.box.lo[axis] >= planes[b0 + 1]) ++b0;
-                        ++enter[b0], ++leave[b1];
-                        if (b0 == b1) {
-                            bin_box[b0].grow(p.box);
-                        } else {  // chopped into the bins it crosses
-                            float v[3][3];
-                            corners(p.src, v);
-                            chop_tri(v, p.box, axis, planes, b0, b1, bin_box);
+                    axis_ok[axis] = ext > 0.0f && std::isfinite(ext);
+                    lo3[axis] = lo, scale[axis] = axis_ok[axis] ? float(kSpatialBins) / ext : 0.0f;
+                    for (int j = 0; j <= kSpatialBins; ++j) planes[axis][j] = j == kSpatialBins ? box.hi[axis] : lo + ext * (float(j) / float(kSpatialBins));
+                }
+                std::vector<SpBins> part(slices);
+                in_slices(count, slices, [&](unsigned sl, size_t i0, size_t i1) {
+                    SpBins& S = part[sl];
+                    for (int axis = 0; axis < 3; ++axis)
+                        for (int i = 0; i < kSpatialBins; ++i) S.box[axis][i].reset(), S.enter[axis][i] = S.leave[axis][i] = 0;
+                    for (size_t i = i0; i < i1; ++i) {
+                        const Prim& p = refs[i];
+                        float v[3][3];
+                        bool have_v = false;
+                        for (int axis = 0; axis < 3; ++axis) {
+                            if (!axis_ok[axis]) continue;
+                            const float* pl = planes[axis];
+                            int b0 = std::min(kSpatialBins - 1, std::max(0, int((p.box.lo[axis] - lo3[axis]) * scale[axis])));
+                            int b1 = std::min(kSpatialBins - 1, std::max(b0, int((p.box.hi[axis] - lo3[axis]) * scale[axis])));
+                            while (b1 > b0 && p.box.hi[axis] <= pl[b1]) --b1;      // (a box that ends ON a plane is not beyond it)
+                            while (b0 < b1 && p.box.lo[axis] >= pl[b0 + 1]) ++b0;
+                            ++S.enter[axis][b0], ++S.leave[axis][b1];
+                            if (b0 == b1) {
+                                S.box[axis][b0].grow(p.box);
+                            } else {  // chopped into the bins it crosses
+                                if (!have_v) corners(p.src, v), have_v = true;
+                                chop_tri(v, p.box, axis, pl, b0, b1, S.box[axis]);
+                            }
                         }
                     }
+                });
+                SpBins& S = part[0];
+                for (unsigned sl = 1; sl < slices; ++sl)
+                    for (int axis = 0; axis < 3; ++axis)
+                        for (int i = 0; i < kSpatialBins; ++i) {
+                            S.box[axis][i].grow(part[sl].box[axis][i]);
+                            S.enter[axis][i] += part[sl].enter[axis][i], S.leave[axis][i] += part[sl].leave[axis][i];
+                        }
+                for (int axis = 0; axis < 3; ++axis) {
+                    if (!axis_ok[axis]) continue;
+                    const Box* bin_box = S.box[axis];
+                    const uint32_t *enter = S.enter[axis], *leave = S.leave[axis];
+                    const float* pl = planes[axis];
                     Box right_box[kSpatialBins];
                     uint32_t right_cnt[kSpatialBins];
                     Box acc;
@@ -391,7 +485,7 @@ struct Builder {
                         n += enter[i - 1];
                         if (n == 0 || right_cnt[i] == 0 || n == count || right_cnt[i] == count) continue;
                         const float cost = acc.half_area() * float(n) + right_box[i].half_area() * float(right_cnt[i]);
-                        if (cost < sp_cost) sp_cost = cost, sp_axis = axis, sp_plane = planes[i], sp_lbox = acc, sp_rbox = right_box[i], sp_nl = n, sp_nr = right_cnt[i];
+                        if (cost < sp_cost) sp_cost = cost, sp_axis = axis, sp_plane = pl[i], sp_lbox = acc, sp_rbox = right_box[i], sp_nl = n, sp_nr = right_cnt[i];
                     }
                 }
             }
@@ -407,9 +501,8 @@ struct Builder {
         if (sp_axis >= 0 && sp_cost < best_cost) {
             // ---- partition by the plane; a reference that crosses it goes to both sides with the boxes of its parts, unless
             // keeping it whole on one side is cheaper (judged against the sides the sweep found: the same for every order) ----
-            left.reserve(sp_nl), right.reserve(sp_nr);
             const float a_l = sp_lbox.half_area(), a_r = sp_rbox.half_area();
-            for (const Prim& p : refs) {
+            const auto place = [&](const Prim& p, std::vector<Prim>& left, std::vector<Prim>& right) {
                 if (p.box.hi[sp_axis] <= sp_plane) {
                     left.push_back(p);
                 } else if (p.box.lo[sp_axis] >= sp_plane) {
@@ -434,7 +527,8 @@ struct Builder {
                         left.push_back(pl), right.push_back(pr);
                     }
                 }
-            }
+            };
+            two_lists(refs, slices, sp_nl, sp_nr, place, left, right);
             used = int64_t(left.size() + right.size()) - int64_t(count);
             if (left.empty() || right.empty() || left.size() == count || right.size() == count || used > budget || left.size() > cap ||
                 right.size() > cap)
@@ -445,13 +539,15 @@ struct Builder {
             if (best_axis >= 0) {
                 const float cmin = cbox.lo[best_axis];
                 const float scale = float(kBins) / (cbox.hi[best_axis] - cbox.lo[best_axis]);
-                auto it = std::partition(refs.begin(), refs.end(), [&](const Prim& p) {
-                    int bi = std::min(kBins - 1, std::max(0, int((p.c[best_axis] - cmin) * scale)));
-                    return bi < best_split;
-                });
-                mid = size_t(it - refs.begin());
+                const auto place = [&](const Prim& p, std::vector<Prim>& l, std::vector<Prim>& r) {
+                    const int bi = std::min(kBins - 1, std::max(0, int((p.c[best_axis] - cmin) * scale)));
+                    (bi < best_split ? l : r).push_back(p);
+                };
+                two_lists(refs, slices, 0, 0, place, left, right);
+                mid = left.size();
+                if (mid == 0 || mid == count || mid > cap || (count - mid) > cap) left.clear(), right.clear();
             }
-            if (mid == 0 || mid == count || mid > cap || (count - mid) > cap) {
+            if (left.empty()) {
                 // degenerate or too unbalanced for the depth budget: median split along the widest axis
                 int axis = 0;
                 for (int k = 1; k < 3; ++k)
@@ -460,9 +556,9 @@ struct Builder {
                 std::nth_element(refs.begin(), refs.begin() + mid, refs.end(), [axis](const Prim& x, const Prim& y) {
                     return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
                 });
+                left.assign(refs.begin(), refs.begin() + mid);
+                right.assign(refs.begin() + mid, refs.end());
             }
-            left.assign(refs.begin(), refs.begin() + mid);
-            right.assign(refs.begin() + mid, refs.end());
         }
         std::vector<Prim>().swap(refs);  // (the list is in its two halves now)
         const int64_t rest = std::max<int64_t>(0, budget - used);
@@ -555,6 +651,7 @@ struct Builder {
         // (the top of the tree, down to lists of task_grain references, is built by this thread alone: about sixteen tasks for a
         // small mesh, lists of 4096 or an eighth of a thread's share for a large one)
         task_grain = std::max<size_t>(std::min<size_t>(std::max<size_t>(n_prims / 16u, 512), 4096), n_prims / (8u * n_threads));
+        slice_threads = n_threads;
         Sink top;
         const ChildInfo top_root = build_node(top, std::move(prims), 0, true, budget);
         std::atomic<size_t> next{0};
