@@ -814,7 +814,7 @@ struct CreateHint {
 // (2.5-3.5 % measured). A handle starts with the cheaper build and, where that was the device's, gets the host's tree
 // in the background (struct Refine); a one-shot call adds what the slower frames of ITS render would cost.
 //   entries        500   2000   8000   32000   69451   262144   871414
-//   host, ms      1.9    8.0    8.8    24.0    37.2    130.7    392.1    (build; spatial splits; threaded from 4096 entries, 16 threads)
+//   host, ms      1.9    8.0    6.6    18.7    31.7    104.7    310.0    (build; spatial splits; threaded from 4096 entries, 16 threads)
 //   device, ms    0.90   1.07   1.31    1.92    2.44     3.67     5.46   (upload + build: a dozen dependent stages, ~25 rounds in 4 batches)
 constexpr double kHostBuildSecPerTri = 4.0e-6, kHostThreadedFrom = 4096.0, kDeviceBuildSec0 = 0.9e-3, kDeviceBuildSecPerDoubling = 0.18e-3,
                  kDeviceBuildSecPerTri = 3.0e-9, kDeviceTreeSlowdown = 0.04;
@@ -822,7 +822,7 @@ bool device_builder_is_cheaper(uint32_t n_total, const CreateHint& hint) {
     const double n = double(n_total);
     const double threads = double(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
     // (the top of the host's tree is built by one thread)
-    const double host_s = kHostBuildSecPerTri * n * (n < kHostThreadedFrom ? 1.0 : 0.08 + 1.0 / threads);
+    const double host_s = kHostBuildSecPerTri * n * (n < kHostThreadedFrom ? 1.0 : 0.06 + 0.9 / threads);
     const double device_s = kDeviceBuildSec0 + kDeviceBuildSecPerDoubling * std::log2(std::max(n, 500.0) / 500.0) + kDeviceBuildSecPerTri * n +
                             (hint.one_shot ? kDeviceTreeSlowdown * hint.render_s_est : 0.0);
     return n_total >= 8u && device_s < host_s;

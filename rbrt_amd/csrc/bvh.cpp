@@ -104,6 +104,7 @@ inline bool is_task_ref(int32_t r) { return r != kNoChild && r < -(int32_t(1) <<
 constexpr size_t kThreadedFrom = 4096;  // entries from which the subtrees are built by worker threads
 constexpr size_t kSlicedFrom = 32768;   // references from which a node of the TOP of the tree is binned in slices by helper threads
 constexpr int kSpatialBins = 32;
+constexpr int kSpatialLostRun = 5;
 constexpr float kSpatialAlpha = 1e-4f;  // try a spatial split when the object split's children overlap by more than this share of the root's surface
 float spatial_budget_frac() {
     static const float v = [] {
@@ -127,6 +128,7 @@ struct Builder {
         std::vector<Prim> refs;
         int depth;
         int64_t budget;
+        int lost;
         Sink sink;
         ChildInfo root;
     };
@@ -315,10 +317,10 @@ struct Builder {
 
     // `top`: this call belongs to the single-threaded top of the tree; lists of at most task_grain references are not
     // built here but queued as tasks (a placeholder ref is returned). `budget`: references this subtree may still add.
-    ChildInfo build_node(Sink& sk, std::vector<Prim> refs, int depth, bool top, int64_t budget) {
+    ChildInfo build_node(Sink& sk, std::vector<Prim> refs, int depth, bool top, int64_t budget, int lost = 0) {
         const size_t count = refs.size();
         if (top && count <= task_grain) {
-            tasks.push_back(Task{std::move(refs), depth, budget, Sink(), ChildInfo()});
+            tasks.push_back(Task{std::move(refs), depth, budget, lost, Sink(), ChildInfo()});
             ChildInfo c;
             c.ref = kTaskRefBase + int32_t(tasks.size() - 1);
             c.box.reset();
@@ -414,10 +416,16 @@ struct Builder {
         Box sp_lbox, sp_rbox;
         uint32_t sp_nl = 0, sp_nr = 0;
         sp_lbox.reset(), sp_rbox.reset();
-        if (budget > 0 && count > size_t(kLeafMax) && best_axis >= 0 && parent_area > 0.0f && root_area > 0.0f) {
+        // (`lost`: how many nodes in a row, up the path to this one, tried a spatial split and kept the object split: after
+        // kSpatialLostRun of them the subtree is taken to be one where cutting triangles does not pay -- a property of the path,
+        // so of the set of triangles. A smooth mesh is then binned spatially on its top levels only: build 90 -> 58 ms for the
+        // bunny stand-in with the SAH cost within 0.05 %, the rough stand-in's tree unchanged)
+        bool sp_tried = false;
+        if (lost < kSpatialLostRun && budget > 0 && count > size_t(kLeafMax) && best_axis >= 0 && parent_area > 0.0f && root_area > 0.0f) {
             Box ov;
             for (int k = 0; k < 3; ++k) ov.lo[k] = std::max(best_lbox.lo[k], best_rbox.lo[k]), ov.hi[k] = std::min(best_lbox.hi[k], best_rbox.hi[k]);
             if (box_ok(ov) && ov.half_area() > kSpatialAlpha * root_area) {
+                sp_tried = true;
                 struct SpBins {
                     Box box[3][kSpatialBins];
                     uint32_t enter[3][kSpatialBins], leave[3][kSpatialBins];
@@ -570,8 +578,9 @@ struct Builder {
         const int64_t b_left = w_l + w_r > 0.0 ? int64_t(double(rest) * (w_l / (w_l + w_r))) : rest / 2;
         const uint32_t node = uint32_t(sk.nodes2.size());
         sk.nodes2.emplace_back();
-        ChildInfo l = build_node(sk, std::move(left), depth + 1, top, b_left);
-        ChildInfo r = build_node(sk, std::move(right), depth + 1, top, rest - b_left);
+        const int lost_next = used > 0 ? 0 : sp_tried ? lost + 1 : lost;
+        ChildInfo l = build_node(sk, std::move(left), depth + 1, top, b_left, lost_next);
+        ChildInfo r = build_node(sk, std::move(right), depth + 1, top, rest - b_left, lost_next);
         set_node(sk.nodes2, node, l, r);
         return ChildInfo{int32_t(node), box, max_e12};
     }
@@ -658,7 +667,7 @@ struct Builder {
         auto worker = [&]() {
             for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
                 Task& t = tasks[k];
-                t.root = build_node(t.sink, std::move(t.refs), t.depth, false, t.budget);  // disjoint lists: no sharing
+                t.root = build_node(t.sink, std::move(t.refs), t.depth, false, t.budget, t.lost);  // disjoint lists: no sharing
             }
         };
         std::vector<std::thread> pool;
