@@ -22,7 +22,7 @@ namespace rbrt {
 // The host builder may reference a triangle from more than one leaf (spatial splits, bvh.cpp): at most kSpatialBudget
 // duplicated references per indexed triangle. A mesh of n_total entries never needs more than bvh_record_capacity records
 // (the scan-visible entries, their duplicates, one dummy record of a degenerate tree).
-constexpr float kSpatialBudget = 0.30f;
+constexpr float kSpatialBudget = 0.60f;
 inline uint64_t bvh_record_capacity(uint32_t n_total) {
     const uint64_t n_tested = uint64_t(n_total / 8u) * 8u;
     return n_tested + uint64_t(double(kSpatialBudget) * double(n_tested)) + 2u;
