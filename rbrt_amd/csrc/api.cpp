@@ -143,6 +143,7 @@ struct rbrt_hip_scene {
     // caller's stream.
     struct Lane {
         hipStream_t stream = nullptr;  // null: the caller's stream (pipeline == 1)
+        int stream_pool_key = -1;      // >= 0: the stream came from the process's pool of one-shot lane streams and goes back to it
         // ONE sample buffer + work counters per lane, and the lane's next launch waits for the resolve of its previous one.
         // (Round 4 gave every lane a second set, taken in turn, so that the next launch could start the moment the previous
         // one ended instead of 90-120 us later -- resolve and background kernel on the caller's stream, a cross-stream hop
@@ -564,6 +565,26 @@ uint32_t list_mode_for(const rbrt_hip_scene* s, bool overlapped) {
     return overlapped ? 0u : s->isolated_list_mode;
 }
 
+// The lane streams of ONE-SHOT scenes (rbrt_hip_render: a scene made for one render and destroyed) are kept by the process and
+// handed from call to call: creating and destroying a stream costs each call 0.3-0.4 ms of its 9. Keyed by device and priority;
+// a stream goes back idle (rbrt_hip_scene_destroy synchronises the device first) and is never destroyed.
+std::mutex g_stream_pool_mu;
+std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+hipStream_t take_pooled_stream(int key) {
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); ++i)
+        if (g_stream_pool[i].first == key) {
+            const hipStream_t st = g_stream_pool[i].second;
+            g_stream_pool.erase(g_stream_pool.begin() + long(i));
+            return st;
+        }
+    return nullptr;
+}
+void give_pooled_stream(int key, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    g_stream_pool.emplace_back(key, st);
+}
+
 // Brings s->lanes to `depth` entries (streams, events, counters and per-wave scratch of each lane).
 int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
     const size_t had = s->lanes.size();
@@ -593,7 +614,12 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         int prio_low = 0, prio_high = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: low >= high)
         if (const char* pe = lab_env("RBRT_LANE_PRIORITY")) prio_low = !std::strcmp(pe, "default") ? 0 : !std::strcmp(pe, "high") ? prio_high : prio_low;
-        hipError_t e = hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, prio_low);
+        hipError_t e = hipSuccess;
+        if (s->one_shot) {
+            R.stream_pool_key = s->device * 64 + (prio_low & 63);
+            R.stream = take_pooled_stream(R.stream_pool_key);
+        }
+        if (!R.stream) e = hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, prio_low);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_helper, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_carried, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&R.ev_ready, hipEventDisableTiming);
@@ -601,7 +627,8 @@ int ensure_lanes(rbrt_hip_scene* s, uint32_t depth) {
         for (auto& B : R.bufs)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&B.ev_resolved, hipEventDisableTiming);
         if (e != hipSuccess) {
-            if (R.stream) (void)hipStreamDestroy(R.stream);
+            if (R.stream && R.stream_pool_key >= 0) give_pooled_stream(R.stream_pool_key, R.stream);
+            else if (R.stream) (void)hipStreamDestroy(R.stream);
             if (R.ev_helper) (void)hipEventDestroy(R.ev_helper);
             if (R.ev_carried) (void)hipEventDestroy(R.ev_carried);
             if (R.ev_ready) (void)hipEventDestroy(R.ev_ready);
@@ -1230,7 +1257,8 @@ int rbrt_hip_scene_destroy(rbrt_hip_scene_t* s) {
     const double td1 = now_s();
     double t_big = 0.0;
     for (auto& L : s->lanes) {
-        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.stream && L.stream_pool_key >= 0) give_pooled_stream(L.stream_pool_key, L.stream);  // (idle: the device was synchronised above)
+        else if (L.stream) (void)hipStreamDestroy(L.stream);
         if (L.ev_helper) (void)hipEventDestroy(L.ev_helper);
         if (L.ev_carried) (void)hipEventDestroy(L.ev_carried);
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
