@@ -29,6 +29,7 @@
  *   RBRT_HELPERS=0|1|2           helper launches (elastic launches): never, by the watcher (1), one with every overlapped launch (tests)
  *   RBRT_HELPER_MIN_ITEMS=<n>    a helper wave joins only while n work items per wave are left (4096); RBRT_HELPER_ROUNDS=1..16 (4)
  *   RBRT_HELPER_MIN_LAUNCH_MI=<n> launches of n Mi work items or more get helper launches (16: smaller ones came out 1 % slower)
+ *   RBRT_HELPER_MIN_FREE=1..16    helper launches only while this many wave slots per CU are free (1)
  *   RBRT_BVH_SPATIAL=0..0.6      the host builder's budget of duplicated references (spatial splits), as a share of the triangles
  *   RBRT_TRACE_CREATE=1          one stderr line per rbrt_hip_scene_create: where its time went
  */

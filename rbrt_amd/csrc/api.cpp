@@ -218,6 +218,7 @@ struct rbrt_hip_scene {
     // process (profiles/r05_helpers_threshold_sweep.txt), median / worst ms per step: no helpers 3.582 / 3.631; 1536: 3.506 /
     // 3.813 (three rounds of ten WORSE than without: late joiners turn bulk into drain); 4096: 3.513 / 3.544; 8192: 3.536 / 3.578
     uint32_t helper_min_items = 4096;
+    uint32_t helper_min_free_per_cu = 1;  // RBRT_HELPER_MIN_FREE (lab): helper launches only while this many wave slots per CU are free
     uint32_t helper_min_launch_mi = 16;  // RBRT_HELPER_MIN_LAUNCH_MI (lab): launches of this many Mi work items or more are helped
     uint32_t helper_rounds = 4;        // RBRT_HELPER_ROUNDS (lab)
     hipStream_t prep_stream = nullptr;  // high priority: the tile passes of cameras the lanes have not seen
@@ -719,7 +720,7 @@ void watcher_main(rbrt_hip_scene* s) {
         }
         if (n_open == 0u || carriers.empty() || now_s() - s->last_call_s < 200e-6) continue;
         const uint32_t free_waves = s->n_waves > resident ? s->n_waves - resident : 0u;
-        if (free_waves < s->n_cus) continue;
+        if (free_waves < s->n_cus * s->helper_min_free_per_cu) continue;
         // The free slots go to the launch issued LAST first (it has the most work left: of the launches of a stream's end the
         // last one otherwise ends alone, a frame's time after the others), up to what its scratch holds, then to the one before.
         std::vector<rbrt_hip_scene::Lane*> open_lanes;
@@ -1163,7 +1164,7 @@ int scene_create_impl(const rbrt_scene_t* scene, int device, rbrt_hip_scene_t** 
             lab_u32("RBRT_OVERLAP_WAVES_PER_CU", 0, 16, s->overlap_waves_per_cu, err) &&
             lab_u32("RBRT_TILE_ISOLATED_MODE", 0, 4, s->isolated_list_mode, err) && lab_u32("RBRT_TILE_TAIL_DIV", 1, 1024, s->tile_tail_div, err) &&
             lab_u32("RBRT_HELPERS", 0, 2, s->helpers_mode, err) && lab_u32("RBRT_HELPER_MIN_ITEMS", 1, 1 << 24, s->helper_min_items, err) &&
-            lab_u32("RBRT_HELPER_MIN_LAUNCH_MI", 0, 4096, s->helper_min_launch_mi, err) &&
+            lab_u32("RBRT_HELPER_MIN_LAUNCH_MI", 0, 4096, s->helper_min_launch_mi, err) && lab_u32("RBRT_HELPER_MIN_FREE", 1, 16, s->helper_min_free_per_cu, err) &&
             lab_u32("RBRT_HELPER_ROUNDS", 1, 16, s->helper_rounds, err);
         if (!knobs_ok) return bail(fail(RBRT_ERR_INVALID_ARG, err));
         s->tile_classes_set = lab_env("RBRT_TILE_CLASSES") != nullptr;
